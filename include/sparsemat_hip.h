@@ -1,0 +1,188 @@
+/*
+ * sparsemat_hip.h -- C ABI of libsparsemat_hip.so: the MI355X (gfx950) drop-in for the
+ * CSR SpMV / BLAS-1 / CG hot path of the Rust crate lostinc0de/sparsemat.
+ *
+ * The host (Rust, C++ or Python) OWNS the CRS arrays; this library copies them to HBM
+ * (or borrows device arrays the host already placed there) and runs hand-written HIP
+ * kernels.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with
+ * SMH_ERR_NO_DEVICE.
+ *
+ * Conventions
+ *   - every function returns an int status (SMH_OK == 0); a message for the calling
+ *     thread's last failure is available from smh_last_error().  Nothing ever
+ *     unwinds/throws across the ABI: the Rust shim turns a non-zero status into the
+ *     reference's panic text.
+ *   - host arrays are borrowed for the duration of the call only.
+ *   - value type T is f32 or f64 (smh_dtype); index type I is u32 (the reference's
+ *     SparseMatCRS<T,u32>; other index widths stay on the reference's CPU path).
+ *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (as void*, may be
+ *     NULL = the handle's own stream) and are asynchronous; the others synchronise.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef SPARSEMAT_HIP_H
+#define SPARSEMAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMH_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------ */
+enum {
+    SMH_OK = 0,
+    SMH_ERR_DIM_MISMATCH = 1,  /* "Dimension mismatch" densevec.rs:53,62; "Matrix and vector size mismatch" linearsolver.rs:35 */
+    SMH_ERR_NOT_SQUARE = 2,    /* "Matrix is not symmetric" linearsolver.rs:31 */
+    SMH_ERR_INDEX_RANGE = 3,   /* a column index >= x.dim(): the implicit slice panic of densevec.rs:41 */
+    SMH_ERR_INVALID = 4,       /* malformed CRS arrays / bad argument / misaligned device pointer */
+    SMH_ERR_HIP = 5,           /* a HIP runtime call failed (message carries hipGetErrorString) */
+    SMH_ERR_OOM = 6,           /* hipMalloc failed */
+    SMH_ERR_NO_DEVICE = 7,     /* no HIP device: there is no CPU fallback */
+    SMH_ERR_CAPACITY = 8       /* nnz >= u32::MAX: "Maximum number of {} entries reached" sparsemat_crs.rs:82-84 */
+};
+
+typedef enum { SMH_F32 = 0, SMH_F64 = 1 } smh_dtype;
+
+/* SpMV kernel families (DESIGN.md "Kernels") */
+typedef enum {
+    SMH_SPMV_AUTO = 0,   /* pick from the row-length statistics taken at create time        */
+    SMH_SPMV_VECTOR = 1, /* K1: (sub-)wavefront per row, 16-B coalesced chunks, shfl reduce  */
+    SMH_SPMV_MERGE = 2,  /* K2: merge-path tiles, LDS-staged products, deterministic fix-up  */
+    SMH_SPMV_SEQ = 3     /* one lane per row, storage order, mul then add: bit-exact vs the */
+                         /* reference loop sparsematrix.rs:146-158 (checker, not fast)      */
+} smh_spmv_variant;
+
+typedef struct smh_crs smh_crs; /* device-resident SparseMatCRS<T,u32>  (sparsemat_crs.rs:9-17) */
+typedef struct smh_vec smh_vec; /* device-resident DenseVec<T>          (densevec.rs:5-7)      */
+
+/* ---- library / device --------------------------------------------------------------- */
+int smh_abi_version(void);
+const char *smh_last_error(void);            /* thread-local, never NULL */
+const char *smh_status_string(int status);   /* the reference's panic text for a status */
+int smh_device_count(int *count_out);        /* 0 devices is SMH_OK with *count_out == 0 */
+int smh_set_device(int device);              /* device used by handles created afterwards (per thread) */
+int smh_device_synchronize(void);
+
+/* ---- SparseMatCRS<T,u32> --------------------------------------------------------------
+ * smh_crs_create: replaces building a SparseMatCRS (fields sparsemat_crs.rs:9-17; the
+ * only bulk constructor, from_sparsemat_index :24-50, is pub(crate)): copies
+ * offset_rows[n_rows+1], columns[nnz], values[nnz] to HBM.  Columns of a row are taken in
+ * storage order, unsorted and with duplicates allowed, exactly as iter_row (:102-110)
+ * yields them.  Monotone offsets, offset_rows[0]==0 and offset_rows[n_rows]==nnz are always
+ * checked (on the device); validate != 0 additionally requires columns < n_cols.          */
+int smh_crs_create(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz,
+                   const uint32_t *offset_rows, const uint32_t *columns, const void *values,
+                   int validate, smh_crs **out);
+/* Same, over arrays that already live in device memory (borrowed, not copied, must outlive
+ * the handle; columns/values 16-byte aligned).  device = ordinal owning the pointers.   */
+int smh_crs_create_dev(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz,
+                       const uint32_t *offset_rows_dev, const uint32_t *columns_dev,
+                       const void *values_dev, int validate, smh_crs **out);
+int smh_crs_destroy(smh_crs *m);
+int smh_crs_update_values(smh_crs *m, const void *values_host); /* host mutated values: re-upload */
+int smh_crs_download(const smh_crs *m, uint32_t *offset_rows, uint32_t *columns, void *values);
+/* n_rows :124-126, n_cols :128-130, n_non_zero_entries :132-134 */
+size_t smh_crs_n_rows(const smh_crs *m);
+size_t smh_crs_n_cols(const smh_crs *m);
+size_t smh_crs_nnz(const smh_crs *m);
+int smh_crs_dtype(const smh_crs *m);
+int smh_crs_max_row_len(const smh_crs *m, uint32_t *out);
+/* SparseMatrix::scale (sparsemat_crs.rs:153-157): values *= a */
+int smh_crs_scale(smh_crs *m, double a);
+/* variant AUTO resolves to; lanes_out = lanes per row of the VECTOR kernel */
+int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out);
+/* override the VECTOR kernel's lanes-per-row (1,2,4,...,64; 0 = automatic) */
+int smh_crs_set_vector_lanes(smh_crs *m, int lanes);
+
+/* SparseMatrix::mvp (sparsematrix.rs:146-158) == `A * v` (Mul, sparsematrix.rs:435-443):
+ * y[0..n_rows) = A.x.  x_len is x.dim(); a column index >= x_len is SMH_ERR_INDEX_RANGE
+ * (the reference panics in densevec.rs:41).  y has exactly n_rows entries (ret.set grows
+ * it one row at a time, vector.rs:40-42 / densevec.rs:44-49); empty rows give 0.        */
+int smh_crs_spmv(smh_crs *m, const void *x_host, size_t x_len, void *y_host, int variant);
+int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant,
+                     void *stream);
+/* merge-path tile table (integer structure, checked bit-exact in tests): tile t starts at
+ * (row_out[t], nnz_out[t]); arrays need smh_crs_merge_tiles()+1 entries.                 */
+size_t smh_crs_merge_tiles(const smh_crs *m);
+size_t smh_crs_merge_tile_items(const smh_crs *m);
+int smh_crs_merge_table(smh_crs *m, uint32_t *row_out, uint32_t *nnz_out);
+
+/* ---- DenseVec<T> ------------------------------------------------------------------------
+ * Vector::with_capacity/from_vec (densevec.rs:24-34), dim (:36-38), iter (:20-22)      */
+int smh_vec_create(smh_dtype dtype, size_t n, smh_vec **out);                  /* zeros */
+int smh_vec_from_host(smh_dtype dtype, size_t n, const void *host, smh_vec **out);
+int smh_vec_wrap_dev(smh_dtype dtype, size_t n, void *dev_ptr, smh_vec **out); /* borrowed */
+int smh_vec_destroy(smh_vec *v);
+int smh_vec_upload(smh_vec *v, const void *host);
+int smh_vec_download(const smh_vec *v, void *host);
+size_t smh_vec_dim(const smh_vec *v);
+int smh_vec_dtype(const smh_vec *v);
+void *smh_vec_data(const smh_vec *v); /* device pointer */
+int smh_vec_copy(smh_vec *dst, const smh_vec *src);                            /* clone() */
+/* Vector::add / sub / scale (densevec.rs:51-58, :60-67, :69-73; += -= *= sugar :76-96):
+ * x += y, x -= y over the first y.dim() entries; SMH_ERR_DIM_MISMATCH iff x.dim() < y.dim() */
+int smh_vec_add(smh_vec *x, const smh_vec *y);
+int smh_vec_sub(smh_vec *x, const smh_vec *y);
+int smh_vec_scale(smh_vec *x, double a);
+/* y += round(a*x)  -- `*x += p.clone() * alpha` linearsolver.rs:47 (densevec.rs:121-130, :76-81) */
+int smh_vec_axpy(smh_vec *y, double a, const smh_vec *x);
+/* p = round(b*p) + r -- `p.scale(beta); p.add(&r)` linearsolver.rs:58-59 */
+int smh_vec_xpby(smh_vec *p, double b, const smh_vec *r);
+/* Vector::inner_prod (vector.rs:50-53; `v * w` densevec.rs:133-140), norm_squared (:56-58):
+ * deterministic two-stage tree reduction in T, result widened to double (T::into::<f64>) */
+int smh_vec_dot(const smh_vec *x, const smh_vec *y, double *out);
+int smh_vec_norm_squared(const smh_vec *x, double *out);
+int smh_vec_norm(const smh_vec *x, double *out); /* vector.rs:61-63 */
+/* SparseMatrix::mvp on device vectors; y is resized semantics-free: y.dim() must be n_rows */
+int smh_crs_spmv_vec(smh_crs *m, const smh_vec *x, smh_vec *y, int variant);
+
+/* ---- ConjugateGradient::solve (linearsolver.rs:27-61) -----------------------------------
+ * Device-resident: SpMV + fused updates + reductions, scalars (alpha, beta, r.r) stay in
+ * HBM; the stop rule `sqrt(f64(r.r)) < tol`, tested before the beta update (:52-54), is
+ * evaluated on the device every iteration and polled by the host every `check_every`
+ * iterations (kernels of later iterations are no-ops once it fired, so x is exactly the x
+ * of the iteration that converged).  tol/iter_max: the private fields :12-15 (Default
+ * 1e-12 / 10000, :17-24).  Status: SMH_ERR_NOT_SQUARE (:30-32), SMH_ERR_DIM_MISMATCH
+ * (:33-36).  iters_out = loop bodies entered (a body that breaks counts), rr_out = last
+ * r.norm_squared() as f64.                                                               */
+int smh_cg_solve(smh_crs *m, const void *b_host, size_t b_len, void *x_host_inout, size_t x_len,
+                 double tol, size_t iter_max, int variant, size_t *iters_out, double *rr_out);
+int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_t iter_max,
+                     int variant, size_t check_every, size_t *iters_out, double *rr_out);
+
+/* ---- synthetic workloads (bench / test support, DESIGN.md "Synthetic inputs") ------------
+ * Counter-based generators writing straight into device memory so 10M..80M-row inputs never
+ * cross PCIe.  pattern: 0 banded-stratified (ascending), 1 uniform (draw order).          */
+int smh_synth_x(smh_dtype dtype, uint64_t seed, size_t begin, size_t n, void *x_dev, void *stream);
+int smh_synth_fixed(smh_dtype dtype, uint64_t seed, int pattern, size_t n, uint32_t k,
+                    size_t row_begin, size_t row_end, uint32_t *offset_rows_dev,
+                    uint32_t *columns_dev, void *values_dev, void *stream);
+int smh_synth_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf_host);
+int smh_synth_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax,
+                               const uint32_t *cdf_host, uint32_t *lengths_host);
+int smh_synth_fill(smh_dtype dtype, uint64_t seed, size_t n_cols, size_t row_begin, size_t row_end,
+                   const uint32_t *offset_rows_dev, uint32_t *columns_dev, void *values_dev,
+                   void *stream);
+/* 7-point Laplacian on an nx*ny*nz grid (natural ordering, diag 6, off-diag -1), rows
+ * [row_begin,row_end), offsets rebased.  offsets need rows+1, columns/values nnz entries
+ * (call with NULL arrays to get nnz_out only).                                            */
+int smh_synth_laplace3d(smh_dtype dtype, size_t nx, size_t ny, size_t nz, size_t row_begin,
+                        size_t row_end, uint32_t *offset_rows_dev, uint32_t *columns_dev,
+                        void *values_dev, size_t *nnz_out, void *stream);
+
+/* ---- raw device memory helpers for hosts without a HIP binding (the Rust shim) ---------- */
+int smh_dev_alloc(size_t bytes, void **out);
+int smh_dev_free(void *p);
+int smh_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int smh_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSEMAT_HIP_H */

@@ -1,0 +1,368 @@
+/*
+ * sparsemat_oracle.c -- TEST INFRASTRUCTURE ONLY (see sparsemat_oracle.h).
+ *
+ * Plain-C, single-thread restatement of the reference crate's arithmetic for
+ * the CSR SpMV / BLAS-1 / CG path.  Build with -ffp-contract=off: the reference
+ * (rustc, no fast-math) rounds every multiply and every add separately.
+ * Parity: pinned by the reference's own known-answer tests (tests/golden/).
+ */
+#include "sparsemat_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================= *
+ * SpMV.  sparsematrix.rs:146-158: for each row i, sum = T::zero(); for each
+ * (col,val) of iter_row(i) in STORAGE order: sum += rhs.get(col) * val; then
+ * ret.set(i,sum).  iter_row = sparsemat_crs.rs:102-110 (slice
+ * [offset_rows[i], offset_rows[i+1])).  rhs.get = densevec.rs:40-42 (bounds
+ * checked -> panic; here ORC_ERR_INDEX_OOB).  u32 -> usize: types.rs:32-36.
+ * ======================================================================= */
+#define DEF_SPMV(SUF, T)                                                                    \
+    int orc_spmv_rows_##SUF(size_t row_begin, size_t row_end, const uint32_t *offset_rows,  \
+                            const uint32_t *columns, const T *values, const T *x,           \
+                            size_t x_len, T *y) {                                           \
+        for (size_t i = row_begin; i < row_end; ++i) {                                      \
+            size_t start = (size_t)offset_rows[i];                                          \
+            size_t end = (size_t)offset_rows[i + 1];                                        \
+            T sum = (T)0;                                                                   \
+            for (size_t k = start; k < end; ++k) {                                          \
+                size_t j = (size_t)columns[k];                                              \
+                if (j >= x_len) return ORC_ERR_INDEX_OOB;                                   \
+                T prod = x[j] * values[k]; /* rounded product (rhs.get(j) * val) */         \
+                sum = sum + prod;          /* rounded add (sum += ...)            */         \
+            }                                                                               \
+            y[i] = sum;                                                                     \
+        }                                                                                   \
+        return ORC_OK;                                                                      \
+    }                                                                                       \
+    int orc_spmv_##SUF(size_t n_rows, const uint32_t *offset_rows, const uint32_t *columns, \
+                       const T *values, const T *x, size_t x_len, T *y) {                   \
+        return orc_spmv_rows_##SUF(0, n_rows, offset_rows, columns, values, x, x_len, y);   \
+    }                                                                                       \
+    void orc_spmv_abs_##SUF(size_t n_rows, const uint32_t *offset_rows,                     \
+                            const uint32_t *columns, const T *values, const T *x,           \
+                            double *out) {                                                  \
+        for (size_t i = 0; i < n_rows; ++i) {                                               \
+            double s = 0.0;                                                                 \
+            for (size_t k = offset_rows[i]; k < (size_t)offset_rows[i + 1]; ++k)            \
+                s += fabs((double)x[columns[k]] * (double)values[k]);                       \
+            out[i] = s;                                                                     \
+        }                                                                                   \
+    }                                                                                       \
+    /* sparsematrix.rs:161-171: sum += lhs.get(i) * val * rhs.get(j), left to right */     \
+    T orc_mat_inner_prod_##SUF(size_t n_rows, const uint32_t *offset_rows,                  \
+                               const uint32_t *columns, const T *values, const T *lhs,      \
+                               const T *rhs) {                                              \
+        T sum = (T)0;                                                                       \
+        for (size_t i = 0; i < n_rows; ++i)                                                 \
+            for (size_t k = offset_rows[i]; k < (size_t)offset_rows[i + 1]; ++k) {          \
+                T t = lhs[i] * values[k];                                                   \
+                t = t * rhs[columns[k]];                                                    \
+                sum = sum + t;                                                              \
+            }                                                                               \
+        return sum;                                                                         \
+    }
+
+DEF_SPMV(f32, float)
+DEF_SPMV(f64, double)
+
+/* ======================================================================= *
+ * DenseVec ops.  densevec.rs:51-58 add, :60-67 sub (panic "Dimension
+ * mismatch" iff self.dim() < rhs.dim(); zip truncates to the shorter), :69-73
+ * scale.  axpy / xpby restate the composite updates of linearsolver.rs:47,49
+ * and :58-59 with the reference's rounding order.
+ * ======================================================================= */
+#define DEF_VEC(SUF, T)                                                        \
+    int orc_vec_add_##SUF(T *x, size_t nx, const T *y, size_t ny) {            \
+        if (nx < ny) return ORC_ERR_SIZE_MISMATCH;                             \
+        for (size_t i = 0; i < ny; ++i) x[i] = x[i] + y[i];                    \
+        return ORC_OK;                                                         \
+    }                                                                          \
+    int orc_vec_sub_##SUF(T *x, size_t nx, const T *y, size_t ny) {            \
+        if (nx < ny) return ORC_ERR_SIZE_MISMATCH;                             \
+        for (size_t i = 0; i < ny; ++i) x[i] = x[i] - y[i];                    \
+        return ORC_OK;                                                         \
+    }                                                                          \
+    void orc_vec_scale_##SUF(T *x, size_t n, T a) {                            \
+        for (size_t i = 0; i < n; ++i) x[i] = x[i] * a;                        \
+    }                                                                          \
+    void orc_vec_axpy_##SUF(T *y, T a, const T *x, size_t n) {                 \
+        for (size_t i = 0; i < n; ++i) {                                       \
+            T t = x[i] * a; /* p.clone() * alpha */                            \
+            y[i] = y[i] + t; /* *x += ...         */                           \
+        }                                                                      \
+    }                                                                          \
+    void orc_vec_xpby_##SUF(T *p, T b, const T *r, size_t n) {                 \
+        for (size_t i = 0; i < n; ++i) {                                       \
+            T t = p[i] * b; /* p.scale(beta) */                                \
+            p[i] = t + r[i]; /* p.add(&r)    */                                \
+        }                                                                      \
+    }                                                                          \
+    /* vector.rs:50-53: zip().map(x*y).sum() -- left fold from zero */         \
+    T orc_dot_##SUF(const T *x, const T *y, size_t n) {                        \
+        T s = (T)0;                                                            \
+        for (size_t i = 0; i < n; ++i) {                                       \
+            T t = x[i] * y[i];                                                 \
+            s = s + t;                                                         \
+        }                                                                      \
+        return s;                                                              \
+    }                                                                          \
+    /* vector.rs:56-58 */                                                      \
+    T orc_norm_squared_##SUF(const T *x, size_t n) {                           \
+        T s = (T)0;                                                            \
+        for (size_t i = 0; i < n; ++i) {                                       \
+            T t = x[i] * x[i];                                                 \
+            s = s + t;                                                         \
+        }                                                                      \
+        return s;                                                              \
+    }                                                                          \
+    /* vector.rs:61-63: f64::sqrt(self.norm_squared().into()) */               \
+    double orc_norm_##SUF(const T *x, size_t n) {                              \
+        return sqrt((double)orc_norm_squared_##SUF(x, n));                     \
+    }
+
+DEF_VEC(f32, float)
+DEF_VEC(f64, double)
+
+/* ======================================================================= *
+ * ConjugateGradient::solve.  linearsolver.rs:27-61.
+ *   :30-32 n_rows != n_cols           -> "Matrix is not symmetric"
+ *   :33-36 n_rows != b.dim()/x.dim()  -> "Matrix and vector size mismatch"
+ *   :38    r = b - A x ; :39 p = r ; :40 rr = r.r
+ *   :41-60 loop: Ap (:43), alpha = rr / p.Ap (:45), x += p*alpha (:47),
+ *          r -= Ap*alpha (:49), rr (:50-51), stop if sqrt(f64(rr)) < tol
+ *          (:52-54, BEFORE the beta update), beta = rr/rr_prev (:56),
+ *          p = beta*p + r (:58-59).
+ * ======================================================================= */
+#define DEF_CG(SUF, T)                                                                       \
+    int orc_cg_##SUF(size_t n_rows, size_t n_cols, const uint32_t *offset_rows,              \
+                     const uint32_t *columns, const T *values, const T *b, size_t b_len,     \
+                     T *x, size_t x_len, double tol, size_t iter_max, size_t *iters_out,     \
+                     double *rr_out) {                                                       \
+        if (n_rows != n_cols) return ORC_ERR_NOT_SQUARE;                                     \
+        if (n_rows != b_len || n_rows != x_len) return ORC_ERR_SIZE_MISMATCH;                \
+        size_t n = n_rows;                                                                   \
+        T *r = (T *)malloc((n ? n : 1) * sizeof(T));                                         \
+        T *p = (T *)malloc((n ? n : 1) * sizeof(T));                                         \
+        T *ap = (T *)malloc((n ? n : 1) * sizeof(T));                                        \
+        int rc = orc_spmv_##SUF(n, offset_rows, columns, values, x, x_len, ap);              \
+        size_t iters = 0;                                                                    \
+        T rr = (T)0;                                                                         \
+        if (rc == ORC_OK) {                                                                  \
+            for (size_t i = 0; i < n; ++i) r[i] = b[i] - ap[i];                              \
+            memcpy(p, r, n * sizeof(T));                                                     \
+            rr = orc_norm_squared_##SUF(r, n);                                               \
+            for (size_t k = 0; k < iter_max; ++k) {                                          \
+                ++iters;                                                                     \
+                rc = orc_spmv_##SUF(n, offset_rows, columns, values, p, n, ap);              \
+                if (rc != ORC_OK) break;                                                     \
+                T alpha = rr / orc_dot_##SUF(p, ap, n);                                      \
+                orc_vec_axpy_##SUF(x, alpha, p, n);                                          \
+                for (size_t i = 0; i < n; ++i) {                                             \
+                    T t = ap[i] * alpha; /* mat_p * alpha */                                 \
+                    r[i] = r[i] - t;     /* r -= ...      */                                 \
+                }                                                                            \
+                T rr_prev = rr;                                                              \
+                rr = orc_norm_squared_##SUF(r, n);                                           \
+                if (sqrt((double)rr) < tol) break;                                           \
+                T beta = rr / rr_prev;                                                       \
+                orc_vec_xpby_##SUF(p, beta, r, n);                                           \
+            }                                                                                \
+        }                                                                                    \
+        if (iters_out) *iters_out = iters;                                                   \
+        if (rr_out) *rr_out = (double)rr;                                                    \
+        free(r);                                                                             \
+        free(p);                                                                             \
+        free(ap);                                                                            \
+        return rc;                                                                           \
+    }
+
+DEF_CG(f32, float)
+DEF_CG(f64, double)
+
+/* ======================================================================= *
+ * SparseMatPar.  sparsemat_par.rs:20-28 (R = max_n_rows / n_blocks) and
+ * :31-35 (block = min(row / R, n_blocks), row_id = row - block*R).
+ * ======================================================================= */
+size_t orc_par_rows_per_block(size_t n_blocks, size_t max_n_rows) { return max_n_rows / n_blocks; }
+
+void orc_par_block_and_row(size_t n_blocks, size_t rows_per_block, size_t row, size_t *block_out,
+                           size_t *row_out) {
+    size_t b = row / rows_per_block;
+    if (b > n_blocks) b = n_blocks; /* the reference clamps to n_blocks, not n_blocks-1 */
+    *block_out = b;
+    *row_out = row - b * rows_per_block;
+}
+
+/* ======================================================================= *
+ * Synthetic workloads (the build's own; spec in DESIGN.md).  Counter based so
+ * the device generator reproduces them bit for bit.
+ * ======================================================================= */
+#define ORC_GOLD 0x9E3779B97F4A7C15ull
+
+uint64_t orc_splitmix64(uint64_t z) {
+    z += ORC_GOLD;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static inline uint64_t rowkey(uint64_t seed, uint64_t row) { return orc_splitmix64(seed ^ (row * ORC_GOLD)); }
+static inline float h2f32(uint64_t h) { return (float)(h >> 40) * 0x1p-23f - 1.0f; }
+static inline double h2f64(uint64_t h) { return (double)(h >> 11) * 0x1p-52 - 1.0; }
+
+void orc_gen_x_f32(uint64_t seed, size_t begin, size_t n, float *x) {
+    for (size_t j = 0; j < n; ++j) x[j] = h2f32(rowkey(seed, begin + j));
+}
+void orc_gen_x_f64(uint64_t seed, size_t begin, size_t n, double *x) {
+    for (size_t j = 0; j < n; ++j) x[j] = h2f64(rowkey(seed, begin + j));
+}
+
+#define DEF_GEN(SUF, T, H2V)                                                                  \
+    void orc_gen_fixed_##SUF(uint64_t seed, int pattern, size_t n, uint32_t k,                \
+                             size_t row_begin, size_t row_end, uint32_t *offset_rows,         \
+                             uint32_t *columns, T *values) {                                  \
+        uint64_t s = n / k;                                                                   \
+        if (s < 1) s = 1;                                                                     \
+        if (s > 256) s = 256;                                                                 \
+        uint64_t w = s * k;                                                                   \
+        _Pragma("omp parallel for schedule(static)")                                          \
+        for (size_t row = row_begin; row < row_end; ++row) {                                  \
+            uint64_t rk = rowkey(seed, row);                                                  \
+            size_t o = (row - row_begin) * (size_t)k;                                         \
+            offset_rows[row - row_begin] = (uint32_t)o;                                       \
+            int64_t base = (int64_t)row - (int64_t)(w / 2);                                   \
+            if (base > (int64_t)n - (int64_t)w) base = (int64_t)n - (int64_t)w;               \
+            if (base < 0) base = 0;                                                           \
+            for (uint32_t j = 0; j < k; ++j) {                                                \
+                uint64_t hc = orc_splitmix64(rk + 2ull * j);                                  \
+                uint64_t hv = orc_splitmix64(rk + 2ull * j + 1ull);                           \
+                uint64_t c = pattern == 0 ? (uint64_t)base + j * s + hc % s : hc % n;         \
+                columns[o + j] = (uint32_t)c;                                                 \
+                values[o + j] = H2V(hv);                                                      \
+            }                                                                                 \
+        }                                                                                     \
+        offset_rows[row_end - row_begin] = (uint32_t)((row_end - row_begin) * (size_t)k);     \
+    }                                                                                         \
+    void orc_gen_fill_##SUF(uint64_t seed, size_t n_cols, size_t row_begin, size_t row_end,   \
+                            const uint32_t *offset_rows, uint32_t *columns, T *values) {      \
+        _Pragma("omp parallel for schedule(dynamic, 4096)")                                   \
+        for (size_t row = row_begin; row < row_end; ++row) {                                  \
+            uint64_t rk = rowkey(seed, row);                                                  \
+            size_t o = offset_rows[row - row_begin];                                          \
+            uint32_t len = offset_rows[row - row_begin + 1] - offset_rows[row - row_begin];   \
+            for (uint32_t j = 0; j < len; ++j) {                                              \
+                uint64_t hc = orc_splitmix64(rk + 2ull * j);                                  \
+                uint64_t hv = orc_splitmix64(rk + 2ull * j + 1ull);                           \
+                columns[o + j] = (uint32_t)(hc % n_cols);                                     \
+                values[o + j] = H2V(hv);                                                      \
+            }                                                                                 \
+        }                                                                                     \
+    }
+
+DEF_GEN(f32, float, h2f32)
+DEF_GEN(f64, double, h2f64)
+
+void orc_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf) {
+    double z = 0.0;
+    for (uint32_t k = 1; k <= kmax; ++k) z += pow((double)k, -alpha);
+    double acc = 0.0;
+    for (uint32_t k = 1; k <= kmax; ++k) {
+        acc += pow((double)k, -alpha);
+        double f = acc / z * 4294967296.0;
+        cdf[k - 1] = f >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)f;
+    }
+    cdf[kmax - 1] = 0xFFFFFFFFu;
+}
+
+void orc_gen_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax,
+                              const uint32_t *cdf, uint32_t *lengths) {
+    for (size_t row = row_begin; row < row_end; ++row) {
+        uint32_t u = (uint32_t)(orc_splitmix64(rowkey(seed, row) ^ 0xA5A5A5A5A5A5A5A5ull) >> 32);
+        /* count of entries cdf[i] <= u (upper bound), clamped to kmax-1 */
+        uint32_t lo = 0, hi = kmax;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        if (lo > kmax - 1) lo = kmax - 1;
+        lengths[row - row_begin] = 1u + lo;
+    }
+}
+
+#define DEF_LAPLACE(SUF, T)                                                                   \
+    size_t orc_laplace2d_##SUF(size_t nx, size_t ny, uint32_t *offset_rows, uint32_t *columns,\
+                               T *values) {                                                   \
+        size_t nnz = 0;                                                                       \
+        for (size_t j = 0; j < ny; ++j)                                                       \
+            for (size_t i = 0; i < nx; ++i) {                                                 \
+                size_t row = j * nx + i;                                                      \
+                if (offset_rows) offset_rows[row] = (uint32_t)nnz;                            \
+                long long nb[5] = {j > 0 ? (long long)(row - nx) : -1,                        \
+                                   i > 0 ? (long long)(row - 1) : -1, (long long)row,         \
+                                   i + 1 < nx ? (long long)(row + 1) : -1,                    \
+                                   j + 1 < ny ? (long long)(row + nx) : -1};                  \
+                for (int t = 0; t < 5; ++t)                                                   \
+                    if (nb[t] >= 0) {                                                         \
+                        if (columns) columns[nnz] = (uint32_t)nb[t];                          \
+                        if (values) values[nnz] = t == 2 ? (T)4 : (T)-1;                      \
+                        ++nnz;                                                                \
+                    }                                                                         \
+            }                                                                                 \
+        if (offset_rows) offset_rows[nx * ny] = (uint32_t)nnz;                                \
+        return nnz;                                                                           \
+    }                                                                                         \
+    size_t orc_laplace3d_##SUF(size_t nx, size_t ny, size_t nz, uint32_t *offset_rows,        \
+                               uint32_t *columns, T *values) {                                \
+        size_t nnz = 0;                                                                       \
+        size_t nxy = nx * ny;                                                                 \
+        for (size_t k = 0; k < nz; ++k)                                                       \
+            for (size_t j = 0; j < ny; ++j)                                                   \
+                for (size_t i = 0; i < nx; ++i) {                                             \
+                    size_t row = k * nxy + j * nx + i;                                        \
+                    if (offset_rows) offset_rows[row] = (uint32_t)nnz;                        \
+                    long long nb[7] = {k > 0 ? (long long)(row - nxy) : -1,                   \
+                                       j > 0 ? (long long)(row - nx) : -1,                    \
+                                       i > 0 ? (long long)(row - 1) : -1, (long long)row,     \
+                                       i + 1 < nx ? (long long)(row + 1) : -1,                \
+                                       j + 1 < ny ? (long long)(row + nx) : -1,               \
+                                       k + 1 < nz ? (long long)(row + nxy) : -1};             \
+                    for (int t = 0; t < 7; ++t)                                               \
+                        if (nb[t] >= 0) {                                                     \
+                            if (columns) columns[nnz] = (uint32_t)nb[t];                      \
+                            if (values) values[nnz] = t == 3 ? (T)6 : (T)-1;                  \
+                            ++nnz;                                                            \
+                        }                                                                     \
+                }                                                                             \
+        if (offset_rows) offset_rows[nxy * nz] = (uint32_t)nnz;                               \
+        return nnz;                                                                           \
+    }
+
+DEF_LAPLACE(f32, float)
+DEF_LAPLACE(f64, double)
+
+/* ======================================================================= *
+ * Merge-path diagonal search (restates the build's K2 partitioner, not a
+ * reference function): list A = row END offsets (offset_rows[1..n_rows]),
+ * list B = the naturals 0..nnz-1.  On diagonal d find the split (row, d-row)
+ * with A[row-1] <= B[d-row] ... by binary search on "A[mid] <= d-1-mid".
+ * ======================================================================= */
+void orc_merge_path_search(size_t n_rows, size_t nnz, const uint32_t *offset_rows,
+                           size_t n_diagonals, const uint64_t *diagonals, uint32_t *row_out,
+                           uint32_t *nnz_out) {
+    const uint32_t *row_end = offset_rows + 1;
+    for (size_t t = 0; t < n_diagonals; ++t) {
+        uint64_t d = diagonals[t];
+        if (d > (uint64_t)n_rows + nnz) d = (uint64_t)n_rows + nnz;
+        uint64_t lo = d > nnz ? d - nnz : 0;
+        uint64_t hi = d < n_rows ? d : n_rows;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)row_end[mid] <= d - 1 - mid) lo = mid + 1; else hi = mid;
+        }
+        row_out[t] = (uint32_t)lo;
+        nnz_out[t] = (uint32_t)(d - lo);
+    }
+}

@@ -1,0 +1,132 @@
+"""ctypes binding of libsparsemat_hip.so (the C ABI declared in include/sparsemat_hip.h).
+
+The library is the product; this module only declares its signatures.  There is no
+fallback: if the shared object is missing or fails to load, importing a symbol raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparsemat_hip.so")
+
+SMH_OK = 0
+SMH_ERR_DIM_MISMATCH, SMH_ERR_NOT_SQUARE, SMH_ERR_INDEX_RANGE, SMH_ERR_INVALID = 1, 2, 3, 4
+SMH_ERR_HIP, SMH_ERR_OOM, SMH_ERR_NO_DEVICE, SMH_ERR_CAPACITY = 5, 6, 7, 8
+SMH_F32, SMH_F64 = 0, 1
+SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ = 0, 1, 2, 3
+VARIANTS = {"auto": SPMV_AUTO, "vector": SPMV_VECTOR, "merge": SPMV_MERGE, "seq": SPMV_SEQ}
+
+_sz = C.c_size_t
+_vp = C.c_void_p
+_u32p = C.POINTER(C.c_uint32)
+_int = C.c_int
+
+# name -> (restype, argtypes); every symbol include/sparsemat_hip.h declares
+SIGNATURES = {
+    "smh_abi_version": (_int, []),
+    "smh_last_error": (C.c_char_p, []),
+    "smh_status_string": (C.c_char_p, [_int]),
+    "smh_device_count": (_int, [C.POINTER(_int)]),
+    "smh_set_device": (_int, [_int]),
+    "smh_device_synchronize": (_int, []),
+    "smh_crs_create": (_int, [_int, _sz, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
+    "smh_crs_create_dev": (_int, [_int, _sz, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
+    "smh_crs_destroy": (_int, [_vp]),
+    "smh_crs_update_values": (_int, [_vp, _vp]),
+    "smh_crs_download": (_int, [_vp, _vp, _vp, _vp]),
+    "smh_crs_n_rows": (_sz, [_vp]),
+    "smh_crs_n_cols": (_sz, [_vp]),
+    "smh_crs_nnz": (_sz, [_vp]),
+    "smh_crs_dtype": (_int, [_vp]),
+    "smh_crs_max_row_len": (_int, [_vp, _u32p]),
+    "smh_crs_scale": (_int, [_vp, C.c_double]),
+    "smh_crs_resolved_variant": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "smh_crs_set_vector_lanes": (_int, [_vp, _int]),
+    "smh_crs_spmv": (_int, [_vp, _vp, _sz, _vp, _int]),
+    "smh_crs_spmv_dev": (_int, [_vp, _vp, _sz, _vp, _int, _vp]),
+    "smh_crs_merge_tiles": (_sz, [_vp]),
+    "smh_crs_merge_tile_items": (_sz, [_vp]),
+    "smh_crs_merge_table": (_int, [_vp, _vp, _vp]),
+    "smh_vec_create": (_int, [_int, _sz, C.POINTER(_vp)]),
+    "smh_vec_from_host": (_int, [_int, _sz, _vp, C.POINTER(_vp)]),
+    "smh_vec_wrap_dev": (_int, [_int, _sz, _vp, C.POINTER(_vp)]),
+    "smh_vec_destroy": (_int, [_vp]),
+    "smh_vec_upload": (_int, [_vp, _vp]),
+    "smh_vec_download": (_int, [_vp, _vp]),
+    "smh_vec_dim": (_sz, [_vp]),
+    "smh_vec_dtype": (_int, [_vp]),
+    "smh_vec_data": (_vp, [_vp]),
+    "smh_vec_copy": (_int, [_vp, _vp]),
+    "smh_vec_add": (_int, [_vp, _vp]),
+    "smh_vec_sub": (_int, [_vp, _vp]),
+    "smh_vec_scale": (_int, [_vp, C.c_double]),
+    "smh_vec_axpy": (_int, [_vp, C.c_double, _vp]),
+    "smh_vec_xpby": (_int, [_vp, C.c_double, _vp]),
+    "smh_vec_dot": (_int, [_vp, _vp, C.POINTER(C.c_double)]),
+    "smh_vec_norm_squared": (_int, [_vp, C.POINTER(C.c_double)]),
+    "smh_vec_norm": (_int, [_vp, C.POINTER(C.c_double)]),
+    "smh_crs_spmv_vec": (_int, [_vp, _vp, _vp, _int]),
+    "smh_cg_solve": (_int, [_vp, _vp, _sz, _vp, _sz, C.c_double, _sz, _int, C.POINTER(_sz),
+                            C.POINTER(C.c_double)]),
+    "smh_cg_solve_vec": (_int, [_vp, _vp, _vp, C.c_double, _sz, _int, _sz, C.POINTER(_sz),
+                                C.POINTER(C.c_double)]),
+    "smh_synth_x": (_int, [_int, C.c_uint64, _sz, _sz, _vp, _vp]),
+    "smh_synth_fixed": (_int, [_int, C.c_uint64, _int, _sz, C.c_uint32, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "smh_synth_powerlaw_cdf": (_int, [C.c_uint32, C.c_double, _vp]),
+    "smh_synth_powerlaw_lengths": (_int, [C.c_uint64, _sz, _sz, C.c_uint32, _vp, _vp]),
+    "smh_synth_fill": (_int, [_int, C.c_uint64, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "smh_synth_laplace3d": (_int, [_int, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
+    "smh_dev_alloc": (_int, [_sz, C.POINTER(_vp)]),
+    "smh_dev_free": (_int, [_vp]),
+    "smh_dev_upload": (_int, [_vp, _vp, _sz]),
+    "smh_dev_download": (_int, [_vp, _vp, _sz]),
+}
+
+_LIB = None
+
+
+class SparseMatPanic(RuntimeError):
+    """A non-zero status of the C ABI; the message is the reference's panic text where one exists."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def lib():
+    """Load libsparsemat_hip.so.  Fails loudly: there is no CPU or pure-Python fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -m sparsemat_amd.build` (hipcc, gfx950). "
+                "sparsemat_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(status):
+    if status != SMH_OK:
+        L = lib()
+        msg = L.smh_last_error().decode(errors="replace") or L.smh_status_string(status).decode()
+        raise SparseMatPanic(status, msg)
+
+
+def dtype_code(np_dtype):
+    import numpy as np
+    dt = np.dtype(np_dtype)
+    if dt == np.float32:
+        return SMH_F32
+    if dt == np.float64:
+        return SMH_F64
+    raise TypeError("the HIP path handles f32/f64 values only (got %s)" % dt)
+
+
+def np_dtype(code):
+    import numpy as np
+    return np.float64 if code == SMH_F64 else np.float32

@@ -1,0 +1,660 @@
+// capi.hip -- extern "C" boundary of libsparsemat_hip.so (see include/sparsemat_hip.h).
+//
+// Host-side logic only: argument checks with the reference's panic conditions, HBM residency of
+// the CRS arrays, kernel-variant selection, the CG driver loop.  No CPU compute path exists here:
+// every entry point that computes needs a HIP device.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+
+#include "internal.hpp"
+
+namespace smh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int fail(int status, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    int status = (e == hipErrorOutOfMemory) ? SMH_ERR_OOM : (e == hipErrorNoDevice ? SMH_ERR_NO_DEVICE : SMH_ERR_HIP);
+    snprintf(g_err, sizeof g_err, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();  // clear sticky state
+    return status;
+}
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(SMH_ERR_NO_DEVICE, "no HIP device visible: libsparsemat_hip has no CPU fallback");
+    }
+    return SMH_OK;
+}
+
+int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d;
+}
+
+// defined in the kernel files
+size_t cg_scalars_bytes(int dtype);
+int cg_begin(int dtype, void *sc, const void *r, size_t n, void *partials, double tol, size_t iter_max, hipStream_t s);
+int cg_iter_tail(int dtype, void *sc, void *x, void *r, void *p, const void *ap, size_t n, void *partials, hipStream_t s);
+void cg_read_scalars(int dtype, const void *host_copy, int *converged, uint64_t *iters, double *rr);
+int synth_x(int dtype, uint64_t seed, size_t begin, size_t n, void *x, hipStream_t s);
+int synth_fixed(int dtype, uint64_t seed, int pattern, size_t n, uint32_t k, size_t row_begin, size_t row_end,
+                uint32_t *off, uint32_t *col, void *val, hipStream_t s);
+int synth_fill(int dtype, uint64_t seed, size_t n_cols, size_t row_begin, size_t row_end, const uint32_t *off,
+               uint32_t *col, void *val, hipStream_t s);
+size_t synth_laplace3d_nnz(size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end);
+int synth_laplace3d(int dtype, size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end, uint32_t *off,
+                    uint32_t *col, void *val, hipStream_t s);
+void synth_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf);
+void synth_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax, const uint32_t *cdf,
+                            uint32_t *lengths);
+
+static bool valid_dtype(int dt) { return dt == SMH_F32 || dt == SMH_F64; }
+
+static int ensure_cap(void **buf, size_t *cap, size_t bytes) {
+    if (*cap >= bytes && *buf) return SMH_OK;
+    if (*buf) { SMH_HIP(hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    SMH_HIP(hipMalloc(buf, want));
+    *cap = want;
+    return SMH_OK;
+}
+
+// ---- variant selection ---------------------------------------------------------------------------
+static int auto_lanes(const smh_crs *m) {
+    if (m->forced_lanes) return m->forced_lanes;
+    const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
+    // one pass of a lane group covers 4*lanes entries: size the group to the mean row
+    int lanes = 1;
+    while (lanes < 64 && 4.0 * lanes < mean) lanes <<= 1;
+    return lanes;
+}
+
+static int resolve_variant(const smh_crs *m, int variant) {
+    if (variant != SMH_SPMV_AUTO) return variant;
+    const int lanes = auto_lanes(m);
+    // skew test: the longest row needs >= 8 passes of a group sized for the mean row
+    if ((uint64_t)m->max_row_len >= 8ull * 4ull * (uint64_t)lanes && m->max_row_len > 64) return SMH_SPMV_MERGE;
+    return SMH_SPMV_VECTOR;
+}
+
+static int ensure_merge_ws(smh_crs *m) {
+    if (m->d_tile_row) return SMH_OK;
+    const uint64_t items = (uint64_t)m->n_rows + (uint64_t)m->nnz;
+    m->n_tiles = (size_t)((items + kMergeTile - 1) / kMergeTile);
+    if (m->n_tiles == 0) return SMH_OK;
+    SMH_HIP(hipMalloc((void **)&m->d_tile_row, (m->n_tiles + 1) * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_tile_nz, (m->n_tiles + 1) * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_carry_row, m->n_tiles * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc(&m->d_carry_val, m->n_tiles * dtype_size(m->dtype)));
+    SMH_TRY(launch_merge_table(m->d_off, m->n_rows, m->nnz, m->n_tiles, m->d_tile_row, m->d_tile_nz, m->stream));
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    return SMH_OK;
+}
+
+// enqueue y = A x on stream s (device pointers)
+static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s) {
+    if (m->nnz > 0 && (size_t)m->max_col >= x_len)
+        return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, m->max_col);
+    const int v = resolve_variant(m, variant);
+    switch (v) {
+        case SMH_SPMV_VECTOR:
+            return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, s);
+        case SMH_SPMV_SEQ:
+            return launch_spmv_seq(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, s);
+        case SMH_SPMV_MERGE:
+            SMH_TRY(ensure_merge_ws(m));
+            return launch_spmv_merge(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->n_tiles,
+                                     m->d_tile_row, m->d_tile_nz, m->d_carry_row, m->d_carry_val, s);
+        default:
+            return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);
+    }
+}
+
+static int finish_create(smh_crs *m, int validate) {
+    SMH_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    if (m->n_rows > 0) {
+        CrsStats *d_st = nullptr, h_st;
+        SMH_HIP(hipMalloc((void **)&d_st, sizeof(CrsStats)));
+        int rc = launch_crs_stats(m->d_off, m->d_col, m->n_rows, m->nnz, d_st, m->stream);
+        if (rc == SMH_OK) {
+            hipError_t e = hipMemcpyAsync(&h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, m->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "crs stats readback", __FILE__, __LINE__);
+        }
+        (void)hipFree(d_st);
+        SMH_TRY(rc);
+        m->max_row_len = h_st.max_row_len;
+        m->max_col = h_st.max_col;
+        m->have_stats = true;
+        // a malformed row structure would send the kernels out of bounds: always refused
+        if (h_st.bad & 1u) return fail(SMH_ERR_INVALID, "offset_rows is not monotone non-decreasing");
+        if (h_st.bad & 2u) return fail(SMH_ERR_INVALID, "offset_rows[0] != 0");
+        if (h_st.bad & 4u) return fail(SMH_ERR_INVALID, "offset_rows[n_rows] != nnz");
+        if (validate && m->nnz > 0 && (size_t)h_st.max_col >= m->n_cols)
+            return fail(SMH_ERR_INDEX_RANGE, "column index %u >= n_cols %zu", h_st.max_col, m->n_cols);
+    }
+    return SMH_OK;
+}
+
+static int check_create_args(int dtype, size_t n_rows, size_t nnz, const void *off, const void *col, const void *val,
+                             smh_crs **out) {
+    if (!out) return fail(SMH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!valid_dtype(dtype)) return fail(SMH_ERR_INVALID, "dtype must be SMH_F32 or SMH_F64");
+    // Index = u32: UNSET = u32::MAX is reserved, entry count must stay below it (sparsemat_crs.rs:82-84)
+    if (nnz >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "Maximum number of %u entries reached", 0xFFFFFFFFu);
+    if (n_rows >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "n_rows does not fit the u32 index type");
+    if (n_rows > 0 && !off) return fail(SMH_ERR_INVALID, "offset_rows is NULL");
+    if (nnz > 0 && (!col || !val)) return fail(SMH_ERR_INVALID, "columns/values is NULL");
+    return SMH_OK;
+}
+
+static int vec_check_pair(const smh_vec *x, const smh_vec *y) {
+    if (!x || !y) return fail(SMH_ERR_INVALID, "NULL vector handle");
+    if (x->dtype != y->dtype) return fail(SMH_ERR_INVALID, "vector dtype mismatch");
+    return SMH_OK;
+}
+
+// scratch for reductions of the vector API: per thread, per device
+struct ReduceScratch { void *d = nullptr; int device = -1; };
+static thread_local ReduceScratch g_red;
+static int reduce_scratch(void **out) {
+    const int dev = current_device();
+    if (!g_red.d || g_red.device != dev) {
+        // (a scratch left on another device is intentionally leaked: handles are device-bound)
+        SMH_HIP(hipMalloc(&g_red.d, (kReducePartials + 8) * sizeof(double)));
+        g_red.device = dev;
+    }
+    *out = g_red.d;
+    return SMH_OK;
+}
+
+}  // namespace smh
+
+using namespace smh;
+
+extern "C" {
+
+int smh_abi_version(void) { return SMH_ABI_VERSION; }
+
+const char *smh_last_error(void) { return g_err; }
+
+const char *smh_status_string(int status) {
+    switch (status) {
+        case SMH_OK: return "ok";
+        case SMH_ERR_DIM_MISMATCH: return "Dimension mismatch";
+        case SMH_ERR_NOT_SQUARE: return "Matrix is not symmetric";
+        case SMH_ERR_INDEX_RANGE: return "index out of bounds";
+        case SMH_ERR_INVALID: return "invalid argument";
+        case SMH_ERR_HIP: return "HIP runtime error";
+        case SMH_ERR_OOM: return "out of device memory";
+        case SMH_ERR_NO_DEVICE: return "no HIP device (no CPU fallback)";
+        case SMH_ERR_CAPACITY: return "Maximum number of entries reached";
+        default: return "unknown status";
+    }
+}
+
+int smh_device_count(int *count_out) {
+    if (!count_out) return fail(SMH_ERR_INVALID, "count_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count_out = n;
+    return SMH_OK;
+}
+
+int smh_set_device(int device) {
+    SMH_TRY(require_device());
+    SMH_HIP(hipSetDevice(device));
+    return SMH_OK;
+}
+
+int smh_device_synchronize(void) {
+    SMH_TRY(require_device());
+    SMH_HIP(hipDeviceSynchronize());
+    return SMH_OK;
+}
+
+// ---- SparseMatCRS ------------------------------------------------------------------------------------
+int smh_crs_create(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz, const uint32_t *offset_rows,
+                   const uint32_t *columns, const void *values, int validate, smh_crs **out) {
+    SMH_TRY(check_create_args(dtype, n_rows, nnz, offset_rows, columns, values, out));
+    SMH_TRY(require_device());
+    smh_crs *m = new (std::nothrow) smh_crs();
+    if (!m) return fail(SMH_ERR_OOM, "host allocation failed");
+    m->dtype = dtype; m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz; m->owns = true;
+    m->device = current_device();
+    const size_t vs = dtype_size(dtype);
+    int rc = SMH_OK;
+    auto go = [&]() -> int {
+        SMH_HIP(hipMalloc((void **)&m->d_off, (n_rows + 1) * sizeof(uint32_t)));
+        SMH_HIP(hipMalloc((void **)&m->d_col, (nnz + 4) * sizeof(uint32_t)));
+        SMH_HIP(hipMalloc(&m->d_val, (nnz + 4) * vs));
+        if (n_rows > 0) SMH_HIP(hipMemcpy(m->d_off, offset_rows, (n_rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        else SMH_HIP(hipMemset(m->d_off, 0, sizeof(uint32_t)));
+        if (nnz > 0) {
+            SMH_HIP(hipMemcpy(m->d_col, columns, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+            SMH_HIP(hipMemcpy(m->d_val, values, nnz * vs, hipMemcpyHostToDevice));
+        }
+        return finish_create(m, validate);
+    };
+    rc = go();
+    if (rc != SMH_OK) { char keep[512]; strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0; smh_crs_destroy(m); strncpy(g_err, keep, sizeof g_err); return rc; }
+    *out = m;
+    return SMH_OK;
+}
+
+int smh_crs_create_dev(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz, const uint32_t *offset_rows_dev,
+                       const uint32_t *columns_dev, const void *values_dev, int validate, smh_crs **out) {
+    SMH_TRY(check_create_args(dtype, n_rows, nnz, offset_rows_dev, columns_dev, values_dev, out));
+    SMH_TRY(require_device());
+    if (((uintptr_t)columns_dev & 15u) || ((uintptr_t)values_dev & 15u))
+        return fail(SMH_ERR_INVALID, "columns/values device pointers must be 16-byte aligned");
+    smh_crs *m = new (std::nothrow) smh_crs();
+    if (!m) return fail(SMH_ERR_OOM, "host allocation failed");
+    m->dtype = dtype; m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz; m->owns = false;
+    m->device = current_device();
+    m->d_off = const_cast<uint32_t *>(offset_rows_dev);
+    m->d_col = const_cast<uint32_t *>(columns_dev);
+    m->d_val = const_cast<void *>(values_dev);
+    int rc = finish_create(m, validate);
+    if (rc != SMH_OK) { char keep[512]; strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0; smh_crs_destroy(m); strncpy(g_err, keep, sizeof g_err); return rc; }
+    *out = m;
+    return SMH_OK;
+}
+
+int smh_crs_destroy(smh_crs *m) {
+    if (!m) return SMH_OK;
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
+    (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
+    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
+    (void)hipGetLastError();
+    delete m;
+    return SMH_OK;
+}
+
+int smh_crs_update_values(smh_crs *m, const void *values_host) {
+    if (!m || !values_host) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (m->nnz) SMH_HIP(hipMemcpy(m->d_val, values_host, m->nnz * dtype_size(m->dtype), hipMemcpyHostToDevice));
+    return SMH_OK;
+}
+
+int smh_crs_download(const smh_crs *m, uint32_t *offset_rows, uint32_t *columns, void *values) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    if (offset_rows) SMH_HIP(hipMemcpy(offset_rows, m->d_off, (m->n_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (columns && m->nnz) SMH_HIP(hipMemcpy(columns, m->d_col, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (values && m->nnz) SMH_HIP(hipMemcpy(values, m->d_val, m->nnz * dtype_size(m->dtype), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+size_t smh_crs_n_rows(const smh_crs *m) { return m ? m->n_rows : 0; }
+size_t smh_crs_n_cols(const smh_crs *m) { return m ? m->n_cols : 0; }
+size_t smh_crs_nnz(const smh_crs *m) { return m ? m->nnz : 0; }
+int smh_crs_dtype(const smh_crs *m) { return m ? m->dtype : -1; }
+
+int smh_crs_max_row_len(const smh_crs *m, uint32_t *out) {
+    if (!m || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    *out = m->max_row_len;
+    return SMH_OK;
+}
+
+int smh_crs_scale(smh_crs *m, double a) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(launch_scale_values(m->dtype, m->d_val, m->nnz, a, m->stream));
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    return SMH_OK;
+}
+
+int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (variant_out) *variant_out = resolve_variant(m, SMH_SPMV_AUTO);
+    if (lanes_out) *lanes_out = auto_lanes(m);
+    return SMH_OK;
+}
+
+int smh_crs_set_vector_lanes(smh_crs *m, int lanes) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (lanes != 0 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))))
+        return fail(SMH_ERR_INVALID, "lanes per row must be 0 or a power of two in 1..64");
+    m->forced_lanes = lanes;
+    return SMH_OK;
+}
+
+int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant, void *stream) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (m->n_rows && (!y_dev || (m->nnz && !x_dev))) return fail(SMH_ERR_INVALID, "NULL device vector");
+    return spmv_enqueue(m, x_dev, x_len, y_dev, variant, stream ? (hipStream_t)stream : m->stream);
+}
+
+int smh_crs_spmv(smh_crs *m, const void *x_host, size_t x_len, void *y_host, int variant) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (m->n_rows == 0) return SMH_OK;
+    if (!y_host || (x_len && !x_host)) return fail(SMH_ERR_INVALID, "NULL host vector");
+    const size_t vs = dtype_size(m->dtype);
+    SMH_TRY(ensure_cap(&m->d_x, &m->d_x_cap, x_len * vs));
+    SMH_TRY(ensure_cap(&m->d_y, &m->d_y_cap, m->n_rows * vs));
+    if (x_len) SMH_HIP(hipMemcpyAsync(m->d_x, x_host, x_len * vs, hipMemcpyHostToDevice, m->stream));
+    SMH_TRY(spmv_enqueue(m, m->d_x, x_len, m->d_y, variant, m->stream));
+    SMH_HIP(hipMemcpyAsync(y_host, m->d_y, m->n_rows * vs, hipMemcpyDeviceToHost, m->stream));
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    return SMH_OK;
+}
+
+size_t smh_crs_merge_tiles(const smh_crs *m) {
+    if (!m) return 0;
+    return (size_t)(((uint64_t)m->n_rows + m->nnz + kMergeTile - 1) / kMergeTile);
+}
+
+size_t smh_crs_merge_tile_items(const smh_crs *) { return kMergeTile; }
+
+int smh_crs_merge_table(smh_crs *m, uint32_t *row_out, uint32_t *nnz_out) {
+    if (!m || !row_out || !nnz_out) return fail(SMH_ERR_INVALID, "NULL argument");
+    SMH_TRY(ensure_merge_ws(m));
+    if (m->n_tiles == 0) { row_out[0] = 0; nnz_out[0] = 0; return SMH_OK; }
+    SMH_HIP(hipMemcpy(row_out, m->d_tile_row, (m->n_tiles + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SMH_HIP(hipMemcpy(nnz_out, m->d_tile_nz, (m->n_tiles + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+// ---- DenseVec ----------------------------------------------------------------------------------------
+int smh_vec_create(smh_dtype dtype, size_t n, smh_vec **out) {
+    if (!out) return fail(SMH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!valid_dtype(dtype)) return fail(SMH_ERR_INVALID, "dtype must be SMH_F32 or SMH_F64");
+    SMH_TRY(require_device());
+    smh_vec *v = new (std::nothrow) smh_vec();
+    if (!v) return fail(SMH_ERR_OOM, "host allocation failed");
+    v->dtype = dtype; v->n = n; v->owns = true; v->device = current_device();
+    const size_t bytes = (n ? n : 1) * dtype_size(dtype);
+    hipError_t e = hipMalloc(&v->d, bytes);
+    if (e == hipSuccess) e = hipMemset(v->d, 0, bytes);
+    if (e != hipSuccess) { delete v; return hip_fail(e, "smh_vec_create", __FILE__, __LINE__); }
+    *out = v;
+    return SMH_OK;
+}
+
+int smh_vec_from_host(smh_dtype dtype, size_t n, const void *host, smh_vec **out) {
+    SMH_TRY(smh_vec_create(dtype, n, out));
+    if (n) {
+        int rc = smh_vec_upload(*out, host);
+        if (rc != SMH_OK) { smh_vec_destroy(*out); *out = nullptr; return rc; }
+    }
+    return SMH_OK;
+}
+
+int smh_vec_wrap_dev(smh_dtype dtype, size_t n, void *dev_ptr, smh_vec **out) {
+    if (!out) return fail(SMH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!valid_dtype(dtype)) return fail(SMH_ERR_INVALID, "dtype must be SMH_F32 or SMH_F64");
+    if (n && !dev_ptr) return fail(SMH_ERR_INVALID, "dev_ptr is NULL");
+    SMH_TRY(require_device());
+    smh_vec *v = new (std::nothrow) smh_vec();
+    if (!v) return fail(SMH_ERR_OOM, "host allocation failed");
+    v->dtype = dtype; v->n = n; v->d = dev_ptr; v->owns = false; v->device = current_device();
+    *out = v;
+    return SMH_OK;
+}
+
+int smh_vec_destroy(smh_vec *v) {
+    if (!v) return SMH_OK;
+    if (v->owns) { (void)hipFree(v->d); (void)hipGetLastError(); }
+    delete v;
+    return SMH_OK;
+}
+
+int smh_vec_upload(smh_vec *v, const void *host) {
+    if (!v || (v->n && !host)) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (v->n) SMH_HIP(hipMemcpy(v->d, host, v->n * dtype_size(v->dtype), hipMemcpyHostToDevice));
+    return SMH_OK;
+}
+
+int smh_vec_download(const smh_vec *v, void *host) {
+    if (!v || (v->n && !host)) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (v->n) SMH_HIP(hipMemcpy(host, v->d, v->n * dtype_size(v->dtype), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+size_t smh_vec_dim(const smh_vec *v) { return v ? v->n : 0; }
+int smh_vec_dtype(const smh_vec *v) { return v ? v->dtype : -1; }
+void *smh_vec_data(const smh_vec *v) { return v ? v->d : nullptr; }
+
+int smh_vec_copy(smh_vec *dst, const smh_vec *src) {
+    SMH_TRY(vec_check_pair(dst, src));
+    if (dst->n != src->n) return fail(SMH_ERR_DIM_MISMATCH, "Dimension mismatch");
+    if (src->n) SMH_HIP(hipMemcpy(dst->d, src->d, src->n * dtype_size(src->dtype), hipMemcpyDeviceToDevice));
+    return SMH_OK;
+}
+
+static int vec_ew(Ew op, smh_vec *x, const smh_vec *y, double a) {
+    SMH_TRY(vec_check_pair(x, y));
+    // densevec.rs:52-54 / :61-63: panic iff self.dim() < rhs.dim(); zip() covers rhs.dim() entries
+    if (x->n < y->n) return fail(SMH_ERR_DIM_MISMATCH, "Dimension mismatch");
+    SMH_TRY(launch_ew(x->dtype, op, x->d, y->d, y->n, a, nullptr, nullptr));
+    SMH_HIP(hipStreamSynchronize(nullptr));
+    return SMH_OK;
+}
+
+int smh_vec_add(smh_vec *x, const smh_vec *y) { return vec_ew(Ew::Add, x, y, 0.0); }
+int smh_vec_sub(smh_vec *x, const smh_vec *y) { return vec_ew(Ew::Sub, x, y, 0.0); }
+int smh_vec_axpy(smh_vec *y, double a, const smh_vec *x) { return vec_ew(Ew::Axpy, y, x, a); }
+int smh_vec_xpby(smh_vec *p, double b, const smh_vec *r) { return vec_ew(Ew::Xpby, p, r, b); }
+
+int smh_vec_scale(smh_vec *x, double a) {
+    if (!x) return fail(SMH_ERR_INVALID, "NULL vector handle");
+    SMH_TRY(launch_ew(x->dtype, Ew::Scale, x->d, nullptr, x->n, a, nullptr, nullptr));
+    SMH_HIP(hipStreamSynchronize(nullptr));
+    return SMH_OK;
+}
+
+int smh_vec_dot(const smh_vec *x, const smh_vec *y, double *out) {
+    SMH_TRY(vec_check_pair(x, y));
+    if (!out) return fail(SMH_ERR_INVALID, "out is NULL");
+    const size_t n = x->n < y->n ? x->n : y->n;  // zip truncates (vector.rs:52)
+    void *scratch = nullptr;
+    SMH_TRY(reduce_scratch(&scratch));
+    char *res = (char *)scratch + kReducePartials * sizeof(double);
+    SMH_TRY(launch_dot(x->dtype, x->d, y->d, n, scratch, res, nullptr));
+    if (x->dtype == SMH_F64) {
+        double h = 0;
+        SMH_HIP(hipMemcpy(&h, res, sizeof h, hipMemcpyDeviceToHost));
+        *out = h;
+    } else {
+        float h = 0;
+        SMH_HIP(hipMemcpy(&h, res, sizeof h, hipMemcpyDeviceToHost));
+        *out = (double)h;
+    }
+    return SMH_OK;
+}
+
+int smh_vec_norm_squared(const smh_vec *x, double *out) { return smh_vec_dot(x, x, out); }
+
+int smh_vec_norm(const smh_vec *x, double *out) {
+    SMH_TRY(smh_vec_norm_squared(x, out));
+    *out = std::sqrt(*out);  // f64::sqrt(self.norm_squared().into())  vector.rs:61-63
+    return SMH_OK;
+}
+
+int smh_crs_spmv_vec(smh_crs *m, const smh_vec *x, smh_vec *y, int variant) {
+    if (!m || !x || !y) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (x->dtype != m->dtype || y->dtype != m->dtype) return fail(SMH_ERR_INVALID, "dtype mismatch");
+    if (y->n != m->n_rows) return fail(SMH_ERR_DIM_MISMATCH, "Dimension mismatch");
+    SMH_TRY(spmv_enqueue(m, x->d, x->n, y->d, variant, m->stream));
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    return SMH_OK;
+}
+
+// ---- ConjugateGradient ---------------------------------------------------------------------------------
+int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_t iter_max, int variant,
+                     size_t check_every, size_t *iters_out, double *rr_out) {
+    if (!m || !b || !x) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (b->dtype != m->dtype || x->dtype != m->dtype) return fail(SMH_ERR_INVALID, "dtype mismatch");
+    if (m->n_rows != m->n_cols) return fail(SMH_ERR_NOT_SQUARE, "Matrix is not symmetric");           // :30-32
+    if (m->n_rows != b->n || m->n_rows != x->n)
+        return fail(SMH_ERR_DIM_MISMATCH, "Matrix and vector size mismatch");                            // :33-36
+    if (check_every == 0) check_every = 4;
+    const size_t n = m->n_rows;
+    const size_t vs = dtype_size(m->dtype);
+    hipStream_t s = m->stream;
+    void *r = nullptr, *p = nullptr, *ap = nullptr, *partials = nullptr, *sc = nullptr, *h_sc = nullptr;
+    int rc = SMH_OK;
+    size_t iters = 0;
+    double rr = 0.0;
+    auto body = [&]() -> int {
+        const size_t vb = (n ? n : 1) * vs;
+        SMH_HIP(hipMalloc(&r, vb));
+        SMH_HIP(hipMalloc(&p, vb));
+        SMH_HIP(hipMalloc(&ap, vb));
+        SMH_HIP(hipMalloc(&partials, (kReducePartials + 8) * vs));
+        SMH_HIP(hipMalloc(&sc, cg_scalars_bytes(m->dtype)));
+        SMH_HIP(hipHostMalloc(&h_sc, cg_scalars_bytes(m->dtype)));
+        // r = b - A x  (:38) ; p = r.clone() (:39) ; rr = r.r (:40)
+        SMH_TRY(spmv_enqueue(m, x->d, x->n, r, variant, s));
+        SMH_TRY(launch_ew(m->dtype, Ew::RSubInto, r, b->d, n, 0.0, nullptr, s));
+        if (n) SMH_HIP(hipMemcpyAsync(p, r, n * vs, hipMemcpyDeviceToDevice, s));
+        SMH_TRY(cg_begin(m->dtype, sc, r, n, partials, tol, iter_max, s));
+        size_t launched = 0;
+        int converged = 0;
+        while (launched < iter_max) {
+            size_t batch = iter_max - launched < check_every ? iter_max - launched : check_every;
+            for (size_t i = 0; i < batch; ++i) {
+                SMH_TRY(spmv_enqueue(m, p, n, ap, variant, s));                                          // :43
+                SMH_TRY(cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, s));                     // :45-59
+            }
+            launched += batch;
+            SMH_HIP(hipMemcpyAsync(h_sc, sc, cg_scalars_bytes(m->dtype), hipMemcpyDeviceToHost, s));
+            SMH_HIP(hipStreamSynchronize(s));
+            uint64_t it64 = 0;
+            cg_read_scalars(m->dtype, h_sc, &converged, &it64, &rr);
+            iters = (size_t)it64;
+            if (converged) break;
+        }
+        if (iter_max == 0) {
+            SMH_HIP(hipMemcpyAsync(h_sc, sc, cg_scalars_bytes(m->dtype), hipMemcpyDeviceToHost, s));
+            SMH_HIP(hipStreamSynchronize(s));
+            uint64_t it64 = 0;
+            cg_read_scalars(m->dtype, h_sc, &converged, &it64, &rr);
+        }
+        return SMH_OK;
+    };
+    rc = body();
+    char keep[512];
+    strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0;
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(r); (void)hipFree(p); (void)hipFree(ap); (void)hipFree(partials); (void)hipFree(sc);
+    if (h_sc) (void)hipHostFree(h_sc);
+    (void)hipGetLastError();
+    strncpy(g_err, keep, sizeof g_err);
+    if (rc != SMH_OK) return rc;
+    if (iters_out) *iters_out = iters;
+    if (rr_out) *rr_out = rr;
+    return SMH_OK;
+}
+
+int smh_cg_solve(smh_crs *m, const void *b_host, size_t b_len, void *x_host_inout, size_t x_len, double tol,
+                 size_t iter_max, int variant, size_t *iters_out, double *rr_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (m->n_rows != m->n_cols) return fail(SMH_ERR_NOT_SQUARE, "Matrix is not symmetric");
+    if (m->n_rows != b_len || m->n_rows != x_len) return fail(SMH_ERR_DIM_MISMATCH, "Matrix and vector size mismatch");
+    smh_vec *b = nullptr, *x = nullptr;
+    int rc = smh_vec_from_host((smh_dtype)m->dtype, b_len, b_host, &b);
+    if (rc == SMH_OK) rc = smh_vec_from_host((smh_dtype)m->dtype, x_len, x_host_inout, &x);
+    if (rc == SMH_OK) rc = smh_cg_solve_vec(m, b, x, tol, iter_max, variant, 0, iters_out, rr_out);
+    if (rc == SMH_OK) rc = smh_vec_download(x, x_host_inout);
+    smh_vec_destroy(b);
+    smh_vec_destroy(x);
+    return rc;
+}
+
+// ---- synthetic workloads ---------------------------------------------------------------------------------
+int smh_synth_x(smh_dtype dtype, uint64_t seed, size_t begin, size_t n, void *x_dev, void *stream) {
+    SMH_TRY(require_device());
+    return synth_x(dtype, seed, begin, n, x_dev, (hipStream_t)stream);
+}
+
+int smh_synth_fixed(smh_dtype dtype, uint64_t seed, int pattern, size_t n, uint32_t k, size_t row_begin,
+                    size_t row_end, uint32_t *offset_rows_dev, uint32_t *columns_dev, void *values_dev, void *stream) {
+    SMH_TRY(require_device());
+    if (k == 0 || n < k || row_end < row_begin || row_end > n) return fail(SMH_ERR_INVALID, "bad generator arguments");
+    if ((uint64_t)(row_end - row_begin) * k >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "block nnz exceeds u32");
+    return synth_fixed(dtype, seed, pattern, n, k, row_begin, row_end, offset_rows_dev, columns_dev, values_dev,
+                       (hipStream_t)stream);
+}
+
+int smh_synth_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf_host) {
+    if (!cdf_host || kmax == 0) return fail(SMH_ERR_INVALID, "bad arguments");
+    synth_powerlaw_cdf(kmax, alpha, cdf_host);
+    return SMH_OK;
+}
+
+int smh_synth_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax, const uint32_t *cdf_host,
+                               uint32_t *lengths_host) {
+    if (!cdf_host || !lengths_host || kmax == 0) return fail(SMH_ERR_INVALID, "bad arguments");
+    synth_powerlaw_lengths(seed, row_begin, row_end, kmax, cdf_host, lengths_host);
+    return SMH_OK;
+}
+
+int smh_synth_fill(smh_dtype dtype, uint64_t seed, size_t n_cols, size_t row_begin, size_t row_end,
+                   const uint32_t *offset_rows_dev, uint32_t *columns_dev, void *values_dev, void *stream) {
+    SMH_TRY(require_device());
+    if (n_cols == 0) return fail(SMH_ERR_INVALID, "n_cols == 0");
+    return synth_fill(dtype, seed, n_cols, row_begin, row_end, offset_rows_dev, columns_dev, values_dev,
+                      (hipStream_t)stream);
+}
+
+int smh_synth_laplace3d(smh_dtype dtype, size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end,
+                        uint32_t *offset_rows_dev, uint32_t *columns_dev, void *values_dev, size_t *nnz_out,
+                        void *stream) {
+    if (row_end < row_begin || row_end > nx * ny * nz) return fail(SMH_ERR_INVALID, "bad row range");
+    const size_t nnz = synth_laplace3d_nnz(nx, ny, nz, row_begin, row_end);
+    if (nnz_out) *nnz_out = nnz;
+    if (!offset_rows_dev && !columns_dev && !values_dev) return SMH_OK;  // size query only (no device needed)
+    if (nnz >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "block nnz exceeds u32");
+    SMH_TRY(require_device());
+    return synth_laplace3d(dtype, nx, ny, nz, row_begin, row_end, offset_rows_dev, columns_dev, values_dev,
+                           (hipStream_t)stream);
+}
+
+// ---- raw device memory helpers -----------------------------------------------------------------------------
+int smh_dev_alloc(size_t bytes, void **out) {
+    if (!out) return fail(SMH_ERR_INVALID, "out is NULL");
+    SMH_TRY(require_device());
+    SMH_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return SMH_OK;
+}
+int smh_dev_free(void *p) {
+    if (p) SMH_HIP(hipFree(p));
+    return SMH_OK;
+}
+int smh_dev_upload(void *dst_dev, const void *src_host, size_t bytes) {
+    if (bytes) SMH_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return SMH_OK;
+}
+int smh_dev_download(void *dst_host, const void *src_dev, size_t bytes) {
+    if (bytes) SMH_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// cg.hip -- K5: device-resident conjugate-gradient iteration for gfx950.
+//
+// Restates ConjugateGradient::solve (reference linearsolver.rs:27-61) as a stream of kernels whose
+// scalars (r.r, p.Ap, alpha, beta, the stop flag, the iteration count) never leave HBM:
+//
+//   per iteration   SpMV  Ap = A p                      (K1 / K2, launched by the caller)   :43
+//                   k_dot_stage1(p, Ap) -> partials                                          :45
+//                   k_cg_alpha   : fold partials, alpha = rr / pAp, decide "active"          :45
+//                   k_cg_update  : x += round(p*alpha); r -= round(Ap*alpha); partials r.r   :47-51
+//                   k_cg_beta    : fold, rr_prev/rr, stop if sqrt(f64(rr)) < tol, else beta  :50-56
+//                   k_cg_p       : p = round(p*beta) + r                                     :58-59
+//
+// "active" = not converged and fewer than iter_max bodies entered; once it drops, the gated
+// kernels are no-ops, so the host may enqueue iterations in batches and poll the flag lazily:
+// x, r, p are exactly those of the iteration in which the reference would have left its loop.
+// Element-wise updates round the product and the sum separately (bit-identical to the reference
+// for equal alpha/beta); the reductions are fixed trees (bitwise reproducible).
+#include "internal.hpp"
+
+namespace smh {
+
+template <typename T>
+struct CgScalars {
+    T rr, rr_prev, pap, alpha, beta;
+    uint32_t converged;
+    uint32_t active;
+    uint64_t iters;
+    uint64_t iter_max;
+    double tol;
+};
+
+template <typename T> struct CgVec;
+template <> struct CgVec<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+template <> struct CgVec<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+
+__device__ __forceinline__ float cg_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double cg_mul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float cg_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double cg_add(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ float cg_sub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ double cg_sub(double a, double b) { return __dsub_rn(a, b); }
+
+template <typename T>
+__device__ __forceinline__ T cg_block_sum(T v, T *s_w) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    T r = T(0);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) r += s_w[w];
+    }
+    return r;
+}
+
+template <typename T>
+__global__ void k_cg_init(CgScalars<T> *sc, double tol, uint64_t iter_max) {
+    sc->rr = sc->rr_prev = sc->pap = sc->alpha = sc->beta = T(0);
+    sc->converged = 0;
+    sc->active = 0;
+    sc->iters = 0;
+    sc->iter_max = iter_max;
+    sc->tol = tol;
+}
+
+// rr = fold(partials)   (after the initial r.r reduction, linearsolver.rs:40)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_cg_set_rr(CgScalars<T> *sc, const T *__restrict__ partials, uint32_t count) {
+    __shared__ T s_w[kBlock / kWave];
+    T acc = T(0);
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
+    const T r = cg_block_sum<T>(acc, s_w);
+    if (threadIdx.x == 0) sc->rr = r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_cg_alpha(CgScalars<T> *sc, const T *__restrict__ partials, uint32_t count) {
+    __shared__ T s_w[kBlock / kWave];
+    T acc = T(0);
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
+    const T pap = cg_block_sum<T>(acc, s_w);
+    if (threadIdx.x == 0) {
+        const bool active = !sc->converged && sc->iters < sc->iter_max;
+        sc->active = active ? 1u : 0u;
+        if (active) {
+            sc->iters += 1;  // a loop body is entered (for _k in 0..iter_max, :41)
+            sc->pap = pap;
+            sc->alpha = sc->rr / pap;  // :45 (no breakdown guard, like the reference)
+        }
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock)
+k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ x, T *__restrict__ r, const T *__restrict__ p,
+            const T *__restrict__ ap, uint64_t n, T *__restrict__ partials) {
+    __shared__ T s_w[kBlock / kWave];
+    if (!sc->active) return;  // block-uniform
+    const T alpha = sc->alpha;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    T acc = T(0);
+    if constexpr (VEC) {
+        typedef typename CgVec<T>::type V;
+        constexpr int N = CgVec<T>::N;
+        const uint64_t nv = n / N;
+        V *xv = reinterpret_cast<V *>(x);
+        V *rv = reinterpret_cast<V *>(r);
+        const V *pv = reinterpret_cast<const V *>(p);
+        const V *apv = reinterpret_cast<const V *>(ap);
+        for (uint64_t i = tid; i < nv; i += nthreads) {
+            V xx = xv[i], rr = rv[i];
+            const V pp = pv[i], aa = apv[i];
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                xx[e] = cg_add(xx[e], cg_mul(pp[e], alpha));  // *x += p.clone() * alpha   :47
+                rr[e] = cg_sub(rr[e], cg_mul(aa[e], alpha));  // r -= mat_p * alpha        :49
+                acc += rr[e] * rr[e];                         // r.norm_squared()          :51
+            }
+            xv[i] = xx;
+            rv[i] = rr;
+        }
+        for (uint64_t i = nv * N + tid; i < n; i += nthreads) {
+            x[i] = cg_add(x[i], cg_mul(p[i], alpha));
+            const T t = cg_sub(r[i], cg_mul(ap[i], alpha));
+            r[i] = t;
+            acc += t * t;
+        }
+    } else {
+        for (uint64_t i = tid; i < n; i += nthreads) {
+            x[i] = cg_add(x[i], cg_mul(p[i], alpha));
+            const T t = cg_sub(r[i], cg_mul(ap[i], alpha));
+            r[i] = t;
+            acc += t * t;
+        }
+    }
+    const T s = cg_block_sum<T>(acc, s_w);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_cg_beta(CgScalars<T> *sc, const T *__restrict__ partials, uint32_t count) {
+    __shared__ T s_w[kBlock / kWave];
+    if (!sc->active) return;
+    T acc = T(0);
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
+    const T rr = cg_block_sum<T>(acc, s_w);
+    if (threadIdx.x == 0) {
+        sc->rr_prev = sc->rr;
+        sc->rr = rr;
+        if (sqrt((double)rr) < sc->tol) {  // :52-54, BEFORE the beta update
+            sc->converged = 1;
+            sc->active = 0;
+        } else {
+            sc->beta = rr / sc->rr_prev;  // :56
+        }
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock)
+k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restrict__ r, uint64_t n) {
+    if (!sc->active) return;
+    const T beta = sc->beta;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    if constexpr (VEC) {
+        typedef typename CgVec<T>::type V;
+        constexpr int N = CgVec<T>::N;
+        const uint64_t nv = n / N;
+        V *pv = reinterpret_cast<V *>(p);
+        const V *rv = reinterpret_cast<const V *>(r);
+        for (uint64_t i = tid; i < nv; i += nthreads) {
+            V pp = pv[i];
+            const V rr = rv[i];
+#pragma unroll
+            for (int e = 0; e < N; ++e) pp[e] = cg_add(cg_mul(pp[e], beta), rr[e]);  // p.scale(beta); p.add(&r) :58-59
+            pv[i] = pp;
+        }
+        for (uint64_t i = nv * N + tid; i < n; i += nthreads) p[i] = cg_add(cg_mul(p[i], beta), r[i]);
+    } else {
+        for (uint64_t i = tid; i < n; i += nthreads) p[i] = cg_add(cg_mul(p[i], beta), r[i]);
+    }
+}
+
+// ---- host-side driver pieces (called from capi.hip) ----------------------------------------------
+unsigned reduce_blocks(size_t n);  // blas1.hip
+
+static inline bool cg_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+size_t cg_scalars_bytes(int dtype) { return dtype == SMH_F64 ? sizeof(CgScalars<double>) : sizeof(CgScalars<float>); }
+
+template <typename T>
+static int cg_begin_t(void *sc, const T *r, size_t n, T *partials, double tol, size_t iter_max, hipStream_t s) {
+    hipLaunchKernelGGL(k_cg_init<T>, dim3(1), dim3(1), 0, s, (CgScalars<T> *)sc, tol, (uint64_t)iter_max);
+    SMH_HIP(hipGetLastError());
+    SMH_TRY(launch_dot(sizeof(T) == 8 ? SMH_F64 : SMH_F32, r, r, n, partials, partials + kReducePartials, s));
+    // launch_dot folded into partials[kReducePartials]; copy it into the scalar block
+    hipLaunchKernelGGL(k_cg_set_rr<T>, dim3(1), dim3(kBlock), 0, s, (CgScalars<T> *)sc, partials + kReducePartials, 1u);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+int cg_begin(int dtype, void *sc, const void *r, size_t n, void *partials, double tol, size_t iter_max, hipStream_t s) {
+    if (dtype == SMH_F64) return cg_begin_t<double>(sc, (const double *)r, n, (double *)partials, tol, iter_max, s);
+    return cg_begin_t<float>(sc, (const float *)r, n, (float *)partials, tol, iter_max, s);
+}
+
+// everything of one iteration AFTER the SpMV Ap = A p
+template <typename T>
+static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T *partials, hipStream_t s) {
+    CgScalars<T> *sc = (CgScalars<T> *)scv;
+    const unsigned rb = reduce_blocks(n);
+    const bool vec = cg_aligned16(x) && cg_aligned16(r) && cg_aligned16(p) && cg_aligned16(ap);
+    // p . Ap
+    SMH_TRY(launch_dot(sizeof(T) == 8 ? SMH_F64 : SMH_F32, p, ap, n, partials, partials + kReducePartials, s));
+    hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, partials + kReducePartials, 1u);
+    SMH_HIP(hipGetLastError());
+    if (vec)
+        hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, sc, x, r, p, ap, (uint64_t)n, partials);
+    else
+        hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, sc, x, r, p, ap, (uint64_t)n, partials);
+    SMH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_cg_beta<T>, dim3(1), dim3(kBlock), 0, s, sc, partials, rb);
+    SMH_HIP(hipGetLastError());
+    uint64_t pb = (n / CgVec<T>::N + kBlock) / kBlock;
+    if (pb > 2048) pb = 2048;
+    if (vec)
+        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, (uint64_t)n);
+    else
+        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, (uint64_t)n);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+int cg_iter_tail(int dtype, void *sc, void *x, void *r, void *p, const void *ap, size_t n, void *partials,
+                 hipStream_t s) {
+    if (dtype == SMH_F64)
+        return cg_iter_tail_t<double>(sc, (double *)x, (double *)r, (double *)p, (const double *)ap, n, (double *)partials, s);
+    return cg_iter_tail_t<float>(sc, (float *)x, (float *)r, (float *)p, (const float *)ap, n, (float *)partials, s);
+}
+
+// host view of the scalar block after a poll
+void cg_read_scalars(int dtype, const void *host_copy, int *converged, uint64_t *iters, double *rr) {
+    if (dtype == SMH_F64) {
+        const CgScalars<double> *h = (const CgScalars<double> *)host_copy;
+        *converged = (int)h->converged; *iters = h->iters; *rr = (double)h->rr;
+    } else {
+        const CgScalars<float> *h = (const CgScalars<float> *)host_copy;
+        *converged = (int)h->converged; *iters = h->iters; *rr = (double)h->rr;
+    }
+}
+
+}  // namespace smh

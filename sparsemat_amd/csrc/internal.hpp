@@ -1,0 +1,101 @@
+// internal.hpp -- shared declarations of libsparsemat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/sparsemat_hip.h"
+
+namespace smh {
+
+// ---- error plumbing: never throw across the C ABI --------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int status, const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define SMH_HIP(call)                                                     \
+    do {                                                                  \
+        hipError_t e__ = (call);                                          \
+        if (e__ != hipSuccess) return ::smh::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define SMH_TRY(expr)                 \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != SMH_OK) return rc__; \
+    } while (0)
+
+int require_device();  // SMH_ERR_NO_DEVICE when no HIP device is visible
+int current_device();
+
+inline size_t dtype_size(int dt) { return dt == SMH_F64 ? 8 : 4; }
+
+constexpr int kWave = 64;           // gfx950 wavefront
+constexpr int kBlock = 256;         // 4 waves: one per SIMD
+constexpr int kMergeItemsPerThread = 8;
+constexpr int kMergeTile = kBlock * kMergeItemsPerThread;  // merge items (rows + nnz) per tile
+constexpr int kReducePartials = 1024;  // blocks of a stage-1 reduction
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------
+// K1 / SEQ
+int launch_spmv_vector(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val,
+                       const void *x, void *y, size_t n_rows, size_t nnz, hipStream_t s);
+int launch_spmv_seq(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
+                    void *y, size_t n_rows, hipStream_t s);
+// K2
+int launch_merge_table(const uint32_t *off, size_t n_rows, size_t nnz, size_t n_tiles, uint32_t *tile_row,
+                       uint32_t *tile_nz, hipStream_t s);
+int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
+                      void *y, size_t n_rows, size_t nnz, size_t n_tiles, const uint32_t *tile_row,
+                      const uint32_t *tile_nz, uint32_t *carry_row, void *carry_val, hipStream_t s);
+// structure statistics / validation
+struct CrsStats {
+    uint32_t max_row_len;
+    uint32_t max_col;
+    uint32_t bad;  // bit0: offsets not monotone, bit1: off[0]!=0, bit2: off[n]!=nnz
+};
+int launch_crs_stats(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t nnz, CrsStats *d_stats,
+                     hipStream_t s);
+// BLAS-1 (a_dev: scalar read from device memory when non-null, else `a`)
+enum class Ew { Add, Sub, Scale, Axpy, Xpby, RSubInto };
+int launch_ew(int dtype, Ew op, void *x, const void *y, size_t n, double a, const void *a_dev, hipStream_t s);
+int launch_dot(int dtype, const void *x, const void *y, size_t n, void *partials, void *result_dev,
+               hipStream_t s);
+int launch_scale_values(int dtype, void *v, size_t n, double a, hipStream_t s);
+
+}  // namespace smh
+
+// ---- handles ------------------------------------------------------------------------------
+struct smh_crs {
+    int dtype = SMH_F32;
+    int device = 0;
+    size_t n_rows = 0, n_cols = 0, nnz = 0;
+    uint32_t *d_off = nullptr;
+    uint32_t *d_col = nullptr;
+    void *d_val = nullptr;
+    bool owns = true;
+    hipStream_t stream = nullptr;
+    // statistics
+    uint32_t max_row_len = 0;
+    uint32_t max_col = 0;
+    bool have_stats = false;
+    int forced_lanes = 0;
+    // merge-path workspace (lazy)
+    size_t n_tiles = 0;
+    uint32_t *d_tile_row = nullptr, *d_tile_nz = nullptr, *d_carry_row = nullptr;
+    void *d_carry_val = nullptr;
+    // staging for the host-pointer API (lazy, reused)
+    void *d_x = nullptr, *d_y = nullptr;
+    size_t d_x_cap = 0, d_y_cap = 0;
+};
+
+struct smh_vec {
+    int dtype = SMH_F32;
+    int device = 0;
+    size_t n = 0;
+    void *d = nullptr;
+    bool owns = true;
+};

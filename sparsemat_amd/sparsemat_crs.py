@@ -1,0 +1,147 @@
+"""SparseMatCRS: host-side mirror of the reference's ``SparseMatCRS<T,u32>`` (sparsemat_crs.rs) for
+the SpMV hot path, backed by a device-resident ``smh_crs``.
+
+The host owns the CRS arrays (``offset_rows``, ``columns``, ``values``); ``from_raw_parts`` copies
+them to HBM once.  ``mvp`` / ``*`` run the hand-written HIP kernels.  Assembly
+(``add_to``/``set``/``get_mut``) stays with the reference's own containers -- out of scope here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from .densevec import DenseVec
+
+
+class SparseMatCRS:
+    def __init__(self, handle, dtype, keep=None):
+        self._h = handle
+        self._dtype = np.dtype(dtype)
+        self._keep = keep
+
+    # ---- constructors ------------------------------------------------------------------------
+    @classmethod
+    def from_raw_parts(cls, n_rows, n_cols, offset_rows, columns, values, validate=True):
+        """Fills the gap the reference leaves (its only bulk constructor, from_sparsemat_index
+        sparsemat_crs.rs:24-50, is pub(crate)): adopt CRS arrays as they are -- rows in storage
+        order, unsorted, duplicates allowed."""
+        values = np.ascontiguousarray(values)
+        if values.dtype not in (np.float32, np.float64):
+            raise TypeError("the HIP path handles f32/f64 values only (got %s)" % values.dtype)
+        off = np.ascontiguousarray(offset_rows, dtype=np.uint32)
+        col = np.ascontiguousarray(columns, dtype=np.uint32)
+        if n_rows and len(off) != n_rows + 1:
+            raise _lib.SparseMatPanic(_lib.SMH_ERR_INVALID, "offset_rows must have n_rows+1 entries")
+        if len(col) != len(values):
+            raise _lib.SparseMatPanic(_lib.SMH_ERR_INVALID, "columns and values differ in length")
+        h = C.c_void_p()
+        check(lib().smh_crs_create(_lib.dtype_code(values.dtype), n_rows, n_cols, len(values),
+                                   off.ctypes.data if len(off) else None,
+                                   col.ctypes.data if len(col) else None,
+                                   values.ctypes.data if len(values) else None,
+                                   1 if validate else 0, C.byref(h)))
+        return cls(h, values.dtype)
+
+    @classmethod
+    def from_device_parts(cls, n_rows, n_cols, nnz, off_ptr, col_ptr, val_ptr, dtype, keep=None,
+                          validate=False):
+        """Borrow CRS arrays already resident in HBM (raw device pointers); ``keep`` is held alive."""
+        h = C.c_void_p()
+        check(lib().smh_crs_create_dev(_lib.dtype_code(dtype), n_rows, n_cols, nnz, C.c_void_p(off_ptr),
+                                       C.c_void_p(col_ptr), C.c_void_p(val_ptr), 1 if validate else 0,
+                                       C.byref(h)))
+        return cls(h, dtype, keep)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().smh_crs_destroy(h)
+            except Exception:
+                pass
+
+    # ---- SparseMatrix accessors (sparsemat_crs.rs:124-134) ------------------------------------
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def n_rows(self):
+        return lib().smh_crs_n_rows(self._h)
+
+    def n_cols(self):
+        return lib().smh_crs_n_cols(self._h)
+
+    def n_non_zero_entries(self):
+        return lib().smh_crs_nnz(self._h)
+
+    def empty(self):  # sparsematrix.rs:119-121
+        return self.n_rows() == 0
+
+    def density(self):  # sparsematrix.rs:237-241
+        return self.n_non_zero_entries() / (self.n_rows() * self.n_cols())
+
+    def raw_parts(self):
+        off = np.empty(self.n_rows() + 1, dtype=np.uint32)
+        col = np.empty(self.n_non_zero_entries(), dtype=np.uint32)
+        val = np.empty(self.n_non_zero_entries(), dtype=self._dtype)
+        check(lib().smh_crs_download(self._h, off.ctypes.data, col.ctypes.data, val.ctypes.data))
+        return off, col, val
+
+    def iter_row(self, row):  # sparsemat_crs.rs:102-110 (row >= n_rows -> empty)
+        if row >= self.n_rows():
+            return []
+        off, col, val = self.raw_parts()
+        return list(zip(col[off[row]:off[row + 1]], val[off[row]:off[row + 1]]))
+
+    def scale(self, a):  # sparsemat_crs.rs:153-157
+        check(lib().smh_crs_scale(self._h, float(a)))
+
+    def update_values(self, values):
+        values = np.ascontiguousarray(values, dtype=self._dtype)
+        assert len(values) == self.n_non_zero_entries()
+        check(lib().smh_crs_update_values(self._h, values.ctypes.data))
+
+    # ---- kernel selection ----------------------------------------------------------------------
+    def resolved_variant(self):
+        v, lanes = C.c_int(), C.c_int()
+        check(lib().smh_crs_resolved_variant(self._h, C.byref(v), C.byref(lanes)))
+        return {1: "vector", 2: "merge", 3: "seq"}[v.value], lanes.value
+
+    def set_vector_lanes(self, lanes):
+        check(lib().smh_crs_set_vector_lanes(self._h, lanes))
+
+    def max_row_len(self):
+        out = C.c_uint32()
+        check(lib().smh_crs_max_row_len(self._h, C.byref(out)))
+        return out.value
+
+    def merge_table(self):
+        n = lib().smh_crs_merge_tiles(self._h)
+        rows = np.zeros(n + 1, dtype=np.uint32)
+        nz = np.zeros(n + 1, dtype=np.uint32)
+        check(lib().smh_crs_merge_table(self._h, rows.ctypes.data, nz.ctypes.data))
+        return rows, nz, lib().smh_crs_merge_tile_items(self._h)
+
+    # ---- SparseMatrix::mvp (sparsematrix.rs:146-158) and `A * v` (:435-443) --------------------
+    def mvp(self, rhs, variant="auto"):
+        """y = A.rhs; returns a NEW vector with dim == n_rows.  ``rhs`` is a DenseVec (device
+        resident) or anything array-like (host: uploaded, result returned as numpy)."""
+        var = _lib.VARIANTS[variant]
+        if isinstance(rhs, DenseVec):
+            ret = DenseVec.zeros(self.n_rows(), self._dtype)
+            check(lib().smh_crs_spmv_vec(self._h, rhs._h, ret._h, var))
+            return ret
+        x = np.ascontiguousarray(rhs, dtype=self._dtype)
+        y = np.zeros(self.n_rows(), dtype=self._dtype)
+        check(lib().smh_crs_spmv(self._h, x.ctypes.data if x.size else None, x.size,
+                                 y.ctypes.data if y.size else None, var))
+        return y
+
+    def __mul__(self, rhs):
+        return self.mvp(rhs)
+
+    def mvp_dev(self, x_ptr, x_len, y_ptr, variant="auto", stream=None):
+        """Asynchronous y = A.x on raw device pointers (stream: a hipStream_t value or None)."""
+        check(lib().smh_crs_spmv_dev(self._h, C.c_void_p(x_ptr), x_len, C.c_void_p(y_ptr),
+                                     _lib.VARIANTS[variant], C.c_void_p(stream or 0)))

@@ -1,0 +1,149 @@
+"""GPU parity of the DenseVec kernels (K3/K4) and the device-resident CG (K5) against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import sparsemat_amd as sm
+from sparsemat_amd import _lib
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("n", [0, 1, 3, 64, 1023, 4096 + 5, 300_001])
+def test_elementwise_bit_exact(gpu, dtype, n):
+    """densevec.rs:51-73 and the composite updates of linearsolver.rs:47,58-59: one rounding per
+    multiply and per add -> bit-identical to the oracle."""
+    rng = np.random.default_rng(n + 1)
+    a, b = rng.uniform(-2, 2, n).astype(dtype), rng.uniform(-2, 2, n).astype(dtype)
+    s = dtype(0.7310585786300049)
+    bits = np.uint32 if dtype == np.float32 else np.uint64
+
+    def same(got, want):
+        assert np.array_equal(got.view(bits), want.view(bits))
+
+    x, y = sm.DenseVec.from_vec(a), sm.DenseVec.from_vec(b)
+    assert x.dim() == n
+    x.add(y); same(x.to_numpy(), oracle.vec_add(a, b))
+    x = sm.DenseVec.from_vec(a); x.sub(y); same(x.to_numpy(), oracle.vec_sub(a, b))
+    x = sm.DenseVec.from_vec(a); x.scale(s); same(x.to_numpy(), oracle.vec_scale(a, s))
+    x = sm.DenseVec.from_vec(a); x.axpy(s, y); same(x.to_numpy(), oracle.vec_axpy(a, s, b))
+    x = sm.DenseVec.from_vec(a); x.xpby(s, y); same(x.to_numpy(), oracle.vec_xpby(a, s, b))
+    # operator sugar (densevec.rs:76-130) leaves the operands untouched
+    x = sm.DenseVec.from_vec(a)
+    same((x + y).to_numpy(), oracle.vec_add(a, b))
+    same((x - y).to_numpy(), oracle.vec_sub(a, b))
+    same((x * s).to_numpy(), oracle.vec_scale(a, s))
+    same(x.to_numpy(), a)
+
+
+def test_elementwise_shorter_rhs_and_mismatch(gpu):
+    """zip truncation and the "Dimension mismatch" panic (densevec.rs:52-54)."""
+    a, b = np.arange(10, dtype=np.float32), np.ones(4, dtype=np.float32)
+    x, y = sm.DenseVec.from_vec(a), sm.DenseVec.from_vec(b)
+    x.add(y)
+    assert np.array_equal(x.to_numpy(), oracle.vec_add(a, b))
+    with pytest.raises(sm.SparseMatPanic) as e:
+        y.add(x)
+    assert e.value.status == _lib.SMH_ERR_DIM_MISMATCH and "Dimension mismatch" in str(e.value)
+    with pytest.raises(oracle.OraclePanic):
+        oracle.vec_add(b, a)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("n", [0, 1, 5, 255, 256, 257, 70_001, 3_000_017])
+def test_reductions(gpu, dtype, n):
+    """vector.rs:50-63.  The reference folds left to right in T; the device uses a fixed tree in T.
+    Both are within n*eps*sum|x_i y_i| of the exact value; the tree is bitwise reproducible."""
+    rng = np.random.default_rng(n + 17)
+    a, b = rng.uniform(-1, 1, n).astype(dtype), rng.uniform(-1, 1, n).astype(dtype)
+    x, y = sm.DenseVec.from_vec(a), sm.DenseVec.from_vec(b)
+    eps = np.finfo(dtype).eps
+    exact = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+    scale = float(np.dot(np.abs(a).astype(np.float64), np.abs(b).astype(np.float64)))
+    d = x.inner_prod(y)
+    assert isinstance(d, dtype)
+    assert abs(float(d) - exact) <= (np.log2(max(n, 2)) + 8) * eps * scale + 1e-300
+    ref = oracle.dot(a, b)
+    assert abs(float(d) - float(ref)) <= 2 * max(n, 1) * eps * scale + 1e-300
+    assert x.inner_prod(y) == d and (x * y) == d  # reproducible; `v * w` sugar (densevec.rs:133-140)
+    nn = x.norm_squared()
+    assert abs(float(nn) - float(oracle.norm_squared(a))) <= 2 * max(n, 1) * eps * float(np.dot(a.astype(np.float64), a.astype(np.float64))) + 1e-300
+    assert x.norm() == np.sqrt(float(nn))
+
+
+def test_cg_reference_known_answer(gpu):
+    """check_cg (src/lib.rs:36-52): 2x2 f64, default CG -> floor(x0*1e4)/1e4 == 0.0909."""
+    with open(GOLDEN) as f:
+        case = [c for c in json.load(f)["cases"] if c["name"] == "check_cg"][0]
+    crs = case["crs"]
+    val = np.array(crs["values"], dtype=np.float64)
+    m = sm.SparseMatCRS.from_raw_parts(crs["n_rows"], crs["n_cols"], crs["offset_rows"], crs["columns"], val)
+    b = np.array([float(s) for s in case["b"]])
+    for variant in ("seq", "vector", "merge", "auto"):
+        x = np.array([float(s) for s in case["x0"]])
+        cg = sm.ConjugateGradient.default()
+        cg.variant = variant
+        cg.solve(m, b, x)
+        assert np.floor(x[0] * 1e4) / 1e4 == float(case["expect_floor_1e4"][0][1])
+        x_ref, it_ref, _ = oracle.cg(2, 2, crs["offset_rows"], crs["columns"], val, b, [2.0, 1.0])
+        assert cg.iterations == it_ref == 2
+        np.testing.assert_allclose(x, x_ref, rtol=1e-14)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 1e-3)], ids=["f64", "f32"])
+def test_cg_laplace3d_matches_oracle(gpu, dtype, tol):
+    """SPD 7-point Laplacian, b = A.1, x0 = 0, reference stop rule (linearsolver.rs:52)."""
+    nx = ny = nz = 12
+    n = nx * ny * nz
+    off, col, val = oracle.laplace3d(nx, ny, nz, dtype)
+    b = oracle.spmv(off, col, val, np.ones(n, dtype))
+    x_ref, it_ref, rr_ref = oracle.cg(n, n, off, col, val, b, np.zeros(n, dtype), tol=tol, iter_max=500)
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    for variant in ("seq", "auto", "merge"):
+        for check_every in (1, 7):
+            x = np.zeros(n, dtype)
+            xd, bd = sm.DenseVec.from_vec(x), sm.DenseVec.from_vec(b)
+            cg = sm.ConjugateGradient(tol, 500, variant=variant, check_every=check_every)
+            cg.solve(m, bd, xd)
+            assert abs(cg.iterations - it_ref) <= 2, (variant, cg.iterations, it_ref)
+            assert np.sqrt(cg.r_norm_squared) < tol
+            np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=50 * tol)
+            np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=50 * tol)
+
+
+def test_cg_iter_max_and_exact_iteration_semantics(gpu):
+    """iter_max bodies are entered at most; with SEQ SpMV and equal scalars the first iteration is
+    bit-identical to the oracle's (element-wise updates round like the reference)."""
+    n = 10 * 10 * 10
+    off, col, val = oracle.laplace3d(10, 10, 10, np.float64)
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, n)
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    for iters in (0, 1, 3):
+        x = np.zeros(n)
+        cg = sm.ConjugateGradient(1e-30, iters, variant="seq", check_every=5)
+        cg.solve(m, b, x)
+        x_ref, it_ref, rr_ref = oracle.cg(n, n, off, col, val, b, np.zeros(n), tol=1e-30, iter_max=iters)
+        assert cg.iterations == it_ref == iters
+        np.testing.assert_allclose(x, x_ref, rtol=1e-12, atol=1e-14)
+        if iters:
+            assert abs(cg.r_norm_squared - rr_ref) <= 1e-10 * rr_ref
+
+
+def test_cg_panics_of_the_reference(gpu):
+    f = np.float64
+    m = sm.SparseMatCRS.from_raw_parts(2, 3, [0, 1, 2], [0, 2], np.array([1, 2], f))
+    with pytest.raises(sm.SparseMatPanic) as e:
+        sm.ConjugateGradient().solve(m, np.ones(2), np.zeros(2))
+    assert e.value.status == _lib.SMH_ERR_NOT_SQUARE and str(e.value) == "Matrix is not symmetric"
+    m = sm.SparseMatCRS.from_raw_parts(2, 2, [0, 1, 2], [0, 1], np.array([1, 2], f))
+    with pytest.raises(sm.SparseMatPanic) as e:
+        sm.ConjugateGradient().solve(m, np.ones(3), np.zeros(2))
+    assert e.value.status == _lib.SMH_ERR_DIM_MISMATCH and str(e.value) == "Matrix and vector size mismatch"
+    with pytest.raises(oracle.OraclePanic):
+        oracle.cg(2, 2, [0, 1, 2], [0, 1], np.array([1, 2], f), np.ones(3), np.zeros(2))

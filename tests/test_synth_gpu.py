@@ -1,0 +1,92 @@
+"""Device generators vs the oracle's independent host generators: bit-exact (integer structure and
+exactly representable values), plus full-size (BASELINE C2) property checks of the SpMV kernels."""
+import numpy as np
+import pytest
+
+import oracle
+import sparsemat_amd as sm
+from sparsemat_amd import synth
+from util import assert_spmv_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("pattern", [synth.PATTERN_BANDED, synth.PATTERN_UNIFORM], ids=["banded", "uniform"])
+@pytest.mark.parametrize("n,k,rb,re", [(5000, 32, 0, 5000), (40, 32, 0, 40), (100_000, 32, 30_000, 41_234), (9000, 7, 8000, 9000)])
+def test_fixed_generator_bit_exact(gpu, dtype, pattern, n, k, rb, re):
+    m = synth.crs_fixed(synth.SEED_MATRIX, pattern, n, k, dtype, rb, re)
+    off, col, val = m.raw_parts()
+    off_r, col_r, val_r = oracle.gen_fixed(synth.SEED_MATRIX, pattern, n, k, dtype, rb, re)
+    assert np.array_equal(off, off_r) and np.array_equal(col, col_r)
+    assert np.array_equal(val.view(np.uint8), val_r.view(np.uint8))
+    assert col.max() < n
+    if pattern == synth.PATTERN_BANDED:  # ascending and distinct inside every row
+        c = col.reshape(-1, k).astype(np.int64)
+        assert np.all(np.diff(c, axis=1) > 0)
+
+
+def test_x_and_powerlaw_and_laplace_generators_bit_exact(gpu):
+    for dtype in (np.float32, np.float64):
+        buf, _ = synth.gen_x(synth.SEED_X, 10_007, dtype, begin=123)
+        x = buf.download(dtype, 10_007)
+        assert np.array_equal(x.view(np.uint8), oracle.gen_x(synth.SEED_X, 10_007, dtype, begin=123).view(np.uint8))
+        assert x.min() >= -1 and x.max() < 1
+    m = synth.crs_powerlaw(synth.SEED_MATRIX, 30_000, 30_000, np.float64)
+    off, col, val = m.raw_parts()
+    off_r, col_r, val_r = oracle.gen_powerlaw(synth.SEED_MATRIX, 30_000, 30_000, np.float64)
+    assert np.array_equal(off, off_r) and np.array_equal(col, col_r) and np.array_equal(val, val_r)
+    lens = np.diff(off.astype(np.int64))
+    assert lens.min() >= 1 and lens.max() <= 2048 and 20 < lens.mean() < 45
+    assert m.resolved_variant()[0] == "merge"
+    m = synth.crs_laplace3d(11, 7, 5, np.float32, 13, 300)
+    off, col, val = m.raw_parts()
+    off_f, col_f, val_f = oracle.laplace3d(11, 7, 5, np.float32)
+    lo, hi = off_f[13], off_f[300]
+    assert np.array_equal(off, off_f[13:301] - lo) and np.array_equal(col, col_f[lo:hi]) and np.array_equal(val, val_f[lo:hi])
+
+
+@pytest.mark.parametrize("dtype,n_rows", [(np.float64, 200_000), (np.float32, 150_000)], ids=["f64", "f32"])
+def test_powerlaw_merge_parity(gpu, dtype, n_rows):
+    """BASELINE C3 shape at a size the oracle finishes in seconds."""
+    m = synth.crs_powerlaw(synth.SEED_MATRIX, n_rows, n_rows, dtype)
+    off, col, val = m.raw_parts()
+    x = oracle.gen_x(synth.SEED_X, n_rows, dtype)
+    for variant in ("merge", "vector", "auto"):
+        assert_spmv_close(m.mvp(x, variant=variant), off, col, val, x, variant)
+    assert np.array_equal(m.mvp(x, variant="seq").view(np.uint8), oracle.spmv(off, col, val, x).view(np.uint8))
+
+
+def test_full_size_c2_properties(gpu):
+    """BASELINE C2 (10M rows x 32, f32) at full size through size-independent properties:
+    sampled row blocks vs the oracle (which regenerates those rows itself), SEQ bit-exact on the
+    samples, the two independent kernels agree everywhere, and linearity."""
+    n, k = 10_000_000, 32
+    m = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32)
+    assert m.n_non_zero_entries() == n * k and m.resolved_variant() == ("vector", 8)
+    xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
+    x = xbuf.download(np.float32, n)
+    ys = {}
+    for variant in ("vector", "merge", "seq"):
+        ybuf = synth.DeviceBuffer(n * 4)
+        m.mvp_dev(xptr, n, ybuf.ptr, variant)
+        sm.lib().smh_device_synchronize()
+        ys[variant] = ybuf.download(np.float32, n)
+    # (a) sampled row blocks against the oracle on rows it regenerates independently
+    for rb in (0, 1, 4095, 4_999_000, n - 3000):
+        re = min(n, rb + 3000)
+        off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32, rb, re)
+        y_ref = oracle.spmv(off, col, val, x)
+        assert np.array_equal(ys["seq"][rb:re].view(np.uint32), y_ref.view(np.uint32))
+        assert_spmv_close(ys["vector"][rb:re], off, col, val, x, "vector rows %d.." % rb)
+        assert_spmv_close(ys["merge"][rb:re], off, col, val, x, "merge rows %d.." % rb)
+    # (b) independent kernels agree on every row (|y| <= 32, sum|a x| ~ 8)
+    assert np.abs(ys["vector"].astype(np.float64) - ys["seq"]).max() < 5e-5
+    assert np.abs(ys["merge"].astype(np.float64) - ys["seq"]).max() < 5e-5
+    # (c) linearity: A(2x) == 2 A x exactly (power-of-two scaling commutes with every rounding)
+    x2 = synth.DeviceBuffer(n * 4)
+    x2.upload(x * np.float32(2))
+    y2 = synth.DeviceBuffer(n * 4)
+    m.mvp_dev(x2.ptr, n, y2.ptr, "vector")
+    sm.lib().smh_device_synchronize()
+    assert np.array_equal(y2.download(np.float32, n), ys["vector"] * np.float32(2))
