@@ -16,8 +16,9 @@
  *   - host arrays are borrowed for the duration of the call only.
  *   - value type T is f32 or f64 (smh_dtype); index type I is u32 (the reference's
  *     SparseMatCRS<T,u32>; other index widths stay on the reference's CPU path).
- *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (as void*, may be
- *     NULL = the handle's own stream) and are asynchronous; the others synchronise.
+ *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (as void*; NULL is the
+ *     HIP null stream, as everywhere in HIP) and are asynchronous; the others run on the
+ *     handle's private stream and synchronise before returning.
  *
  * Each entry point cites the reference interface it replaces (paths relative to the
  * reference repository root).
@@ -99,6 +100,15 @@ int smh_crs_scale(smh_crs *m, double a);
 int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out);
 /* override the VECTOR kernel's lanes-per-row (1,2,4,...,64; 0 = automatic) */
 int smh_crs_set_vector_lanes(smh_crs *m, int lanes);
+/* K1r, the VECTOR kernel with an LDS-resident sliding window of x: mode -1 =
+ * automatic (used when >= half of the rows fit the ring), 0 = never, 1 = whenever lanes <= 8 */
+int smh_crs_set_ring(smh_crs *m, int mode);
+/* the K1r phase plan (integer structure, invariants checked in tests): phase_ptr_out needs
+ * n_blocks+1 entries, phases_out 5 u32 per phase {row_begin,row_end,load_lo,load_hi,use_ring};
+ * call first with NULL arrays to get the sizes.                                           */
+int smh_crs_ring_plan(smh_crs *m, uint32_t *n_blocks_out, size_t *n_phases_out,
+                      double *ring_fraction_out, int *active_out, uint32_t *phase_ptr_out,
+                      uint32_t *phases_out);
 
 /* SparseMatrix::mvp (sparsematrix.rs:146-158) == `A * v` (Mul, sparsematrix.rs:435-443):
  * y[0..n_rows) = A.x.  x_len is x.dim(); a column index >= x_len is SMH_ERR_INDEX_RANGE
@@ -158,7 +168,8 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
 
 /* ---- synthetic workloads (bench / test support, DESIGN.md "Synthetic inputs") ------------
  * Counter-based generators writing straight into device memory so 10M..80M-row inputs never
- * cross PCIe.  pattern: 0 banded-stratified (ascending), 1 uniform (draw order).          */
+ * cross PCIe.  pattern: 0 banded-stratified (ascending), 1 uniform (draw order),
+ * 2 contiguous band (k consecutive columns around the diagonal).          */
 int smh_synth_x(smh_dtype dtype, uint64_t seed, size_t begin, size_t n, void *x_dev, void *stream);
 int smh_synth_fixed(smh_dtype dtype, uint64_t seed, int pattern, size_t n, uint32_t k,
                     size_t row_begin, size_t row_end, uint32_t *offset_rows_dev,

@@ -240,6 +240,12 @@ void orc_gen_x_f64(uint64_t seed, size_t begin, size_t n, double *x) {
                 uint64_t hc = orc_splitmix64(rk + 2ull * j);                                  \
                 uint64_t hv = orc_splitmix64(rk + 2ull * j + 1ull);                           \
                 uint64_t c = pattern == 0 ? (uint64_t)base + j * s + hc % s : hc % n;         \
+                if (pattern == 2) {                                                           \
+                    int64_t b2 = (int64_t)row - (int64_t)(k / 2);                             \
+                    if (b2 > (int64_t)n - (int64_t)k) b2 = (int64_t)n - (int64_t)k;           \
+                    if (b2 < 0) b2 = 0;                                                       \
+                    c = (uint64_t)b2 + j;                                                     \
+                }                                                                             \
                 columns[o + j] = (uint32_t)c;                                                 \
                 values[o + j] = H2V(hv);                                                      \
             }                                                                                 \

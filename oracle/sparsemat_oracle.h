@@ -102,7 +102,8 @@ void orc_gen_x_f32(uint64_t seed, size_t begin, size_t n, float *x);
 void orc_gen_x_f64(uint64_t seed, size_t begin, size_t n, double *x);
 /* fixed `k` nnz per row, rows [row_begin,row_end) of an n x n matrix; offsets
  * are rebased to the block (offset_rows[0]==0), columns stay global.
- * pattern 0 = banded-stratified (ascending), 1 = uniform (draw order). */
+ * pattern 0 = banded-stratified (ascending), 1 = uniform (draw order),
+ * 2 = contiguous band (k consecutive columns around the diagonal). */
 void orc_gen_fixed_f32(uint64_t seed, int pattern, size_t n, uint32_t k, size_t row_begin,
                        size_t row_end, uint32_t *offset_rows, uint32_t *columns, float *values);
 void orc_gen_fixed_f64(uint64_t seed, int pattern, size_t n, uint32_t k, size_t row_begin,

@@ -42,6 +42,8 @@ SIGNATURES = {
     "smh_crs_scale": (_int, [_vp, C.c_double]),
     "smh_crs_resolved_variant": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "smh_crs_set_vector_lanes": (_int, [_vp, _int]),
+    "smh_crs_set_ring": (_int, [_vp, _int]),
+    "smh_crs_ring_plan": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(C.c_double), C.POINTER(_int), _vp, _vp]),
     "smh_crs_spmv": (_int, [_vp, _vp, _sz, _vp, _int]),
     "smh_crs_spmv_dev": (_int, [_vp, _vp, _sz, _vp, _int, _vp]),
     "smh_crs_merge_tiles": (_sz, [_vp]),

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "internal.hpp"
 
@@ -65,6 +66,8 @@ int synth_fill(int dtype, uint64_t seed, size_t n_cols, size_t row_begin, size_t
 size_t synth_laplace3d_nnz(size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end);
 int synth_laplace3d(int dtype, size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end, uint32_t *off,
                     uint32_t *col, void *val, hipStream_t s);
+void build_ring_plan(size_t n_rows, size_t elem_size, const uint32_t *cmin, const uint32_t *cmax, size_t n_blocks,
+                     std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases, double *ring_row_fraction);
 void synth_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf);
 void synth_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax, const uint32_t *cdf,
                             uint32_t *lengths);
@@ -112,14 +115,68 @@ static int ensure_merge_ws(smh_crs *m) {
     return SMH_OK;
 }
 
+// K1r: inspector pass + host plan, once per matrix
+static int ensure_ring_plan(smh_crs *m) {
+    if (m->ring_planned) return SMH_OK;
+    const size_t n_tiles = (m->n_rows + 63) / 64;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    unsigned blocks = (unsigned)(2 * cus);  // two 512-thread blocks (64 KiB of LDS each) per CU
+    blocks = (blocks + 7u) & ~7u;
+    std::vector<uint32_t> cmin(n_tiles), cmax(n_tiles);
+    if (n_tiles) {
+        uint32_t *d_min = nullptr, *d_max = nullptr;
+        SMH_HIP(hipMalloc((void **)&d_min, n_tiles * sizeof(uint32_t)));
+        hipError_t e = hipMalloc((void **)&d_max, n_tiles * sizeof(uint32_t));
+        int rc = e == hipSuccess ? launch_tile_span(m->d_off, m->d_col, m->n_rows, n_tiles, d_min, d_max, m->stream)
+                                 : hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+        if (rc == SMH_OK) {
+            e = hipMemcpyAsync(cmin.data(), d_min, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(cmax.data(), d_max, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "tile span readback", __FILE__, __LINE__);
+        }
+        (void)hipFree(d_min); (void)hipFree(d_max);
+        SMH_TRY(rc);
+    }
+    std::vector<uint32_t> phase_ptr;
+    std::vector<RingPhase> phases;
+    build_ring_plan(m->n_rows, dtype_size(m->dtype), cmin.data(), cmax.data(), blocks, phase_ptr, phases, &m->ring_fraction);
+    SMH_HIP(hipMalloc((void **)&m->d_phase_ptr, phase_ptr.size() * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_phases, (phases.size() + 1) * sizeof(RingPhase)));
+    SMH_HIP(hipMemcpy(m->d_phase_ptr, phase_ptr.data(), phase_ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!phases.empty())
+        SMH_HIP(hipMemcpy(m->d_phases, phases.data(), phases.size() * sizeof(RingPhase), hipMemcpyHostToDevice));
+    m->ring_blocks = blocks;
+    m->ring_n_phases = phases.size();
+    m->ring_planned = true;
+    return SMH_OK;
+}
+
+// does the VECTOR family run as K1r (LDS x-ring) for this matrix?
+static int vector_uses_ring(smh_crs *m, bool *out) {
+    *out = false;
+    if (m->use_ring == 0 || auto_lanes(m) > 8 || m->n_rows == 0) return SMH_OK;
+    SMH_TRY(ensure_ring_plan(m));
+    *out = m->use_ring == 1 || m->ring_fraction >= 0.5;
+    return SMH_OK;
+}
+
 // enqueue y = A x on stream s (device pointers)
 static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s) {
     if (m->nnz > 0 && (size_t)m->max_col >= x_len)
         return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, m->max_col);
     const int v = resolve_variant(m, variant);
     switch (v) {
-        case SMH_SPMV_VECTOR:
+        case SMH_SPMV_VECTOR: {
+            bool ring = false;
+            SMH_TRY(vector_uses_ring(m, &ring));
+            if (ring)
+                return launch_spmv_ring(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->nnz,
+                                        m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
             return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, s);
+        }
         case SMH_SPMV_SEQ:
             return launch_spmv_seq(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, s);
         case SMH_SPMV_MERGE:
@@ -289,6 +346,7 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
+    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);
     (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
@@ -335,6 +393,30 @@ int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out)
     return SMH_OK;
 }
 
+int smh_crs_set_ring(smh_crs *m, int mode) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "ring mode must be -1 (auto), 0 (off) or 1 (on)");
+    m->use_ring = mode;
+    return SMH_OK;
+}
+
+int smh_crs_ring_plan(smh_crs *m, uint32_t *n_blocks_out, size_t *n_phases_out, double *ring_fraction_out,
+                      int *active_out, uint32_t *phase_ptr_out, uint32_t *phases_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(ensure_ring_plan(m));
+    bool ring = false;
+    SMH_TRY(vector_uses_ring(m, &ring));
+    if (n_blocks_out) *n_blocks_out = m->ring_blocks;
+    if (n_phases_out) *n_phases_out = m->ring_n_phases;
+    if (ring_fraction_out) *ring_fraction_out = m->ring_fraction;
+    if (active_out) *active_out = ring ? 1 : 0;
+    if (phase_ptr_out)
+        SMH_HIP(hipMemcpy(phase_ptr_out, m->d_phase_ptr, (m->ring_blocks + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (phases_out && m->ring_n_phases)
+        SMH_HIP(hipMemcpy(phases_out, m->d_phases, m->ring_n_phases * sizeof(RingPhase), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
 int smh_crs_set_vector_lanes(smh_crs *m, int lanes) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (lanes != 0 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))))
@@ -346,7 +428,7 @@ int smh_crs_set_vector_lanes(smh_crs *m, int lanes) {
 int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant, void *stream) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (m->n_rows && (!y_dev || (m->nnz && !x_dev))) return fail(SMH_ERR_INVALID, "NULL device vector");
-    return spmv_enqueue(m, x_dev, x_len, y_dev, variant, stream ? (hipStream_t)stream : m->stream);
+    return spmv_enqueue(m, x_dev, x_len, y_dev, variant, (hipStream_t)stream);
 }
 
 int smh_crs_spmv(smh_crs *m, const void *x_host, size_t x_len, void *y_host, int variant) {

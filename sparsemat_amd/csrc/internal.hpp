@@ -51,6 +51,17 @@ int launch_merge_table(const uint32_t *off, size_t n_rows, size_t nnz, size_t n_
 int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
                       void *y, size_t n_rows, size_t nnz, size_t n_tiles, const uint32_t *tile_row,
                       const uint32_t *tile_nz, uint32_t *carry_row, void *carry_val, hipStream_t s);
+// K1r (LDS x-ring): inspector, host plan, kernel
+struct RingPhase {
+    uint32_t row_begin, row_end;  // rows of this phase (row_begin is a multiple of 64)
+    uint32_t load_lo, load_hi;    // columns of x to add to the LDS ring before the phase (may be empty)
+    uint32_t use_ring;            // 0: the phase's column span exceeds the ring -> global gathers
+};
+int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t n_tiles, uint32_t *cmin,
+                     uint32_t *cmax, hipStream_t s);
+int launch_spmv_ring(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
+                     void *y, size_t nnz, unsigned n_blocks, const uint32_t *phase_ptr, const RingPhase *phases,
+                     hipStream_t s);
 // structure statistics / validation
 struct CrsStats {
     uint32_t max_row_len;
@@ -87,6 +98,14 @@ struct smh_crs {
     size_t n_tiles = 0;
     uint32_t *d_tile_row = nullptr, *d_tile_nz = nullptr, *d_carry_row = nullptr;
     void *d_carry_val = nullptr;
+    // K1r plan (lazy)
+    bool ring_planned = false;
+    unsigned ring_blocks = 0;
+    double ring_fraction = 0.0;  // share of rows whose gathers are served from the LDS ring
+    size_t ring_n_phases = 0;
+    uint32_t *d_phase_ptr = nullptr;
+    smh::RingPhase *d_phases = nullptr;
+    int use_ring = -1;  // -1 automatic, 0 never, 1 always (when lanes <= 8)
     // staging for the host-pointer API (lazy, reused)
     void *d_x = nullptr, *d_y = nullptr;
     size_t d_x_cap = 0, d_y_cap = 0;

@@ -55,7 +55,13 @@ __global__ void k_synth_fixed(uint64_t seed, int pattern, uint64_t n, uint32_t k
         int64_t base = (int64_t)row - (int64_t)(w / 2);
         if (base > (int64_t)n - (int64_t)w) base = (int64_t)n - (int64_t)w;
         if (base < 0) base = 0;
-        const uint64_t c = pattern == 0 ? (uint64_t)base + j * s + hc % s : hc % n;
+        uint64_t c = pattern == 0 ? (uint64_t)base + j * s + hc % s : hc % n;
+        if (pattern == 2) {  // contiguous band of k columns centred on the diagonal
+            int64_t b2 = (int64_t)row - (int64_t)(k / 2);
+            if (b2 > (int64_t)n - (int64_t)k) b2 = (int64_t)n - (int64_t)k;
+            if (b2 < 0) b2 = 0;
+            c = (uint64_t)b2 + j;
+        }
         col[e] = (uint32_t)c;
         val[e] = hash_to_unit<T>(hv);
         if (j == 0) off[lr] = (uint32_t)e;

@@ -111,6 +111,20 @@ class SparseMatCRS:
     def set_vector_lanes(self, lanes):
         check(lib().smh_crs_set_vector_lanes(self._h, lanes))
 
+    def set_ring(self, mode):
+        """K1r (LDS x-ring) for the vector family: -1 automatic, 0 off, 1 on."""
+        check(lib().smh_crs_set_ring(self._h, mode))
+
+    def ring_plan(self):
+        """(n_blocks, ring_fraction, active, phase_ptr, phases[n,5]) of the K1r plan."""
+        nb, nph, frac, act = C.c_uint32(), C.c_size_t(), C.c_double(), C.c_int()
+        check(lib().smh_crs_ring_plan(self._h, C.byref(nb), C.byref(nph), C.byref(frac), C.byref(act), None, None))
+        ptr = np.zeros(nb.value + 1, dtype=np.uint32)
+        ph = np.zeros((nph.value, 5), dtype=np.uint32)
+        check(lib().smh_crs_ring_plan(self._h, None, None, None, None, ptr.ctypes.data,
+                                      ph.ctypes.data if nph.value else None))
+        return nb.value, frac.value, bool(act.value), ptr, ph
+
     def max_row_len(self):
         out = C.c_uint32()
         check(lib().smh_crs_max_row_len(self._h, C.byref(out)))

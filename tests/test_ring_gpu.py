@@ -1,0 +1,112 @@
+"""K1r (vector kernel with the LDS x-ring): plan invariants (integer structure) and value parity."""
+import numpy as np
+import pytest
+
+import oracle
+import sparsemat_amd as sm
+from sparsemat_amd import synth
+from util import assert_spmv_close, random_crs
+
+pytestmark = pytest.mark.gpu
+RING_BYTES = 65536
+
+
+def check_plan(m, off, col):
+    """Every row is covered exactly once, in order, by its block's phases; a ring phase's window
+    (what the ring holds after its load) contains every column its rows reference."""
+    n_rows = len(off) - 1
+    ring = RING_BYTES // np.dtype(m.dtype).itemsize
+    nb, frac, active, ptr, ph = m.ring_plan()
+    assert nb % 8 == 0 and len(ptr) == nb + 1 and ptr[0] == 0 and ptr[-1] == len(ph)
+    assert np.all(np.diff(ptr.astype(np.int64)) >= 0)
+    next_row = 0
+    ring_rows = 0
+    for b in range(nb):
+        lo = hi = 0
+        for p in range(ptr[b], ptr[b + 1]):
+            rb, re, llo, lhi, use = (int(v) for v in ph[p])
+            assert rb == next_row and re > rb and rb % 64 == 0
+            next_row = re
+            if llo < lhi:
+                assert lhi - llo <= ring
+                if llo == hi and hi > lo:  # continuation of the window
+                    hi = lhi
+                    lo = max(lo, hi - ring)
+                else:  # restart
+                    lo, hi = llo, lhi
+            if use:
+                ring_rows += re - rb
+                cols = col[off[rb]:off[re]]
+                if len(cols):
+                    assert cols.min() >= lo and cols.max() < hi, (b, p, cols.min(), cols.max(), lo, hi)
+                    assert hi - lo <= ring
+    assert next_row == n_rows
+    assert abs(frac - ring_rows / max(n_rows, 1)) < 1e-12
+    return frac, active
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("pattern,n,k", [(synth.PATTERN_BANDED, 200_000, 32), (synth.PATTERN_DIAG, 70_001, 32),
+                                          (synth.PATTERN_UNIFORM, 50_000, 32), (synth.PATTERN_BANDED, 3000, 7)])
+def test_ring_plan_and_parity_generated(gpu, dtype, pattern, n, k):
+    m = synth.crs_fixed(synth.SEED_MATRIX, pattern, n, k, dtype)
+    off, col, val = m.raw_parts()
+    x = oracle.gen_x(synth.SEED_X, n, dtype)
+    frac, active = check_plan(m, off, col)
+    if pattern != synth.PATTERN_UNIFORM and not (dtype == np.float64 and pattern == synth.PATTERN_BANDED and k == 32):
+        assert frac == 1.0 and active
+    if pattern == synth.PATTERN_UNIFORM:
+        assert frac == 0.0 and not active  # span of a tile exceeds the ring: global gathers
+    for lanes in (1, 2, 4, 8):
+        m.set_vector_lanes(lanes)
+        for ring in (1, 0):
+            m.set_ring(ring)
+            assert_spmv_close(m.mvp(x, variant="vector"), off, col, val, x, "lanes%d ring%d" % (lanes, ring))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_ring_mixed_phases_random(gpu, dtype):
+    """Blocks of narrow-band rows interleaved with wide rows, empty rows and a window that jumps
+    backwards: ring phases, restarts and global-gather phases in one matrix."""
+    rng = np.random.default_rng(99)
+    n_rows, n_cols = 40_000, 300_000
+    lens = rng.integers(0, 40, size=n_rows)
+    lens[5000:5600] = 0
+    off = np.zeros(n_rows + 1, dtype=np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = np.empty(int(off[-1]), dtype=np.uint32)
+    centers = np.linspace(0, n_cols - 1, n_rows)
+    centers[20_000:30_000] = np.linspace(100_000, 0, 10_000)  # runs backwards
+    for i in range(n_rows):
+        a, b = off[i], off[i + 1]
+        if 12_000 <= i < 12_128 or i % 1777 == 0:  # wide rows: span the whole vector
+            col[a:b] = rng.integers(0, n_cols, size=b - a)
+        else:
+            lo = int(max(0, centers[i] - 1500))
+            col[a:b] = rng.integers(lo, min(n_cols, lo + 3000), size=b - a)
+    val = rng.uniform(-1, 1, size=len(col)).astype(dtype)
+    x = rng.uniform(-1, 1, size=n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    frac, _ = check_plan(m, off, col)
+    assert 0.5 < frac < 1.0
+    for lanes in (2, 8):
+        m.set_vector_lanes(lanes)
+        m.set_ring(1)
+        y = m.mvp(x, variant="vector")
+        assert_spmv_close(y, off, col, val, x, "mixed lanes%d" % lanes)
+        assert np.array_equal(y, m.mvp(x, variant="vector")), "ring kernel is bitwise reproducible"
+
+
+def test_ring_small_and_edge_shapes(gpu):
+    f = np.float32
+    rng = np.random.default_rng(4)
+    for n_rows, n_cols in [(1, 1), (63, 10), (64, 64), (65, 17_000), (129, 5)]:
+        lens = rng.integers(0, 70, size=n_rows)
+        off, col, val = random_crs(rng, n_rows, n_cols, lens, f, dup=True)
+        x = rng.uniform(-1, 1, n_cols).astype(f)
+        m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+        check_plan(m, off, col)
+        m.set_ring(1)
+        for lanes in (1, 2, 4, 8):
+            m.set_vector_lanes(lanes)
+            assert_spmv_close(m.mvp(x, variant="vector"), off, col, val, x, "%dx%d lanes%d" % (n_rows, n_cols, lanes))

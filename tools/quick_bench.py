@@ -35,10 +35,16 @@ def algo_bytes(m, n_x):
     return m.n_non_zero_entries() * (vs + 4) + (m.n_rows() + 1) * 4 + m.n_rows() * vs + n_x * vs
 
 
+def report(tag, B, med, mn):
+    print("  %-22s median %.3f ms  min %.3f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
+        tag, med, mn, B / med / 1e6, B / med / 1e6 / 80), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000)
-    ap.add_argument("--cases", default="banded,uniform,powerlaw")
+    ap.add_argument("--cases", default="banded,diag,uniform,powerlaw")
+    ap.add_argument("--lanes", default="4,8,16")
     args = ap.parse_args()
     torch.cuda.init()
     n = args.rows
@@ -46,26 +52,37 @@ def main():
         if case == "powerlaw":
             dtype = np.float64
             m = synth.crs_powerlaw(synth.SEED_MATRIX, n, n, dtype)
-        else:
+        elif case.startswith("lap"):
             dtype = np.float32
-            pat = synth.PATTERN_BANDED if case == "banded" else synth.PATTERN_UNIFORM
+            g = int(case[3:])
+            m = synth.crs_laplace3d(g, g, g, dtype)
+        else:
+            dtype = np.float64 if case.endswith("64") else np.float32
+            pat = {"banded": synth.PATTERN_BANDED, "uniform": synth.PATTERN_UNIFORM, "diag": synth.PATTERN_DIAG}[
+                case.replace("64", "")]
             m = synth.crs_fixed(synth.SEED_MATRIX, pat, n, 32, dtype)
-        xbuf, xptr = synth.gen_x(synth.SEED_X, n, dtype)
-        ybuf = synth.DeviceBuffer(n * np.dtype(dtype).itemsize)
-        B = algo_bytes(m, n)
-        print("== %s: rows %d nnz %d dtype %s auto=%s max_row %d bytes %.3f GB" % (
-            case, n, m.n_non_zero_entries(), np.dtype(dtype).name, m.resolved_variant(), m.max_row_len(), B / 1e9), flush=True)
-        for lanes in (2, 4, 8, 16, 32, 64):
+        nr = m.n_rows()
+        xbuf, xptr = synth.gen_x(synth.SEED_X, nr, dtype)
+        ybuf = synth.DeviceBuffer(nr * np.dtype(dtype).itemsize)
+        B = algo_bytes(m, nr)
+        nb, frac, act, ptr, ph = m.ring_plan()
+        print("== %s: rows %d nnz %d dtype %s auto=%s max_row %d bytes %.3f GB | ring: blocks %d phases %d fraction %.3f active %s" % (
+            case, nr, m.n_non_zero_entries(), np.dtype(dtype).name, m.resolved_variant(), m.max_row_len(), B / 1e9,
+            nb, len(ph), frac, act), flush=True)
+        for lanes in [int(v) for v in args.lanes.split(",")]:
             m.set_vector_lanes(lanes)
-            med, mn = time_variant(m, xptr, n, ybuf.ptr, "vector")
-            print("  vector lanes=%-2d  median %.3f ms  min %.3f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
-                lanes, med, mn, B / med / 1e6, B / med / 1e6 / 80), flush=True)
+            for ring in (0, 1):
+                if ring and lanes > 8:
+                    continue
+                m.set_ring(ring)
+                med, mn = time_variant(m, xptr, nr, ybuf.ptr, "vector")
+                report("vector lanes=%d ring=%d" % (lanes, ring), B, med, mn)
         m.set_vector_lanes(0)
-        med, mn = time_variant(m, xptr, n, ybuf.ptr, "merge")
-        print("  merge            median %.3f ms  min %.3f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
-            med, mn, B / med / 1e6, B / med / 1e6 / 80), flush=True)
-        med, mn = time_variant(m, xptr, n, ybuf.ptr, "seq", reps=3, warm=1)
-        print("  seq              median %.3f ms" % med, flush=True)
+        m.set_ring(-1)
+        med, mn = time_variant(m, xptr, nr, ybuf.ptr, "merge")
+        report("merge", B, med, mn)
+        med, mn = time_variant(m, xptr, nr, ybuf.ptr, "auto")
+        report("auto", B, med, mn)
         del m, xbuf, ybuf
 
 
