@@ -1,0 +1,189 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sparsemat_hip.h declares, fails loudly
+without a device (no CPU fallback), the product never touches oracle/, and the SparseMatPar host logic
+(partition arithmetic, gather layout) incl. a world_size-2 gloo run."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import sparsemat_amd as sm
+from sparsemat_amd import _lib, sparsemat_par
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sparsemat_hip.h")
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(smh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = sm.lib()
+    names = _declared_symbols()
+    assert len(names) >= 50
+    for name in names:
+        assert hasattr(L, name), "libsparsemat_hip.so lacks %s" % name
+        assert name in _lib.SIGNATURES, "python binding lacks %s" % name
+    assert sorted(_lib.SIGNATURES) == names, "binding declares symbols the header does not"
+    assert L.smh_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", sm.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (smh_[a-z0-9_]+)", out))
+    assert exported == set(names), exported ^ set(names)
+
+
+def test_library_is_built_for_gfx950_only():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", sm.LIB_PATH], capture_output=True, text=True)
+    blob = open(sm.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"sm_90"):
+        assert other not in blob
+
+
+def _no_gpu():
+    n = C.c_int(0)
+    sm.lib().smh_device_count(C.byref(n))
+    return n.value == 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
+def test_compute_fails_loudly_without_a_device():
+    f = np.float32
+    with pytest.raises(sm.SparseMatPanic) as e:
+        sm.SparseMatCRS.from_raw_parts(1, 1, [0, 1], [0], np.array([1.0], f))
+    assert e.value.status == _lib.SMH_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    with pytest.raises(sm.SparseMatPanic):
+        sm.DenseVec.from_vec(np.ones(3, f))
+    # argument errors are reported before the device is needed, with the reference's wording
+    h = C.c_void_p()
+    rc = sm.lib().smh_crs_create(0, 1, 1, 0xFFFFFFFF, None, None, None, 1, C.byref(h))
+    assert rc == _lib.SMH_ERR_CAPACITY and b"Maximum number of 4294967295 entries reached" in sm.lib().smh_last_error()
+    assert sm.lib().smh_status_string(_lib.SMH_ERR_NOT_SQUARE) == b"Matrix is not symmetric"
+    assert sm.lib().smh_status_string(_lib.SMH_ERR_DIM_MISMATCH) == b"Dimension mismatch"
+
+
+def test_product_never_uses_the_oracle():
+    """oracle/ is test infrastructure: nothing under sparsemat_amd/ or include/ may name it."""
+    for base in ("sparsemat_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    text = open(os.path.join(dirpath, fn), errors="replace").read()
+                    assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), fn
+                    assert "liboracle" not in text, fn
+                    assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", text), fn
+
+
+def test_laplace3d_closed_form_offsets_match_the_oracle():
+    """Host part of the device generator (size query needs no GPU): prefix counts are bit-exact."""
+    import oracle
+    for dims in [(1, 1, 1), (2, 1, 1), (1, 3, 1), (1, 1, 4), (3, 4, 5), (7, 7, 7)]:
+        off, col, val = oracle.laplace3d(*dims)
+        n = dims[0] * dims[1] * dims[2]
+        for rb in range(0, n + 1):
+            assert sm.synth.laplace3d_nnz(*dims, 0, rb) == off[rb]
+    assert sm.synth.laplace3d_nnz(512, 512, 512) == 937_951_232  # BASELINE C4
+
+
+def test_powerlaw_host_generator_matches_the_oracle():
+    import oracle
+    off = sm.synth.powerlaw_offsets(sm.synth.SEED_MATRIX, 50_000)
+    off_ref, _, _ = oracle.gen_powerlaw(sm.synth.SEED_MATRIX, 50_000, 50_000)
+    assert np.array_equal(off, off_ref)
+
+
+# ---- SparseMatPar host logic --------------------------------------------------------------------------
+def test_partition_arithmetic():
+    import oracle
+    for n_blocks, n_rows in [(4, 16), (4, 18), (8, 80_000_000), (3, 10), (2, 5), (1, 7)]:
+        r = sparsemat_par.rows_per_block(n_blocks, n_rows)
+        assert r == oracle.par_rows_per_block(n_blocks, n_rows) == n_rows // n_blocks  # sparsemat_par.rs:21
+        covered = []
+        for b in range(n_blocks):
+            lo, hi = sparsemat_par.block_range(n_blocks, n_rows, b)
+            assert lo == b * r  # results are placed at b * R (:64)
+            covered += list(range(lo, hi)) if n_rows < 100 else []
+        if n_rows < 100:
+            assert covered == list(range(n_rows))
+            for row in range(n_rows):
+                b, lr = sparsemat_par.block_and_row(n_blocks, n_rows, row)
+                ob, olr = oracle.par_block_and_row(n_blocks, r, row)
+                if ob < n_blocks:  # where the reference's clamp is in range the two agree
+                    assert (b, lr) == (ob, olr)
+                lo, hi = sparsemat_par.block_range(n_blocks, n_rows, b)
+                assert lo <= row < hi and lr == row - lo
+
+
+def test_split_crs_rebases_offsets_and_keeps_global_columns():
+    import oracle
+    rng = np.random.default_rng(0)
+    n_rows, n_cols = 103, 77
+    lens = rng.integers(0, 9, n_rows)
+    off = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = rng.integers(0, n_cols, off[-1]).astype(np.uint32)
+    val = rng.uniform(-1, 1, off[-1]).astype(np.float32)
+    x = rng.uniform(-1, 1, n_cols).astype(np.float32)
+    y = oracle.spmv(off, col, val, x)
+    parts = []
+    for b in range(4):
+        lo, lc, lv = sparsemat_par.split_crs(n_rows, off, col, val, 4, b)
+        assert lo[0] == 0 and lo[-1] == len(lc) == len(lv)
+        parts.append(oracle.spmv(lo, lc, lv, x))
+    assert np.array_equal(np.concatenate(parts), y)  # bit-exact: row sums do not depend on the split
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import oracle
+from sparsemat_amd import sparsemat_par
+from sparsemat_amd.sparsemat_par import SparseMatPar
+
+class CheckerBlock:  # test-only local product (the CPU oracle); the product's block is HipBlock
+    def __init__(self, off, col, val):
+        self.off, self.col, self.val, self.n_rows = off, col, val, len(off) - 1
+    def mvp_into(self, x, y):
+        y.copy_(torch.from_numpy(oracle.spmv(self.off, self.col, self.val, x.numpy())))
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+for n_rows in (64, 101):  # even split (in-place gather) and ragged last block (padded gather)
+    rng = np.random.default_rng(42)
+    n_cols = n_rows
+    lens = rng.integers(0, 12, n_rows)
+    off = np.zeros(n_rows + 1, np.uint32); np.cumsum(lens, out=off[1:])
+    col = rng.integers(0, n_cols, off[-1]).astype(np.uint32)
+    val = rng.uniform(-1, 1, off[-1]).astype(np.float32)
+    x = rng.uniform(-1, 1, n_cols).astype(np.float32)
+    lo, lc, lv = sparsemat_par.split_crs(n_rows, off, col, val, world, rank)
+    par = SparseMatPar.with_sub_matrices(world, n_rows, n_cols, rank, CheckerBlock(lo, lc, lv))
+    y_ref = oracle.spmv(off, col, val, x)
+    xt = torch.from_numpy(x.copy())
+    for it in range(3):  # iterate: the gathered vector feeds the next product (CG-style)
+        yt = par.mvp(xt)
+        assert yt.shape == (n_rows,)
+        assert np.array_equal(yt.numpy(), y_ref), (rank, n_rows, it)
+        xt = yt.clone(); y_ref = oracle.spmv(off, col, val, y_ref)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %%d ok" %% rank)
+'''
+
+
+def test_sparsemat_par_gloo_world_size_2(tmp_path):
+    """N>1 path on CPU: 2 processes, gloo, local products by the checker block, all-gather layout."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in o, o

@@ -1,0 +1,176 @@
+"""CPU: the oracle pinned to the reference's own known-answer tests (tests/golden/reference_kats.json),
+the assembly restatement's storage order, and independent cross-checks (scipy)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import oracle
+from oracle import assembly
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")
+with open(GOLDEN) as f:
+    CASES = json.load(f)["cases"]
+
+
+def _values(case):
+    crs = case["crs"]
+    if case["dtype"] == "f32":
+        return np.array([int(b, 16) for b in crs["values_bits"]], dtype=np.uint32).view(np.float32)
+    return np.array([int(b, 16) for b in crs["values_bits"]], dtype=np.uint64).view(np.float64)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if "expect_mvp" in c], ids=lambda c: c["name"])
+def test_oracle_spmv_reproduces_reference_asserts(case):
+    """assert_eq!(mvp.get(0), 34.544) / 20.16 (src/lib.rs:81,151,175,199): exact f32 equality."""
+    crs, dt = case["crs"], np.float32
+    val = _values(case)
+    x = np.array([dt(float(s)) for s in case["x"]], dtype=dt)
+    y = oracle.spmv(crs["offset_rows"], crs["columns"], val, x)
+    assert len(y) == crs["n_rows"]  # dim == n_rows (vector.rs:40-42 growth)
+    for i, lit in case["expect_mvp"]:
+        assert y[i] == dt(float(lit))
+    # a sorted-column accumulation does NOT reproduce 34.544: the oracle must keep storage order
+    if case["name"] == "check_sparsemat_indexlist":
+        off, col = crs["offset_rows"], np.array(crs["columns"])
+        order = np.argsort(col[off[0]:off[1]], kind="stable")
+        s = dt(0)
+        for k in order:
+            s = dt(s + dt(x[col[k]] * val[k]))
+        assert s != dt(34.544)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if "ops" in c], ids=lambda c: c["name"])
+def test_assembly_restatement_storage_order(case):
+    """Replaying the reference tests' call sequences yields the committed CRS arrays and the iteration
+    orders the reference asserts (src/lib.rs:67-71, 122-128)."""
+    dt = np.float32 if case["dtype"] == "f32" else np.float64
+    name = case["name"]
+    if name == "check_sparsemat_crs":
+        m = assembly.CrsPushMatrix(dt)
+    elif name == "check_sparsemat_par":
+        m = assembly.ParMatrix(case["par"]["n_blocks"], case["par"]["max_n_rows"], dt)
+    else:
+        m = assembly.IndexListMatrix(dt)
+    for op, i, j, lit in case["ops"]:
+        getattr(m, op)(i, j, dt(float(lit)))
+    n_rows, n_cols, off, col, val = m.to_crs_arrays()
+    crs = case["crs"]
+    assert (n_rows, n_cols) == (crs["n_rows"], crs["n_cols"])
+    assert list(off) == crs["offset_rows"] and list(col) == crs["columns"]
+    assert np.array_equal(val, _values(case))
+    flat = [(i, int(col[k]), val[k]) for i in range(n_rows) for k in range(off[i], off[i + 1])]
+    for key in ("iter_prefix", "iter_full"):
+        if key in case:
+            for (i, j, lit), got in zip(case[key], flat):
+                assert (i, j) == got[:2] and got[2] == dt(float(lit))
+            if key == "iter_full":
+                assert len(flat) == len(case[key])
+    for i, j, lit in case.get("expect_get", []):
+        assert m.get(i, j) == dt(float(lit))
+    for i, dense in case.get("expect_row_dense", []):
+        row = np.zeros(n_cols, dt)
+        for k in range(off[i], off[i + 1]):
+            row[col[k]] = val[k]
+        assert [("%s" % v) for v in row] == ["0.0" if d == "0" else d for d in dense]
+    if "expect_density" in case:
+        num, den = case["expect_density"]
+        assert len(val) / (n_rows * n_cols) == num / den
+
+
+def test_oracle_cg_reproduces_reference_assert():
+    """check_cg (src/lib.rs:36-52)."""
+    case = [c for c in CASES if c["name"] == "check_cg"][0]
+    crs = case["crs"]
+    b = np.array([float(s) for s in case["b"]])
+    x0 = np.array([float(s) for s in case["x0"]])
+    x, iters, rr = oracle.cg(crs["n_rows"], crs["n_cols"], crs["offset_rows"], crs["columns"], _values(case), b, x0,
+                             tol=case["cg"]["tol"], iter_max=case["cg"]["iter_max"])
+    for i, lit in case["expect_floor_1e4"]:
+        assert np.floor(x[i] * 1e4) / 1e4 == float(lit)
+    assert iters == 2 and np.sqrt(rr) < 1e-12
+    np.testing.assert_allclose(x, [1 / 11, 7 / 11], rtol=1e-14)
+
+
+def test_oracle_panics_mirror_the_reference():
+    f = np.float64
+    with pytest.raises(oracle.OraclePanic) as e:  # densevec.rs:41
+        oracle.spmv([0, 1], [3], np.array([1.0]), np.ones(3))
+    assert e.value.code == oracle.ORC_ERR_INDEX_OOB
+    with pytest.raises(oracle.OraclePanic) as e:  # linearsolver.rs:30-32
+        oracle.cg(2, 3, [0, 1, 2], [0, 2], np.array([1, 2], f), np.ones(2), np.zeros(2))
+    assert str(e.value) == "Matrix is not symmetric"
+    with pytest.raises(oracle.OraclePanic) as e:  # linearsolver.rs:33-36
+        oracle.cg(2, 2, [0, 1, 2], [0, 1], np.array([1, 2], f), np.ones(3), np.zeros(2))
+    assert str(e.value) == "Matrix and vector size mismatch"
+    with pytest.raises(oracle.OraclePanic):  # densevec.rs:52-54
+        oracle.vec_add(np.ones(2), np.ones(3))
+    assert np.array_equal(oracle.vec_add(np.ones(3), np.ones(2)), [2, 2, 1])  # zip truncation
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_oracle_against_scipy(dtype):
+    """Third-party sanity (tolerance only): scipy CSR product and CG on an SPD Laplacian."""
+    rng = np.random.default_rng(1)
+    n_rows, n_cols = 500, 400
+    lens = rng.integers(0, 50, n_rows)
+    off = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = rng.integers(0, n_cols, off[-1]).astype(np.uint32)
+    val = rng.uniform(-1, 1, off[-1]).astype(dtype)
+    x = rng.uniform(-1, 1, n_cols).astype(dtype)
+    a = sp.csr_matrix((val.astype(np.float64), col, off), shape=(n_rows, n_cols))
+    np.testing.assert_allclose(oracle.spmv(off, col, val, x), a @ x.astype(np.float64), rtol=0,
+                               atol=60 * np.finfo(dtype).eps * 50)
+    off, col, val = oracle.laplace3d(6, 5, 4, np.float64)
+    n = 120
+    a = sp.csr_matrix((val, col, off), shape=(n, n))
+    assert (abs(a - a.T)).nnz == 0
+    b = rng.uniform(-1, 1, n)
+    xs, info = spla.cg(a, b, rtol=1e-12, atol=0)
+    xo, iters, rr = oracle.cg(n, n, off, col, val, b, np.zeros(n), tol=1e-11)
+    assert info == 0 and iters < 200
+    np.testing.assert_allclose(xo, xs, rtol=1e-8, atol=1e-10)
+
+
+def test_oracle_blas1_and_reductions():
+    rng = np.random.default_rng(2)
+    a, b = rng.uniform(-1, 1, 1000).astype(np.float32), rng.uniform(-1, 1, 1000).astype(np.float32)
+    s = np.float32(0)
+    for u, v in zip(a, b):
+        s = np.float32(s + np.float32(u * v))  # left fold, two roundings (vector.rs:50-53)
+    assert oracle.dot(a, b) == s
+    assert oracle.norm(a) == np.sqrt(np.float64(oracle.norm_squared(a)))
+    al = np.float32(0.37)
+    assert np.array_equal(oracle.vec_axpy(a, al, b), (a + (b * al)).astype(np.float32))
+    assert np.array_equal(oracle.vec_xpby(a, al, b), ((a * al) + b).astype(np.float32))
+
+
+def test_oracle_par_arithmetic_keeps_the_reference_clamp():
+    """sparsemat_par.rs:21 (integer division) and :31-35 (clamp to n_blocks, the reference's off-by-one)."""
+    assert oracle.par_rows_per_block(4, 16) == 4 and oracle.par_rows_per_block(4, 18) == 4
+    assert oracle.par_block_and_row(4, 4, 0) == (0, 0)
+    assert oracle.par_block_and_row(4, 4, 15) == (3, 3)
+    assert oracle.par_block_and_row(4, 4, 17) == (4, 1)  # block id 4 of 4: out of bounds in the reference
+
+
+def test_generators_are_deterministic_and_in_range():
+    off, col, val = oracle.gen_fixed(1, oracle.PATTERN_BANDED, 10_000, 32, np.float32, 100, 400)
+    assert off[0] == 0 and off[-1] == 300 * 32 and col.max() < 10_000
+    c = col.reshape(-1, 32).astype(np.int64)
+    assert np.all(np.diff(c, axis=1) > 0)
+    rows = np.arange(100, 400)[:, None]
+    assert np.all(np.abs(c - rows) <= 8192)
+    off2, col2, val2 = oracle.gen_fixed(1, oracle.PATTERN_BANDED, 10_000, 32, np.float32, 100, 400)
+    assert np.array_equal(col, col2) and np.array_equal(val, val2)
+    assert val.min() >= -1 and val.max() < 1
+    cdf = oracle.powerlaw_cdf()
+    assert np.all(np.diff(cdf.astype(np.int64)) >= 0) and cdf[-1] == 0xFFFFFFFF
+    off, col, val = oracle.gen_powerlaw(5, 20_000, 20_000)
+    lens = np.diff(off.astype(np.int64))
+    assert lens.min() >= 1 and lens.max() <= 2048 and 15 < lens.mean() < 60
+    off, col, val = oracle.laplace2d(1000, 1000)
+    assert len(val) == 4_996_000  # BASELINE C1: nnz of the 1000x1000 5-point Laplacian
