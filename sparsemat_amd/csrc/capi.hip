@@ -159,7 +159,7 @@ static int vector_uses_ring(smh_crs *m, bool *out) {
     *out = false;
     if (m->use_ring == 0 || auto_lanes(m) > 8 || m->n_rows == 0) return SMH_OK;
     SMH_TRY(ensure_ring_plan(m));
-    *out = m->use_ring == 1 || m->ring_fraction >= 0.5;
+    *out = m->use_ring >= 1 || m->ring_fraction >= 0.5;
     return SMH_OK;
 }
 
@@ -172,9 +172,13 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
         case SMH_SPMV_VECTOR: {
             bool ring = false;
             SMH_TRY(vector_uses_ring(m, &ring));
-            if (ring)
+            if (ring && m->use_ring == 2)
                 return launch_spmv_ring(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->nnz,
                                         m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
+            if (ring)
+                // owned arrays are padded to a multiple of 4 entries; borrowed ones may end inside a 16-B chunk
+                return launch_spmv_ring2(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz,
+                                         m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
             return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, s);
         }
         case SMH_SPMV_SEQ:
@@ -346,8 +350,7 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
-    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);
-    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
+    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
     return SMH_OK;
@@ -395,7 +398,7 @@ int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out)
 
 int smh_crs_set_ring(smh_crs *m, int mode) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
-    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "ring mode must be -1 (auto), 0 (off) or 1 (on)");
+    if (mode < -1 || mode > 2) return fail(SMH_ERR_INVALID, "ring mode must be -1 (auto), 0 (off), 1 (on) or 2 (on, unpipelined body)");
     m->use_ring = mode;
     return SMH_OK;
 }

@@ -62,6 +62,9 @@ int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 int launch_spmv_ring(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
                      void *y, size_t nnz, unsigned n_blocks, const uint32_t *phase_ptr, const RingPhase *phases,
                      hipStream_t s);
+int launch_spmv_ring2(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
+                      void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
+                      const RingPhase *phases, hipStream_t s);
 // structure statistics / validation
 struct CrsStats {
     uint32_t max_row_len;
@@ -105,7 +108,7 @@ struct smh_crs {
     size_t ring_n_phases = 0;
     uint32_t *d_phase_ptr = nullptr;
     smh::RingPhase *d_phases = nullptr;
-    int use_ring = -1;  // -1 automatic, 0 never, 1 always (when lanes <= 8)
+    int use_ring = -1;  // -1 automatic, 0 never, 1 always (when lanes <= 8), 2 always with the first K1r body
     // staging for the host-pointer API (lazy, reused)
     void *d_x = nullptr, *d_y = nullptr;
     size_t d_x_cap = 0, d_y_cap = 0;

@@ -1,0 +1,267 @@
+// spmv_ring2.hip -- K1r, software-pipelined body (same plan, same result as spmv_ring.hip).
+//
+// Profile of the first K1r body (profiles/r01_pmc_sq_ring_v1.json): waves are parked on memory 81 % of
+// their cycles and every wave alternates "issue 8 KiB of loads -> wait -> reduce", so the bytes in
+// flight per CU sag while a wave computes.  This body keeps every wave's memory queue primed:
+//
+//   unit  = SB steps x (64/LANES) rows of one wave (LANES 8: 4 steps x 8 rows = 32 rows, 8 KiB of
+//           columns+values)
+//   per iteration, in program order (vmcnt retires in order, so older loads must be the ones needed
+//   first):   offsets(unit+2)  ->  chunk loads(unit+1)  ->  consume(unit)
+//   i.e. row offsets are fetched two units ahead (one coalesced load per unit, fanned out to the lane
+//   groups with ds_bpermute), the 16-B column/value chunks one unit ahead, and the LDS gathers / FMAs /
+//   butterfly / transposed coalesced store of the current unit run under the next unit's HBM latency.
+//   Steady state is straight-line code (no branch between issue and consume), so hipcc's counted
+//   s_waitcnt vmcnt(N) leaves exactly the next unit's loads in flight.
+//   All chunk loads are unconditional and branch-free: addresses are clamped to the last whole chunk
+//   that is safe to read, entries outside the row are masked with selects (never multiplied in: LDS
+//   garbage may be NaN), and the <= 3 entries of an unpadded array's final partial chunk are added by
+//   a one-thread fix-up kernel (in storage order: they are the last entries of their rows).
+#include "internal.hpp"
+
+namespace smh {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kRing2Threads = 512;
+constexpr int kRing2Bytes = 65536;
+constexpr int kRing2Waves = kRing2Threads / kWave;
+#ifndef SMH_RING2_SB
+#define SMH_RING2_SB 2
+#endif
+constexpr int kRing2SB = SMH_RING2_SB;  // steps per unit: two units x SB x 32 B per lane live in VGPRs
+
+template <typename T, int SB>
+struct Unit {
+    uint32_t o0, o1;  // lane L: off[base+L], off[base+L+1] (rows clamped to the phase end)
+    uint32_t c[SB][4];
+    T v[SB][4];
+};
+
+template <typename T>
+__device__ __forceinline__ void load_chunk_nb(const uint32_t *__restrict__ col, const T *__restrict__ val, uint64_t k,
+                                              uint32_t (&c)[4], T (&v)[4]) {
+    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(col + k));
+    c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(val + k));
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else {
+        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k));
+        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k + 2));
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    }
+}
+
+__device__ __forceinline__ float r2_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double r2_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename T, int SB>
+__device__ __forceinline__ void load_offsets(Unit<T, SB> &u, const uint32_t *__restrict__ off, uint64_t base,
+                                             uint64_t row_end, uint32_t lane) {
+    uint64_t r0 = base + lane, r1 = base + lane + 1;
+    r0 = r0 < row_end ? r0 : row_end;
+    r1 = r1 < row_end ? r1 : row_end;
+    u.o0 = off[r0];
+    u.o1 = off[r1];
+}
+
+// row bounds of (step t, this lane's group), limited to the entries the kernel may touch
+template <int LANES>
+__device__ __forceinline__ void row_bounds(uint32_t o0, uint32_t o1, int t, uint32_t lane, uint32_t nnz_lim,
+                                           uint32_t &s, uint32_t &e) {
+    constexpr int RPS = kWave / LANES;
+    const int src = t * RPS + (int)(lane / LANES);
+    s = (uint32_t)__shfl((int)o0, src, kWave);
+    e = (uint32_t)__shfl((int)o1, src, kWave);
+    s = s < nnz_lim ? s : nnz_lim;
+    e = e < nnz_lim ? e : nnz_lim;
+}
+
+template <typename T, int LANES, int SB>
+__device__ __forceinline__ void issue_unit(Unit<T, SB> &u, const uint32_t *__restrict__ col, const T *__restrict__ val,
+                                           uint32_t nnz_lim, uint64_t last_chunk, uint32_t lane) {
+    const uint32_t j = lane % LANES;
+#pragma unroll
+    for (int t = 0; t < SB; ++t) {
+        uint32_t s, e;
+        row_bounds<LANES>(u.o0, u.o1, t, lane, nnz_lim, s, e);
+        uint64_t k = (uint64_t)(s & ~3u) + 4u * j;
+        k = k < last_chunk ? k : last_chunk;  // lanes without work re-read a valid chunk (masked later)
+        load_chunk_nb<T>(col, val, k, u.c[t], u.v[t]);
+    }
+}
+
+template <typename T, int LANES, int SB, bool RING>
+__device__ __forceinline__ void consume_unit(const Unit<T, SB> &u, uint64_t base, uint64_t row_end,
+                                             const uint32_t *__restrict__ col, const T *__restrict__ val,
+                                             const T *__restrict__ x, const T *ring, T *__restrict__ y,
+                                             uint32_t nnz_lim, uint32_t lane) {
+    constexpr int RPS = kWave / LANES;
+    constexpr uint32_t MASK = kRing2Bytes / sizeof(T) - 1;
+    const uint32_t j = lane % LANES;
+    T out = T(0);
+#pragma unroll
+    for (int t = 0; t < SB; ++t) {
+        uint32_t s, e;
+        row_bounds<LANES>(u.o0, u.o1, t, lane, nnz_lim, s, e);
+        const uint32_t sa = s & ~3u;      // chunk grid is anchored at element 0
+        const uint32_t lo = s - sa;       // 0..3: entries of the first chunk that belong to the previous row
+        const uint32_t len = e - sa;      // row end relative to the aligned start
+        T sum = T(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t rel = 4u * j + q;
+            const bool in = rel >= lo && rel < len;
+            T xv;
+            if constexpr (RING) xv = ring[u.c[t][q] & MASK];
+            else xv = x[in ? u.c[t][q] : 0u];
+            const T f = r2_fma(u.v[t][q], xv, sum);
+            sum = in ? f : sum;
+        }
+        // rows longer than one pass of the lane group (rare; not pipelined)
+        for (uint32_t rel = 4u * j + 4u * LANES; rel < len; rel += 4u * LANES) {
+            uint32_t cc[4];
+            T vv[4];
+            load_chunk_nb<T>(col, val, (uint64_t)sa + rel, cc, vv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = rel + q < len;
+                T xv;
+                if constexpr (RING) xv = ring[cc[q] & MASK];
+                else xv = x[in ? cc[q] : 0u];
+                const T f = r2_fma(vv[q], xv, sum);
+                sum = in ? f : sum;
+            }
+        }
+#pragma unroll
+        for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);
+        // transpose: lane L keeps the sum of the unit's row L (held by every lane of group L % RPS in step L / RPS)
+        const T got = __shfl(sum, (int)((lane % RPS) * LANES), kWave);
+        out = ((int)(lane / RPS) == t) ? got : out;
+    }
+    const uint64_t row = base + lane;
+    if (lane < (uint32_t)(SB * RPS) && row < row_end) y[row] = out;
+}
+
+template <typename T, int LANES, bool RING>
+__device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
+                                           const T *__restrict__ val, const T *__restrict__ x, const T *ring,
+                                           T *__restrict__ y, uint64_t rb, uint64_t re, uint32_t nnz_lim,
+                                           uint64_t last_chunk, uint32_t wave, uint32_t lane) {
+    constexpr int STEPS = LANES;
+    constexpr int SB = STEPS < kRing2SB ? STEPS : kRing2SB;
+    constexpr int RU = SB * (kWave / LANES);                 // rows per unit
+    constexpr uint64_t STRIDE = (uint64_t)kRing2Waves * RU;  // rows between two units of a wave
+    uint64_t base = rb + (uint64_t)wave * RU;
+    if (base >= re) return;
+    Unit<T, SB> A, B, N;  // N: only its offsets are used (the unit after next)
+    load_offsets(A, off, base, re, lane);
+    load_offsets(B, off, base + STRIDE, re, lane);
+    issue_unit<T, LANES, SB>(A, col, val, nnz_lim, last_chunk, lane);
+    for (;;) {
+        if (base + STRIDE >= re) {
+            consume_unit<T, LANES, SB, RING>(A, base, re, col, val, x, ring, y, nnz_lim, lane);
+            break;
+        }
+        // program order = age order: offsets(+2) older than chunks(+1); both stay in flight under consume
+        load_offsets(N, off, base + 2 * STRIDE, re, lane);
+        issue_unit<T, LANES, SB>(B, col, val, nnz_lim, last_chunk, lane);
+        consume_unit<T, LANES, SB, RING>(A, base, re, col, val, x, ring, y, nnz_lim, lane);
+        A.o0 = N.o0; A.o1 = N.o1;
+        base += STRIDE;
+        if (base + STRIDE >= re) {
+            consume_unit<T, LANES, SB, RING>(B, base, re, col, val, x, ring, y, nnz_lim, lane);
+            break;
+        }
+        load_offsets(N, off, base + 2 * STRIDE, re, lane);
+        issue_unit<T, LANES, SB>(A, col, val, nnz_lim, last_chunk, lane);
+        consume_unit<T, LANES, SB, RING>(B, base, re, col, val, x, ring, y, nnz_lim, lane);
+        B.o0 = N.o0; B.o1 = N.o1;
+        base += STRIDE;
+    }
+}
+
+template <typename T, int LANES>
+__global__ void __launch_bounds__(kRing2Threads, 4)  // 4 waves per SIMD = two 512-thread blocks per CU
+k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
+             const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
+             const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases) {
+    __shared__ T ring[kRing2Bytes / sizeof(T)];
+    constexpr uint32_t MASK = kRing2Bytes / sizeof(T) - 1;
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);  // XCD-aware: neighbours share an L2
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t p0 = phase_ptr[lb], p1 = phase_ptr[lb + 1];
+    for (uint32_t p = p0; p < p1; ++p) {
+        const RingPhase ph = phases[p];
+        if (ph.load_hi > ph.load_lo) {
+            __syncthreads();  // the previous phase's gathers are done before its slots are overwritten
+            for (uint64_t cidx = (uint64_t)ph.load_lo + threadIdx.x; cidx < ph.load_hi; cidx += kRing2Threads)
+                ring[cidx & MASK] = x[cidx];
+            __syncthreads();
+        }
+        if (ph.use_ring)
+            phase_rows<T, LANES, true>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+        else
+            phase_rows<T, LANES, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+    }
+}
+
+// the <= 3 entries of an unpadded array's last partial chunk, appended to their rows in storage order
+template <typename T>
+__global__ void k_ring2_tail(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
+                             const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows,
+                             uint64_t k_begin, uint64_t nnz) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t r = n_rows - 1;
+    while (r > 0 && (uint64_t)off[r] > k_begin) --r;  // row holding entry k_begin
+    for (uint64_t k = k_begin; k < nnz; ++k) {
+        while ((uint64_t)off[r + 1] <= k) ++r;
+        y[r] = r2_fma(val[k], x[col[k]], y[r]);
+    }
+}
+
+template <typename T>
+static int launch_ring2_t(int lanes, const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y,
+                          size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
+                          const RingPhase *phases, hipStream_t s) {
+    // entries the streaming kernel may touch: everything when the arrays are padded to a multiple of 4,
+    // else only whole chunks (the rest goes to k_ring2_tail)
+    const uint64_t nnz_lim = padded ? nnz : (nnz & ~uint64_t(3));
+    if (nnz_lim == 0) {
+        SMH_HIP(hipMemsetAsync(y, 0, n_rows * sizeof(T), s));
+    } else {
+        const uint64_t last_chunk = (nnz_lim - 1) & ~uint64_t(3);
+        dim3 grid(n_blocks), block(kRing2Threads);
+        switch (lanes) {
+            case 1: hipLaunchKernelGGL((k_spmv_ring2<T, 1>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
+            case 2: hipLaunchKernelGGL((k_spmv_ring2<T, 2>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
+            case 4: hipLaunchKernelGGL((k_spmv_ring2<T, 4>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
+            case 8: hipLaunchKernelGGL((k_spmv_ring2<T, 8>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
+            default: return fail(SMH_ERR_INVALID, "ring kernel: lanes per row must be 1, 2, 4 or 8 (got %d)", lanes);
+        }
+        SMH_HIP(hipGetLastError());
+    }
+    if (nnz_lim != nnz) {
+        hipLaunchKernelGGL(k_ring2_tail<T>, dim3(1), dim3(64), 0, s, off, col, val, x, y, (uint64_t)n_rows, nnz_lim, (uint64_t)nnz);
+        SMH_HIP(hipGetLastError());
+    }
+    return SMH_OK;
+}
+
+int launch_spmv_ring2(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
+                      void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
+                      const RingPhase *phases, hipStream_t s) {
+    if (n_rows == 0) return SMH_OK;
+    if (dtype == SMH_F64)
+        return launch_ring2_t<double>(lanes, off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz,
+                                      padded, n_blocks, phase_ptr, phases, s);
+    return launch_ring2_t<float>(lanes, off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded,
+                                 n_blocks, phase_ptr, phases, s);
+}
+
+}  // namespace smh

@@ -59,7 +59,7 @@ def test_ring_plan_and_parity_generated(gpu, dtype, pattern, n, k):
         assert frac == 0.0 and not active  # span of a tile exceeds the ring: global gathers
     for lanes in (1, 2, 4, 8):
         m.set_vector_lanes(lanes)
-        for ring in (1, 0):
+        for ring in (1, 2, 0):
             m.set_ring(ring)
             assert_spmv_close(m.mvp(x, variant="vector"), off, col, val, x, "lanes%d ring%d" % (lanes, ring))
 

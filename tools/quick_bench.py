@@ -71,7 +71,7 @@ def main():
             nb, len(ph), frac, act), flush=True)
         for lanes in [int(v) for v in args.lanes.split(",")]:
             m.set_vector_lanes(lanes)
-            for ring in (0, 1):
+            for ring in (0, 2, 1):
                 if ring and lanes > 8:
                     continue
                 m.set_ring(ring)
