@@ -1,0 +1,174 @@
+// sparsemat.hpp -- C++ host-side mirror of the reference crate's interface for the hot path, header-only
+// over the C ABI of libsparsemat_hip.so (include/sparsemat_hip.h).
+//
+// The reference is a Rust crate; this image has no Rust toolchain, so the tested host side above the C
+// ABI is this C++ mirror (same names, argument meaning and failure behaviour as the reference) plus the
+// Python mirror used by the tests/bench (sparsemat_amd/).  The Rust shim a maintainer would add is in
+// rust/ and INTEGRATION.md.
+//
+//   sparsemat::DenseVec<T>            <- densevec.rs:5-140, vector.rs:5-64
+//   sparsemat::SparseMatCRS<T>        <- sparsemat_crs.rs (Index = u32), SparseMatrix::mvp sparsematrix.rs:146-158
+//   sparsemat::ConjugateGradient      <- linearsolver.rs:6-61
+//   sparsemat::Panic                  <- the reference's panic!() texts (linearsolver.rs:31,35; densevec.rs:53,62)
+//
+// T is float or double.  Everything computes on the device; there is no CPU fallback.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "sparsemat_hip.h"
+
+namespace sparsemat {
+
+struct Panic : std::runtime_error {
+    int status;
+    Panic(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
+};
+
+namespace detail {
+inline void check(int status) {
+    if (status != SMH_OK) {
+        std::string msg = smh_last_error();
+        if (msg.empty()) msg = smh_status_string(status);
+        throw Panic(status, msg);
+    }
+}
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr smh_dtype value = SMH_F32; };
+template <> struct dtype_of<double> { static constexpr smh_dtype value = SMH_F64; };
+}  // namespace detail
+
+template <typename T>
+class DenseVec {
+  public:
+    using Value = T;
+    DenseVec() { detail::check(smh_vec_create(detail::dtype_of<T>::value, 0, &h_)); }
+    explicit DenseVec(size_t n) { detail::check(smh_vec_create(detail::dtype_of<T>::value, n, &h_)); }
+    // Vector::from_vec (densevec.rs:30-34)
+    static DenseVec from_vec(const std::vector<T> &v) {
+        DenseVec r(nullptr);
+        detail::check(smh_vec_from_host(detail::dtype_of<T>::value, v.size(), v.data(), &r.h_));
+        return r;
+    }
+    DenseVec(const DenseVec &o) : DenseVec(o.dim()) { detail::check(smh_vec_copy(h_, o.h_)); }  // Clone
+    DenseVec(DenseVec &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    DenseVec &operator=(DenseVec o) { std::swap(h_, o.h_); return *this; }
+    ~DenseVec() { smh_vec_destroy(h_); }
+
+    size_t dim() const { return smh_vec_dim(h_); }  // densevec.rs:36-38
+    std::vector<T> to_vec() const {                 // iter().collect()
+        std::vector<T> v(dim());
+        detail::check(smh_vec_download(h_, v.data()));
+        return v;
+    }
+    T get(size_t i) const {                         // densevec.rs:40-42 (bounds checked)
+        if (i >= dim()) throw Panic(SMH_ERR_INDEX_RANGE, "index out of bounds");
+        return to_vec()[i];
+    }
+    void add(const DenseVec &rhs) { detail::check(smh_vec_add(h_, rhs.h_)); }   // :51-58
+    void sub(const DenseVec &rhs) { detail::check(smh_vec_sub(h_, rhs.h_)); }   // :60-67
+    void scale(T a) { detail::check(smh_vec_scale(h_, (double)a)); }            // :69-73
+    T inner_prod(const DenseVec &rhs) const {                                   // vector.rs:50-53
+        double out = 0;
+        detail::check(smh_vec_dot(h_, rhs.h_, &out));
+        return (T)out;
+    }
+    T norm_squared() const {                                                    // vector.rs:56-58
+        double out = 0;
+        detail::check(smh_vec_norm_squared(h_, &out));
+        return (T)out;
+    }
+    double norm() const { return std::sqrt((double)norm_squared()); }           // vector.rs:61-63
+    // operator sugar (densevec.rs:76-140)
+    DenseVec &operator+=(const DenseVec &r) { add(r); return *this; }
+    DenseVec &operator-=(const DenseVec &r) { sub(r); return *this; }
+    DenseVec &operator*=(T a) { scale(a); return *this; }
+    friend DenseVec operator+(DenseVec l, const DenseVec &r) { l += r; return l; }
+    friend DenseVec operator-(DenseVec l, const DenseVec &r) { l -= r; return l; }
+    friend DenseVec operator*(DenseVec l, T a) { l *= a; return l; }
+    friend T operator*(const DenseVec &l, const DenseVec &r) { return l.inner_prod(r); }
+
+    smh_vec *handle() const { return h_; }
+
+  private:
+    explicit DenseVec(std::nullptr_t) : h_(nullptr) {}
+    smh_vec *h_ = nullptr;
+};
+
+template <typename T>
+class SparseMatCRS {
+  public:
+    using Value = T;
+    using Index = uint32_t;
+    // The reference has no public raw-array constructor (from_sparsemat_index is pub(crate),
+    // sparsemat_crs.rs:24-50): this is the documented addition.  Arrays are borrowed for the call.
+    static SparseMatCRS from_raw_parts(size_t n_rows, size_t n_cols, const std::vector<uint32_t> &offset_rows,
+                                       const std::vector<uint32_t> &columns, const std::vector<T> &values) {
+        if (n_rows && offset_rows.size() != n_rows + 1) throw Panic(SMH_ERR_INVALID, "offset_rows must have n_rows+1 entries");
+        if (columns.size() != values.size()) throw Panic(SMH_ERR_INVALID, "columns and values differ in length");
+        SparseMatCRS m;
+        detail::check(smh_crs_create(detail::dtype_of<T>::value, n_rows, n_cols, values.size(), offset_rows.data(),
+                                     columns.data(), values.data(), 1, &m.h_));
+        return m;
+    }
+    SparseMatCRS(SparseMatCRS &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    SparseMatCRS &operator=(SparseMatCRS &&o) noexcept { std::swap(h_, o.h_); return *this; }
+    SparseMatCRS(const SparseMatCRS &) = delete;
+    ~SparseMatCRS() { smh_crs_destroy(h_); }
+
+    size_t n_rows() const { return smh_crs_n_rows(h_); }              // sparsemat_crs.rs:124-126
+    size_t n_cols() const { return smh_crs_n_cols(h_); }              // :128-130
+    size_t n_non_zero_entries() const { return smh_crs_nnz(h_); }     // :132-134
+    bool empty() const { return n_rows() == 0; }                      // sparsematrix.rs:119-121
+    void scale(T a) { detail::check(smh_crs_scale(h_, (double)a)); }  // sparsemat_crs.rs:153-157
+
+    // SparseMatrix::mvp (sparsematrix.rs:146-158): returns a NEW vector with dim == n_rows
+    DenseVec<T> mvp(const DenseVec<T> &rhs, int variant = SMH_SPMV_AUTO) const {
+        DenseVec<T> ret(n_rows());
+        detail::check(smh_crs_spmv_vec(h_, rhs.handle(), ret.handle(), variant));
+        return ret;
+    }
+    std::vector<T> mvp(const std::vector<T> &rhs, int variant = SMH_SPMV_AUTO) const {
+        std::vector<T> y(n_rows());
+        detail::check(smh_crs_spmv(h_, rhs.data(), rhs.size(), y.data(), variant));
+        return y;
+    }
+    // `A * v` (sparsemat_ops! Mul<DenseVec>, sparsematrix.rs:435-443)
+    friend DenseVec<T> operator*(const SparseMatCRS &a, const DenseVec<T> &v) { return a.mvp(v); }
+
+    smh_crs *handle() const { return h_; }
+
+  private:
+    SparseMatCRS() = default;
+    smh_crs *h_ = nullptr;
+};
+
+// linearsolver.rs:12-61.  The reference keeps tol / iter_max private with only Default (1e-12, 10000);
+// the two-argument constructor is the documented addition.
+class ConjugateGradient {
+  public:
+    ConjugateGradient() = default;
+    ConjugateGradient(double tol, size_t iter_max) : tol_(tol), iter_max_(iter_max) {}
+    // LinearSolver::solve(&self, mat, b, x): x is updated in place; panics become sparsemat::Panic with
+    // the reference's text ("Matrix is not symmetric", "Matrix and vector size mismatch").
+    template <typename T>
+    void solve(const SparseMatCRS<T> &mat, const DenseVec<T> &b, DenseVec<T> &x) {
+        detail::check(smh_cg_solve_vec(mat.handle(), b.handle(), x.handle(), tol_, iter_max_, SMH_SPMV_AUTO, 0,
+                                       &iterations_, &r_norm_squared_));
+    }
+    size_t iterations() const { return iterations_; }
+    double r_norm_squared() const { return r_norm_squared_; }
+
+  private:
+    double tol_ = 1e-12;
+    size_t iter_max_ = 10000;
+    size_t iterations_ = 0;
+    double r_norm_squared_ = 0.0;
+};
+
+}  // namespace sparsemat

@@ -1,0 +1,73 @@
+//! Drop-in glue between lostinc0de/sparsemat and libsparsemat_hip.so (MI355X / gfx950).
+//!
+//! NOT COMPILED HERE (no Rust toolchain in the build image).  It shows exactly what a maintainer adds
+//! to the crate: a device handle cached next to the CRS arrays, an override of the trait default
+//! `SparseMatrix::mvp` (src/sparsematrix.rs:146-158) inside `impl SparseMatrix for SparseMatCRS`
+//! (src/sparsemat_crs.rs:95-158), and a device-resident `ConjugateGradient::solve`
+//! (src/linearsolver.rs:27-61).  Non-zero statuses are re-raised as the reference's panics.
+pub mod ffi;
+
+use std::ffi::CStr;
+use std::os::raw::{c_int, c_void};
+
+/// Value types the HIP path accelerates; everything else stays on the reference's CPU loop.
+pub trait HipValue: Copy {
+    const DTYPE: c_int;
+}
+impl HipValue for f32 { const DTYPE: c_int = ffi::SMH_F32; }
+impl HipValue for f64 { const DTYPE: c_int = ffi::SMH_F64; }
+
+fn check(status: c_int) {
+    if status != ffi::SMH_OK {
+        // same text as the reference's panic!() ("Matrix is not symmetric", "Dimension mismatch", ...)
+        let msg = unsafe { CStr::from_ptr(ffi::smh_last_error()) }.to_string_lossy().into_owned();
+        panic!("{}", msg);
+    }
+}
+
+/// Device-resident copy of a `SparseMatCRS<T, u32>`; the Rust side keeps owning the Vecs.
+pub struct DeviceCrs {
+    handle: *mut ffi::smh_crs,
+    n_rows: usize,
+}
+
+impl DeviceCrs {
+    /// `offset_rows`, `columns`, `values` are the private fields of SparseMatCRS
+    /// (src/sparsemat_crs.rs:12-14), borrowed for the duration of the call.
+    pub fn new<T: HipValue>(n_rows: usize, n_cols: usize, offset_rows: &[u32], columns: &[u32], values: &[T]) -> Self {
+        assert_eq!(offset_rows.len(), n_rows + 1);
+        assert_eq!(columns.len(), values.len());
+        let mut handle = std::ptr::null_mut();
+        check(unsafe {
+            ffi::smh_crs_create(T::DTYPE, n_rows, n_cols, values.len(), offset_rows.as_ptr(), columns.as_ptr(),
+                                values.as_ptr() as *const c_void, 1, &mut handle)
+        });
+        DeviceCrs { handle, n_rows }
+    }
+
+    /// `SparseMatrix::mvp` for `V = DenseVec<T>`: returns a new Vec with `n_rows` entries.
+    pub fn mvp<T: HipValue + Default>(&self, x: &[T]) -> Vec<T> {
+        let mut y = vec![T::default(); self.n_rows];
+        check(unsafe {
+            ffi::smh_crs_spmv(self.handle, x.as_ptr() as *const c_void, x.len(), y.as_mut_ptr() as *mut c_void,
+                              ffi::SMH_SPMV_AUTO)
+        });
+        y
+    }
+
+    /// `ConjugateGradient::solve`: `x` is updated in place; returns (iterations, r.r).
+    pub fn cg_solve<T: HipValue>(&self, b: &[T], x: &mut [T], tol: f64, iter_max: usize) -> (usize, f64) {
+        let (mut iters, mut rr) = (0usize, 0f64);
+        check(unsafe {
+            ffi::smh_cg_solve(self.handle, b.as_ptr() as *const c_void, b.len(), x.as_mut_ptr() as *mut c_void,
+                              x.len(), tol, iter_max, ffi::SMH_SPMV_AUTO, &mut iters, &mut rr)
+        });
+        (iters, rr)
+    }
+}
+
+impl Drop for DeviceCrs {
+    fn drop(&mut self) {
+        unsafe { ffi::smh_crs_destroy(self.handle) };
+    }
+}

@@ -1,0 +1,78 @@
+// Replays the reference's own SpMV / CG unit tests (lostinc0de/sparsemat src/lib.rs:36-52, 114-154,
+// 54-82) through the C++ mirror of its interface (include/sparsemat.hpp) on the GPU.
+// Built and run by tests/test_cpp_surface_gpu.py.
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "sparsemat.hpp"
+
+using namespace sparsemat;
+
+static int failures = 0;
+#define CHECK(cond)                                                         \
+    do {                                                                    \
+        if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+int main() {
+    // check_sparsemat_crs (src/lib.rs:114-154): CRS as add_to leaves it (row 3 stored as (3,3),(3,2))
+    {
+        auto a = SparseMatCRS<float>::from_raw_parts(4, 4, {0, 1, 2, 3, 5}, {1, 2, 2, 3, 2}, {4.2f, 4.12f, 2.12f, 5.12f, 1.12f});
+        auto v = DenseVec<float>::from_vec({2.0f, 4.8f, 1.2f, 3.4f});
+        auto y = a * v;                      // sp_crs.clone() * v
+        CHECK(y.dim() == 4);
+        CHECK(y.get(0) == 20.16f);           // assert_eq!(mvp.get(0), 20.16)
+        CHECK(a.n_non_zero_entries() == 5 && a.n_rows() == 4 && a.n_cols() == 4);
+        auto ys = a.mvp(v, SMH_SPMV_SEQ).to_vec();
+        CHECK(ys[0] == 20.16f && ys[3] == 3.4f * 5.12f + 1.2f * 1.12f);
+    }
+    // check_sparsemat_indexlist -> to_crs (src/lib.rs:54-82): row 0 stored as (0,1),(0,2),(0,0)
+    {
+        auto a = SparseMatCRS<float>::from_raw_parts(3, 3, {0, 3, 5, 6}, {1, 2, 0, 2, 1, 2},
+                                                     {4.2f, 0.12f, 7.12f, 4.12f, 2.24f, 2.12f});
+        auto y = a.mvp(std::vector<float>{2.0f, 4.8f, 1.2f}, SMH_SPMV_SEQ);
+        CHECK(y[0] == 34.544f);              // assert_eq!(mvp.get(0), 34.544)
+        auto y2 = a.mvp(std::vector<float>{2.0f, 4.8f, 1.2f});
+        CHECK(std::fabs(y2[0] - 34.544f) <= 1e-5f * 34.544f);
+    }
+    // check_cg (src/lib.rs:36-52)
+    {
+        auto a = SparseMatCRS<double>::from_raw_parts(2, 2, {0, 2, 4}, {0, 1, 0, 1}, {4.0, 1.0, 1.0, 3.0});
+        auto b = DenseVec<double>::from_vec({1.0, 2.0});
+        auto x = DenseVec<double>::from_vec({2.0, 1.0});
+        ConjugateGradient cg;                // ::default()
+        cg.solve(a, b, x);
+        CHECK(std::floor(x.get(0) * 10000.0) / 10000.0 == 0.0909);
+        CHECK(cg.iterations() == 2);
+    }
+    // DenseVec operators (densevec.rs:76-140)
+    {
+        auto p = DenseVec<float>::from_vec({1.0f, 2.0f, 3.0f});
+        auto q = DenseVec<float>::from_vec({0.5f, 0.25f, 4.0f});
+        CHECK((p + q).to_vec() == (std::vector<float>{1.5f, 2.25f, 7.0f}));
+        CHECK((p - q).to_vec() == (std::vector<float>{0.5f, 1.75f, -1.0f}));
+        CHECK((p * 2.0f).to_vec() == (std::vector<float>{2.0f, 4.0f, 6.0f}));
+        CHECK(p * q == 13.0f && p.norm_squared() == 14.0f && p.norm() == std::sqrt(14.0));
+        CHECK(p.to_vec() == (std::vector<float>{1.0f, 2.0f, 3.0f}));  // operands untouched
+    }
+    // panics of the reference
+    {
+        auto a = SparseMatCRS<double>::from_raw_parts(2, 3, {0, 1, 2}, {0, 2}, {1.0, 2.0});
+        auto b = DenseVec<double>::from_vec({1.0, 2.0});
+        auto x = DenseVec<double>::from_vec({0.0, 0.0});
+        try { ConjugateGradient().solve(a, b, x); CHECK(false); }
+        catch (const Panic &e) { CHECK(std::string(e.what()) == "Matrix is not symmetric"); }   // linearsolver.rs:31
+        auto sq = SparseMatCRS<double>::from_raw_parts(2, 2, {0, 1, 2}, {0, 1}, {1.0, 2.0});
+        auto b3 = DenseVec<double>::from_vec({1.0, 2.0, 3.0});
+        try { ConjugateGradient().solve(sq, b3, x); CHECK(false); }
+        catch (const Panic &e) { CHECK(std::string(e.what()) == "Matrix and vector size mismatch"); }  // :35
+        try { x.add(b3); CHECK(false); }
+        catch (const Panic &e) { CHECK(std::string(e.what()) == "Dimension mismatch"); }          // densevec.rs:53
+        try { a.mvp(std::vector<double>{1.0, 2.0}); CHECK(false); }                              // densevec.rs:41
+        catch (const Panic &e) { CHECK(e.status == SMH_ERR_INDEX_RANGE); }
+    }
+    std::printf(failures ? "FAILED (%d)\n" : "ok (%d failures)\n", failures);
+    return failures ? 1 : 0;
+}
