@@ -137,7 +137,7 @@ def main():
         args.gpus = world
 
     traffic, traffic_note = None, "skipped"
-    if world == 1 and not args.child and not args.no_traffic:
+    if world == 1 and "RANK" not in os.environ and not args.child and not args.no_traffic:
         traffic, traffic_note = pmc_traffic(args)  # before this process initialises the GPU
 
     import numpy as np
@@ -149,7 +149,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     sm._lib.check(sm.lib().smh_set_device(local_rank))
-    if world > 1:
+    # SMH_BENCH_FORCE_DIST=1: exercise the RCCL path (process group + in-place all-gather) even with one rank
+    force_dist = os.environ.get("SMH_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -174,7 +177,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     # HIP events around every SpMV kernel launch (same stream as the launch)
@@ -182,22 +185,18 @@ def main():
     y_local = y[begin:end]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if world == 1:
-            ev[i][0].record(stream)
-            par.mvp_local(x, y_local)
-            ev[i][1].record(stream)
-        else:
-            ev[i][0].record(stream)
-            par.mvp_local(x, y_local)
-            ev[i][1].record(stream)
+        ev[i][0].record(stream)
+        par.mvp_local(x, y_local)
+        ev[i][1].record(stream)
+        if use_dist:
             dist.all_gather_into_tensor(y, y_local)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -234,7 +233,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
