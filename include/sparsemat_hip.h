@@ -55,8 +55,10 @@ typedef enum {
     SMH_SPMV_AUTO = 0,   /* pick from the row-length statistics taken at create time        */
     SMH_SPMV_VECTOR = 1, /* K1: (sub-)wavefront per row, 16-B coalesced chunks, shfl reduce  */
     SMH_SPMV_MERGE = 2,  /* K2: merge-path tiles, LDS-staged products, deterministic fix-up  */
-    SMH_SPMV_SEQ = 3     /* one lane per row, storage order, mul then add: bit-exact vs the */
+    SMH_SPMV_SEQ = 3,    /* one lane per row, storage order, mul then add: bit-exact vs the */
                          /* reference loop sparsematrix.rs:146-158 (checker, not fast)      */
+    SMH_SPMV_STREAM = 4  /* K1s: short rows; dense entry stream, rounded products in LDS,   */
+                         /* one thread folds a row in storage order: fast AND bit-exact     */
 } smh_spmv_variant;
 
 typedef struct smh_crs smh_crs; /* device-resident SparseMatCRS<T,u32>  (sparsemat_crs.rs:9-17) */
@@ -100,8 +102,12 @@ int smh_crs_scale(smh_crs *m, double a);
 int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out);
 /* override the VECTOR kernel's lanes-per-row (1,2,4,...,64; 0 = automatic) */
 int smh_crs_set_vector_lanes(smh_crs *m, int lanes);
-/* K1r, the VECTOR kernel with an LDS-resident sliding window of x: mode -1 =
- * automatic (used when >= half of the rows fit the ring), 0 = never, 1 = whenever lanes <= 8 */
+/* 16-B chunks per lane and pass of the pipelined VECTOR body (1..3; 0 = automatic): a lane group
+ * covers 4*lanes*chunks entry slots of its row per pass */
+int smh_crs_set_vector_chunks(smh_crs *m, int chunks);
+/* K1r, the pipelined VECTOR kernel with an LDS-resident sliding window of x: mode -1 =
+ * automatic (whenever lanes <= 8; rows whose column span exceeds the ring gather from L2),
+ * 0 = plain K1, 1 = same as -1, 2 = the first, unpipelined K1r body */
 int smh_crs_set_ring(smh_crs *m, int mode);
 /* the K1r phase plan (integer structure, invariants checked in tests): phase_ptr_out needs
  * n_blocks+1 entries, phases_out 5 u32 per phase {row_begin,row_end,load_lo,load_hi,use_ring};

@@ -7,14 +7,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsparsemat_hip.so")
+# SPARSEMAT_HIP_LIB: load an A/B build of the same ABI instead (development aid)
+LIB_PATH = os.environ.get("SPARSEMAT_HIP_LIB") or os.path.join(_HERE, "libsparsemat_hip.so")
 
 SMH_OK = 0
 SMH_ERR_DIM_MISMATCH, SMH_ERR_NOT_SQUARE, SMH_ERR_INDEX_RANGE, SMH_ERR_INVALID = 1, 2, 3, 4
 SMH_ERR_HIP, SMH_ERR_OOM, SMH_ERR_NO_DEVICE, SMH_ERR_CAPACITY = 5, 6, 7, 8
 SMH_F32, SMH_F64 = 0, 1
-SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ = 0, 1, 2, 3
-VARIANTS = {"auto": SPMV_AUTO, "vector": SPMV_VECTOR, "merge": SPMV_MERGE, "seq": SPMV_SEQ}
+SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ, SPMV_STREAM = 0, 1, 2, 3, 4
+VARIANTS = {"auto": SPMV_AUTO, "vector": SPMV_VECTOR, "merge": SPMV_MERGE, "seq": SPMV_SEQ, "stream": SPMV_STREAM}
 
 _sz = C.c_size_t
 _vp = C.c_void_p
@@ -42,6 +43,7 @@ SIGNATURES = {
     "smh_crs_scale": (_int, [_vp, C.c_double]),
     "smh_crs_resolved_variant": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "smh_crs_set_vector_lanes": (_int, [_vp, _int]),
+    "smh_crs_set_vector_chunks": (_int, [_vp, _int]),
     "smh_crs_set_ring": (_int, [_vp, _int]),
     "smh_crs_ring_plan": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(C.c_double), C.POINTER(_int), _vp, _vp]),
     "smh_crs_spmv": (_int, [_vp, _vp, _sz, _vp, _int]),

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsparsemat_hip.so")
-SOURCES = ["capi.hip", "spmv_vector.hip", "spmv_ring.hip", "spmv_ring2.hip","spmv_merge.hip", "blas1.hip", "cg.hip", "synth.hip"]
+SOURCES = ["capi.hip", "spmv_vector.hip", "spmv_ring.hip", "spmv_ring2.hip", "spmv_stream.hip","spmv_merge.hip", "blas1.hip", "cg.hip", "synth.hip"]
 HEADERS = [os.path.join(CSRC, "internal.hpp"), os.path.join(HERE, "..", "include", "sparsemat_hip.h")]
 # -ffp-contract=off: the element-wise / SEQ kernels must round a*b and (a*b)+c separately, like the
 # reference; where an FMA is wanted (K1's accumulation) the kernels call __builtin_fma explicitly.
@@ -34,18 +34,21 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
-    if not force and not stale():
+def build(force=False, verbose=False, extra_flags=(), out=None, objsuffix=""):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
+    extra_flags/out/objsuffix build an A/B variant next to the product (development aid)."""
+    global LIB
+    lib = out or LIB
+    if out is None and not force and not stale():
         return LIB
-    objdir = os.path.join(HERE, "csrc", "_obj")
+    objdir = os.path.join(HERE, "csrc", "_obj" + objsuffix)
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -58,9 +61,9 @@ def build(force=False, verbose=False):
             print(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join("%s:\n%s" % f for f in failed))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -87,15 +87,32 @@ static int ensure_cap(void **buf, size_t *cap, size_t bytes) {
 static int auto_lanes(const smh_crs *m) {
     if (m->forced_lanes) return m->forced_lanes;
     const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
-    // one pass of a lane group covers 4*lanes entries: size the group to the mean row
+    // one pass of a lane group covers 4*lanes entry slots: size the group to the mean row; short rows
+    // start anywhere inside their first 16-B chunk, so they get 3 slots of slack (measured on the 7-point
+    // Laplacian: 4 lanes 2.87 ms, 2 lanes 3.68 ms, 1 lane x 3 chunks 3.11 ms)
+    const double need = mean < 16.0 ? mean + 3.0 : mean;
     int lanes = 1;
-    while (lanes < 64 && 4.0 * lanes < mean) lanes <<= 1;
+    while (lanes < 64 && 4.0 * lanes < need) lanes <<= 1;
     return lanes;
+}
+
+// 16-B chunks each lane loads per pass (pipelined K1r body only): 4*lanes*chunks entry slots per row and pass
+static int auto_chunks(const smh_crs *m) {
+    const int lanes = auto_lanes(m);
+    if (m->forced_chunks) {
+        if (lanes == 1) return m->forced_chunks;
+        if (lanes == 2) return m->forced_chunks > 2 ? 2 : m->forced_chunks;
+        return 1;
+    }
+    return 1;
 }
 
 static int resolve_variant(const smh_crs *m, int variant) {
     if (variant != SMH_SPMV_AUTO) return variant;
     const int lanes = auto_lanes(m);
+    // short rows (stencils, FEM): the dense CSR-stream kernel, as long as every 256-row tile fits its LDS stage
+    const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
+    if (mean <= 12.0 && m->max_row_len <= 64 && m->max_tile_entries <= (uint32_t)kStreamCap) return SMH_SPMV_STREAM;
     // skew test: the longest row needs >= 8 passes of a group sized for the mean row
     if ((uint64_t)m->max_row_len >= 8ull * 4ull * (uint64_t)lanes && m->max_row_len > 64) return SMH_SPMV_MERGE;
     return SMH_SPMV_VECTOR;
@@ -159,7 +176,9 @@ static int vector_uses_ring(smh_crs *m, bool *out) {
     *out = false;
     if (m->use_ring == 0 || auto_lanes(m) > 8 || m->n_rows == 0) return SMH_OK;
     SMH_TRY(ensure_ring_plan(m));
-    *out = m->use_ring >= 1 || m->ring_fraction >= 0.5;
+    // the pipelined body also wins without the ring (its global-gather phases), so it is the default
+    // whenever its lane widths apply; mode 0 keeps the plain K1 kernel selectable
+    *out = true;
     return SMH_OK;
 }
 
@@ -177,12 +196,14 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
                                         m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
             if (ring)
                 // owned arrays are padded to a multiple of 4 entries; borrowed ones may end inside a 16-B chunk
-                return launch_spmv_ring2(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz,
+                return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz,
                                          m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
             return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, s);
         }
         case SMH_SPMV_SEQ:
             return launch_spmv_seq(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, s);
+        case SMH_SPMV_STREAM:
+            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, s);
         case SMH_SPMV_MERGE:
             SMH_TRY(ensure_merge_ws(m));
             return launch_spmv_merge(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->n_tiles,
@@ -200,6 +221,15 @@ static int finish_create(smh_crs *m, int validate) {
         int rc = launch_crs_stats(m->d_off, m->d_col, m->n_rows, m->nnz, d_st, m->stream);
         if (rc == SMH_OK) {
             hipError_t e = hipMemcpyAsync(&h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, m->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+            // (reuse the first word of the scratch for the K1s tile statistic)
+            if (e == hipSuccess && !(h_st.bad & 1u)) {
+                uint32_t mt = 0;
+                rc = launch_stream_max_tile(m->d_off, m->n_rows, &d_st->max_row_len, m->stream);
+                if (rc == SMH_OK) e = hipMemcpyAsync(&mt, &d_st->max_row_len, sizeof mt, hipMemcpyDeviceToHost, m->stream);
+                if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);
+                m->max_tile_entries = mt;
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
             if (e != hipSuccess) rc = hip_fail(e, "crs stats readback", __FILE__, __LINE__);
         }
@@ -393,6 +423,13 @@ int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out)
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (variant_out) *variant_out = resolve_variant(m, SMH_SPMV_AUTO);
     if (lanes_out) *lanes_out = auto_lanes(m);
+    return SMH_OK;
+}
+
+int smh_crs_set_vector_chunks(smh_crs *m, int chunks) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (chunks < 0 || chunks > 3) return fail(SMH_ERR_INVALID, "chunks per lane must be 0 (automatic), 1, 2 or 3");
+    m->forced_chunks = chunks;
     return SMH_OK;
 }
 

@@ -38,6 +38,8 @@ constexpr int kBlock = 256;         // 4 waves: one per SIMD
 constexpr int kMergeItemsPerThread = 8;
 constexpr int kMergeTile = kBlock * kMergeItemsPerThread;  // merge items (rows + nnz) per tile
 constexpr int kReducePartials = 1024;  // blocks of a stage-1 reduction
+constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
+constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 // K1 / SEQ
@@ -51,6 +53,10 @@ int launch_merge_table(const uint32_t *off, size_t n_rows, size_t nnz, size_t n_
 int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
                       void *y, size_t n_rows, size_t nnz, size_t n_tiles, const uint32_t *tile_row,
                       const uint32_t *tile_nz, uint32_t *carry_row, void *carry_val, hipStream_t s);
+// K1s (CSR-stream for short rows)
+int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
+                       size_t n_rows, size_t nnz, bool padded, hipStream_t s);
+int launch_stream_max_tile(const uint32_t *off, size_t n_rows, uint32_t *d_out, hipStream_t s);
 // K1r (LDS x-ring): inspector, host plan, kernel
 struct RingPhase {
     uint32_t row_begin, row_end;  // rows of this phase (row_begin is a multiple of 64)
@@ -62,7 +68,7 @@ int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 int launch_spmv_ring(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
                      void *y, size_t nnz, unsigned n_blocks, const uint32_t *phase_ptr, const RingPhase *phases,
                      hipStream_t s);
-int launch_spmv_ring2(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
+int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
                       void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
                       const RingPhase *phases, hipStream_t s);
 // structure statistics / validation
@@ -95,8 +101,10 @@ struct smh_crs {
     // statistics
     uint32_t max_row_len = 0;
     uint32_t max_col = 0;
+    uint32_t max_tile_entries = 0;  // most entries in any 256-row tile (K1s eligibility)
     bool have_stats = false;
     int forced_lanes = 0;
+    int forced_chunks = 0;
     // merge-path workspace (lazy)
     size_t n_tiles = 0;
     uint32_t *d_tile_row = nullptr, *d_tile_nz = nullptr, *d_carry_row = nullptr;

@@ -92,7 +92,8 @@ void build_ring_plan(size_t n_rows, size_t elem_size, const uint32_t *cmin, cons
             const bool empty0 = cmin[t] > cmax[t];
             size_t e = t + 1;
             if (!empty0 && umax + 1 - umin > ring) {
-                // span wider than the ring: global gathers for this tile alone
+                // span wider than the ring: one global-gather phase over the run of such tiles
+                while (e < t_end && cmin[e] <= cmax[e] && (uint64_t)cmax[e] + 1 - cmin[e] > ring) ++e;
                 RingPhase p{(uint32_t)(t * kTileRows), (uint32_t)std::min<uint64_t>((uint64_t)e * kTileRows, n_rows), 0, 0, 0};
                 phases.push_back(p);
                 t = e;

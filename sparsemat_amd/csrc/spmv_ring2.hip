@@ -31,26 +31,43 @@ constexpr int kRing2Waves = kRing2Threads / kWave;
 #ifndef SMH_RING2_SB
 #define SMH_RING2_SB 2
 #endif
-constexpr int kRing2SB = SMH_RING2_SB;  // steps per unit: two units x SB x 32 B per lane live in VGPRs
+constexpr int kRing2SB = SMH_RING2_SB;
+// steps per unit: two units x SB x 32 B per lane live in VGPRs
+// Addressing A/B (same box, interleaved runs): 32-bit byte offsets (saddr form, would also need a < 2^30
+// entries-per-phase guard) gave 0.465 vs 0.465 ms on C2 and 2.89 vs 2.76 ms on the 512^3 Laplacian against
+// 64-bit offsets -- no gain, so the guard-free 64-bit form is the default.
+#ifndef SMH_RING2_SADDR
+#define SMH_RING2_SADDR 0
+#endif
+#if SMH_RING2_SADDR
+#define SMH_R2_OFF(rel, size) ((size_t)((rel) * (size)))
+#else
+#define SMH_R2_OFF(rel, size) ((size_t)(rel) * (size))
+#endif
 
-template <typename T, int SB>
+template <typename T, int NCH>
 struct Unit {
     uint32_t o0, o1;  // lane L: off[base+L], off[base+L+1] (rows clamped to the phase end)
-    uint32_t c[SB][4];
-    T v[SB][4];
+    uint32_t c[NCH][4];
+    T v[NCH][4];
 };
 
+// colp/valp are wave-uniform (SGPR) base pointers of the phase's first chunk, rel a 32-bit element offset
+// from it: hipcc emits the saddr form `global_load_dwordx4 v, v_off, s[base]`, one address VGPR per load
 template <typename T>
-__device__ __forceinline__ void load_chunk_nb(const uint32_t *__restrict__ col, const T *__restrict__ val, uint64_t k,
+__device__ __forceinline__ void load_chunk_nb(const uint32_t *__restrict__ colp, const T *__restrict__ valp, uint32_t rel,
                                               uint32_t (&c)[4], T (&v)[4]) {
-    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(col + k));
+    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(
+        reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 4u)));
     c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
     if constexpr (sizeof(T) == 4) {
-        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(val + k));
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
+            reinterpret_cast<const char *>(valp) + SMH_R2_OFF(rel, 4u)));
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
     } else {
-        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k));
-        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k + 2));
+        const char *pv = reinterpret_cast<const char *>(valp) + SMH_R2_OFF(rel, 8u);
+        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(pv));
+        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(pv) + 1);
         v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
     }
 }
@@ -58,8 +75,8 @@ __device__ __forceinline__ void load_chunk_nb(const uint32_t *__restrict__ col, 
 __device__ __forceinline__ float r2_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double r2_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-template <typename T, int SB>
-__device__ __forceinline__ void load_offsets(Unit<T, SB> &u, const uint32_t *__restrict__ off, uint64_t base,
+template <typename T, int NCH>
+__device__ __forceinline__ void load_offsets(Unit<T, NCH> &u, const uint32_t *__restrict__ off, uint64_t base,
                                              uint64_t row_end, uint32_t lane) {
     uint64_t r0 = base + lane, r1 = base + lane + 1;
     r0 = r0 < row_end ? r0 : row_end;
@@ -72,32 +89,43 @@ __device__ __forceinline__ void load_offsets(Unit<T, SB> &u, const uint32_t *__r
 template <int LANES>
 __device__ __forceinline__ void row_bounds(uint32_t o0, uint32_t o1, int t, uint32_t lane, uint32_t nnz_lim,
                                            uint32_t &s, uint32_t &e) {
-    constexpr int RPS = kWave / LANES;
-    const int src = t * RPS + (int)(lane / LANES);
-    s = (uint32_t)__shfl((int)o0, src, kWave);
-    e = (uint32_t)__shfl((int)o1, src, kWave);
+    if constexpr (LANES == 1) {  // one lane per row: the lane already holds its own row's offsets
+        s = o0;
+        e = o1;
+    } else {
+        constexpr int RPS = kWave / LANES;
+        const int src = t * RPS + (int)(lane / LANES);
+        s = (uint32_t)__shfl((int)o0, src, kWave);
+        e = (uint32_t)__shfl((int)o1, src, kWave);
+    }
     s = s < nnz_lim ? s : nnz_lim;
     e = e < nnz_lim ? e : nnz_lim;
 }
 
-template <typename T, int LANES, int SB>
-__device__ __forceinline__ void issue_unit(Unit<T, SB> &u, const uint32_t *__restrict__ col, const T *__restrict__ val,
-                                           uint32_t nnz_lim, uint64_t last_chunk, uint32_t lane) {
+// A lane group covers 4*LANES*CH entry slots of its row per pass: chunk (ch, j) = slots [4*(ch*LANES+j), +4)
+template <typename T, int LANES, int CH, int SB>
+__device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const uint32_t *__restrict__ colp,
+                                           const T *__restrict__ valp, uint32_t kb, uint32_t nnz_lim, uint32_t last_rel,
+                                           uint32_t lane) {
     const uint32_t j = lane % LANES;
 #pragma unroll
     for (int t = 0; t < SB; ++t) {
         uint32_t s, e;
         row_bounds<LANES>(u.o0, u.o1, t, lane, nnz_lim, s, e);
-        uint64_t k = (uint64_t)(s & ~3u) + 4u * j;
-        k = k < last_chunk ? k : last_chunk;  // lanes without work re-read a valid chunk (masked later)
-        load_chunk_nb<T>(col, val, k, u.c[t], u.v[t]);
+        s = s > kb ? s : kb;  // (only rows past the arrays' readable end are below kb: they are empty)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            uint32_t rel = (s & ~3u) - kb + 4u * (ch * LANES + j);
+            rel = rel < last_rel ? rel : last_rel;  // lanes without work re-read a valid chunk (masked later)
+            load_chunk_nb<T>(colp, valp, rel, u.c[t * CH + ch], u.v[t * CH + ch]);
+        }
     }
 }
 
-template <typename T, int LANES, int SB, bool RING>
-__device__ __forceinline__ void consume_unit(const Unit<T, SB> &u, uint64_t base, uint64_t row_end,
-                                             const uint32_t *__restrict__ col, const T *__restrict__ val,
-                                             const T *__restrict__ x, const T *ring, T *__restrict__ y,
+template <typename T, int LANES, int CH, int SB, bool RING>
+__device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t base, uint64_t row_end,
+                                             const uint32_t *__restrict__ colp, const T *__restrict__ valp,
+                                             const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
                                              uint32_t nnz_lim, uint32_t lane) {
     constexpr int RPS = kWave / LANES;
     constexpr uint32_t MASK = kRing2Bytes / sizeof(T) - 1;
@@ -107,25 +135,30 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB> &u, uint64_t base
     for (int t = 0; t < SB; ++t) {
         uint32_t s, e;
         row_bounds<LANES>(u.o0, u.o1, t, lane, nnz_lim, s, e);
+        s = s > kb ? s : kb;
+        e = e > s ? e : s;
         const uint32_t sa = s & ~3u;      // chunk grid is anchored at element 0
         const uint32_t lo = s - sa;       // 0..3: entries of the first chunk that belong to the previous row
         const uint32_t len = e - sa;      // row end relative to the aligned start
         T sum = T(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t rel = 4u * j + q;
-            const bool in = rel >= lo && rel < len;
-            T xv;
-            if constexpr (RING) xv = ring[u.c[t][q] & MASK];
-            else xv = x[in ? u.c[t][q] : 0u];
-            const T f = r2_fma(u.v[t][q], xv, sum);
-            sum = in ? f : sum;
+        for (int ch = 0; ch < CH; ++ch) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t rel = 4u * (ch * LANES + j) + q;
+                const bool in = rel >= lo && rel < len;
+                T xv;
+                if constexpr (RING) xv = ring[u.c[t * CH + ch][q] & MASK];
+                else xv = x[in ? u.c[t * CH + ch][q] : 0u];
+                const T f = r2_fma(u.v[t * CH + ch][q], xv, sum);
+                sum = in ? f : sum;
+            }
         }
         // rows longer than one pass of the lane group (rare; not pipelined)
-        for (uint32_t rel = 4u * j + 4u * LANES; rel < len; rel += 4u * LANES) {
+        for (uint32_t rel = 4u * (CH * LANES + j); rel < len; rel += 4u * LANES) {
             uint32_t cc[4];
             T vv[4];
-            load_chunk_nb<T>(col, val, (uint64_t)sa + rel, cc, vv);
+            load_chunk_nb<T>(colp, valp, sa - kb + rel, cc, vv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool in = rel + q < len;
@@ -136,55 +169,66 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB> &u, uint64_t base
                 sum = in ? f : sum;
             }
         }
+        if constexpr (LANES == 1) {
+            out = sum;
+        } else {
 #pragma unroll
-        for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);
-        // transpose: lane L keeps the sum of the unit's row L (held by every lane of group L % RPS in step L / RPS)
-        const T got = __shfl(sum, (int)((lane % RPS) * LANES), kWave);
-        out = ((int)(lane / RPS) == t) ? got : out;
+            for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);
+            // transpose: lane L keeps the sum of the unit's row L (held by every lane of group L % RPS in step L / RPS)
+            const T got = __shfl(sum, (int)((lane % RPS) * LANES), kWave);
+            out = ((int)(lane / RPS) == t) ? got : out;
+        }
     }
     const uint64_t row = base + lane;
     if (lane < (uint32_t)(SB * RPS) && row < row_end) y[row] = out;
 }
 
-template <typename T, int LANES, bool RING>
+template <typename T, int LANES, int CH, bool RING>
 __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
                                            const T *__restrict__ val, const T *__restrict__ x, const T *ring,
                                            T *__restrict__ y, uint64_t rb, uint64_t re, uint32_t nnz_lim,
                                            uint64_t last_chunk, uint32_t wave, uint32_t lane) {
     constexpr int STEPS = LANES;
-    constexpr int SB = STEPS < kRing2SB ? STEPS : kRing2SB;
+    constexpr int SBMAX = sizeof(T) == 8 ? 1 : kRing2SB;  // f64 chunks take 12 VGPRs: one step per unit
+    constexpr int SB = STEPS < SBMAX ? STEPS : SBMAX;
     constexpr int RU = SB * (kWave / LANES);                 // rows per unit
     constexpr uint64_t STRIDE = (uint64_t)kRing2Waves * RU;  // rows between two units of a wave
     uint64_t base = rb + (uint64_t)wave * RU;
     if (base >= re) return;
-    Unit<T, SB> A, B, N;  // N: only its offsets are used (the unit after next)
+    // 32-bit addressing inside the phase: everything is relative to the phase's first (aligned) entry
+    uint32_t kb = __builtin_amdgcn_readfirstlane(off[rb]) & ~3u;
+    kb = kb < (uint32_t)last_chunk ? kb : (uint32_t)last_chunk;
+    const uint32_t last_rel = (uint32_t)last_chunk - kb;
+    const uint32_t *colp = col + kb;
+    const T *valp = val + kb;
+    Unit<T, SB * CH> A, B, N;  // N: only its offsets are used (the unit after next)
     load_offsets(A, off, base, re, lane);
     load_offsets(B, off, base + STRIDE, re, lane);
-    issue_unit<T, LANES, SB>(A, col, val, nnz_lim, last_chunk, lane);
+    issue_unit<T, LANES, CH, SB>(A, colp, valp, kb, nnz_lim, last_rel, lane);
     for (;;) {
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, SB, RING>(A, base, re, col, val, x, ring, y, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         // program order = age order: offsets(+2) older than chunks(+1); both stay in flight under consume
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
-        issue_unit<T, LANES, SB>(B, col, val, nnz_lim, last_chunk, lane);
-        consume_unit<T, LANES, SB, RING>(A, base, re, col, val, x, ring, y, nnz_lim, lane);
+        issue_unit<T, LANES, CH, SB>(B, colp, valp, kb, nnz_lim, last_rel, lane);
+        consume_unit<T, LANES, CH, SB, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         A.o0 = N.o0; A.o1 = N.o1;
         base += STRIDE;
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, SB, RING>(B, base, re, col, val, x, ring, y, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
-        issue_unit<T, LANES, SB>(A, col, val, nnz_lim, last_chunk, lane);
-        consume_unit<T, LANES, SB, RING>(B, base, re, col, val, x, ring, y, nnz_lim, lane);
+        issue_unit<T, LANES, CH, SB>(A, colp, valp, kb, nnz_lim, last_rel, lane);
+        consume_unit<T, LANES, CH, SB, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         B.o0 = N.o0; B.o1 = N.o1;
         base += STRIDE;
     }
 }
 
-template <typename T, int LANES>
+template <typename T, int LANES, int CH>
 __global__ void __launch_bounds__(kRing2Threads, 4)  // 4 waves per SIMD = two 512-thread blocks per CU
 k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
              const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
@@ -205,9 +249,9 @@ k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
             __syncthreads();
         }
         if (ph.use_ring)
-            phase_rows<T, LANES, true>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, true>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
         else
-            phase_rows<T, LANES, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
     }
 }
 
@@ -226,7 +270,7 @@ __global__ void k_ring2_tail(const uint32_t *__restrict__ off, const uint32_t *_
 }
 
 template <typename T>
-static int launch_ring2_t(int lanes, const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y,
+static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y,
                           size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
                           const RingPhase *phases, hipStream_t s) {
     // entries the streaming kernel may touch: everything when the arrays are padded to a multiple of 4,
@@ -237,13 +281,21 @@ static int launch_ring2_t(int lanes, const uint32_t *off, const uint32_t *col, c
     } else {
         const uint64_t last_chunk = (nnz_lim - 1) & ~uint64_t(3);
         dim3 grid(n_blocks), block(kRing2Threads);
-        switch (lanes) {
-            case 1: hipLaunchKernelGGL((k_spmv_ring2<T, 1>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
-            case 2: hipLaunchKernelGGL((k_spmv_ring2<T, 2>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
-            case 4: hipLaunchKernelGGL((k_spmv_ring2<T, 4>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
-            case 8: hipLaunchKernelGGL((k_spmv_ring2<T, 8>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, phase_ptr, phases); break;
-            default: return fail(SMH_ERR_INVALID, "ring kernel: lanes per row must be 1, 2, 4 or 8 (got %d)", lanes);
+#define SMH_R2_LAUNCH(L, C)                                                                                          \
+    hipLaunchKernelGGL((k_spmv_ring2<T, L, C>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, \
+                       phase_ptr, phases)
+        switch (lanes * 16 + chunks) {
+            case 1 * 16 + 1: SMH_R2_LAUNCH(1, 1); break;
+            case 1 * 16 + 2: SMH_R2_LAUNCH(1, 2); break;
+            case 1 * 16 + 3: SMH_R2_LAUNCH(1, 3); break;
+            case 2 * 16 + 1: SMH_R2_LAUNCH(2, 1); break;
+            case 2 * 16 + 2: SMH_R2_LAUNCH(2, 2); break;
+            case 4 * 16 + 1: SMH_R2_LAUNCH(4, 1); break;
+            case 8 * 16 + 1: SMH_R2_LAUNCH(8, 1); break;
+            default:
+                return fail(SMH_ERR_INVALID, "ring kernel: unsupported (lanes per row, chunks per lane) = (%d, %d)", lanes, chunks);
         }
+#undef SMH_R2_LAUNCH
         SMH_HIP(hipGetLastError());
     }
     if (nnz_lim != nnz) {
@@ -253,14 +305,14 @@ static int launch_ring2_t(int lanes, const uint32_t *off, const uint32_t *col, c
     return SMH_OK;
 }
 
-int launch_spmv_ring2(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
+int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
                       void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
                       const RingPhase *phases, hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
     if (dtype == SMH_F64)
-        return launch_ring2_t<double>(lanes, off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz,
+        return launch_ring2_t<double>(lanes, chunks, off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz,
                                       padded, n_blocks, phase_ptr, phases, s);
-    return launch_ring2_t<float>(lanes, off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded,
+    return launch_ring2_t<float>(lanes, chunks, off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded,
                                  n_blocks, phase_ptr, phases, s);
 }
 

@@ -106,10 +106,13 @@ class SparseMatCRS:
     def resolved_variant(self):
         v, lanes = C.c_int(), C.c_int()
         check(lib().smh_crs_resolved_variant(self._h, C.byref(v), C.byref(lanes)))
-        return {1: "vector", 2: "merge", 3: "seq"}[v.value], lanes.value
+        return {1: "vector", 2: "merge", 3: "seq", 4: "stream"}[v.value], lanes.value
 
     def set_vector_lanes(self, lanes):
         check(lib().smh_crs_set_vector_lanes(self._h, lanes))
+
+    def set_vector_chunks(self, chunks):
+        check(lib().smh_crs_set_vector_chunks(self._h, chunks))
 
     def set_ring(self, mode):
         """K1r (LDS x-ring) for the vector family: -1 automatic, 0 off, 1 on."""

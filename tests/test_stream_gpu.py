@@ -1,0 +1,77 @@
+"""K1s (CSR-stream for short rows): BIT-EXACT against the oracle (rounded products, storage-order fold), on
+every shape incl. tiles that overflow the LDS stage, unsorted/duplicate columns and unpadded borrowed arrays."""
+import numpy as np
+import pytest
+
+import oracle
+import sparsemat_amd as sm
+from sparsemat_amd import synth
+from util import random_crs
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("kind", ["short", "len8", "empty_heavy", "overflow_tile", "ragged"])
+def test_stream_bit_exact(gpu, dtype, kind):
+    rng = np.random.default_rng({"short": 1, "len8": 2, "empty_heavy": 3, "overflow_tile": 4, "ragged": 5}[kind])
+    n_rows, n_cols = 5003, 4001
+    if kind == "short":
+        lens = rng.integers(0, 10, n_rows)
+    elif kind == "len8":
+        lens = np.full(n_rows, 8)  # power-of-two stride in LDS: the skewed index must keep it conflict-free AND right
+    elif kind == "empty_heavy":
+        lens = rng.integers(0, 4, n_rows)
+        lens[rng.random(n_rows) < 0.7] = 0
+    elif kind == "overflow_tile":
+        lens = rng.integers(0, 9, n_rows)
+        lens[300:420] = 60  # tile 1 holds > 4096 entries: folded from global memory
+        lens[1000] = 5000   # one very long row
+    else:
+        lens = rng.integers(0, 40, n_rows)
+    off, col, val = random_crs(rng, n_rows, n_cols, lens, dtype, dup=True)
+    x = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    y = m.mvp(x, variant="stream")
+    y_ref = oracle.spmv(off, col, val, x)
+    assert np.array_equal(bits(y), bits(y_ref)), "K1s must be bit-exact (%d rows differ)" % (bits(y) != bits(y_ref)).sum()
+    if kind in ("short", "len8", "empty_heavy"):
+        assert m.resolved_variant()[0] == "stream"
+        assert np.array_equal(bits(m.mvp(x)), bits(y_ref))  # AUTO == K1s here
+    else:
+        assert m.resolved_variant()[0] != "stream"
+
+
+def test_stream_on_laplacians_and_borrowed_unpadded_arrays(gpu):
+    for dims in [(37, 23, 1), (9, 7, 5), (64, 64, 4)]:
+        off, col, val = oracle.laplace3d(*dims, np.float32)
+        n = dims[0] * dims[1] * dims[2]
+        x = oracle.gen_x(synth.SEED_X, n, np.float32)
+        m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+        assert m.resolved_variant()[0] == "stream"
+        assert np.array_equal(bits(m.mvp(x)), bits(oracle.spmv(off, col, val, x)))
+    # device-born Laplacian: borrowed arrays whose nnz is not a multiple of 4 (tail chunk read entry by entry)
+    row_end = next(re for re in range(300, 310) if synth.laplace3d_nnz(11, 7, 5, 13, re) % 4 != 0)
+    m = synth.crs_laplace3d(11, 7, 5, np.float32, 13, row_end)
+    off, col, val = m.raw_parts()
+    assert len(val) % 4 != 0
+    x = oracle.gen_x(synth.SEED_X, 11 * 7 * 5, np.float32)
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
+
+
+def test_stream_edge_shapes(gpu):
+    f = np.float32
+    m = sm.SparseMatCRS.from_raw_parts(5, 3, [0, 0, 0, 0, 0, 0], [], np.array([], f))
+    assert np.array_equal(m.mvp(np.ones(3, f), variant="stream"), np.zeros(5, f))
+    m = sm.SparseMatCRS.from_raw_parts(1, 2, [0, 1], [1], np.array([2.5], f))
+    assert np.array_equal(m.mvp(np.array([1, 3, 9], f), variant="stream"), np.array([7.5], f))
+    rng = np.random.default_rng(8)
+    for n_rows in (255, 256, 257, 513):
+        off, col, val = random_crs(rng, n_rows, 100, rng.integers(0, 7, n_rows), f)
+        x = rng.uniform(-1, 1, 100).astype(f)
+        m = sm.SparseMatCRS.from_raw_parts(n_rows, 100, off, col, val)
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))

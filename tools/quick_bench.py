@@ -69,18 +69,23 @@ def main():
         print("== %s: rows %d nnz %d dtype %s auto=%s max_row %d bytes %.3f GB | ring: blocks %d phases %d fraction %.3f active %s" % (
             case, nr, m.n_non_zero_entries(), np.dtype(dtype).name, m.resolved_variant(), m.max_row_len(), B / 1e9,
             nb, len(ph), frac, act), flush=True)
-        for lanes in [int(v) for v in args.lanes.split(",")]:
+        for spec in args.lanes.split(","):  # "lanes" or "lanes:chunks"
+            lanes, chunks = (int(v) for v in (spec + ":0").split(":")[:2])
             m.set_vector_lanes(lanes)
-            for ring in (0, 2, 1):
+            m.set_vector_chunks(chunks)
+            for ring in ((0, 1) if chunks == 0 else (1,)):
                 if ring and lanes > 8:
                     continue
                 m.set_ring(ring)
                 med, mn = time_variant(m, xptr, nr, ybuf.ptr, "vector")
-                report("vector lanes=%d ring=%d" % (lanes, ring), B, med, mn)
+                report("vector lanes=%s %s" % (spec, "K1r" if ring else "K1"), B, med, mn)
         m.set_vector_lanes(0)
+        m.set_vector_chunks(0)
         m.set_ring(-1)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "merge")
         report("merge", B, med, mn)
+        med, mn = time_variant(m, xptr, nr, ybuf.ptr, "stream")
+        report("stream (K1s)", B, med, mn)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "auto")
         report("auto", B, med, mn)
         del m, xbuf, ybuf
