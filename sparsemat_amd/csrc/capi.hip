@@ -5,6 +5,7 @@
 // every entry point that computes needs a HIP device.
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -139,7 +140,12 @@ static int ensure_ring_plan(smh_crs *m) {
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    unsigned blocks = (unsigned)(2 * cus);  // two 512-thread blocks (64 KiB of LDS each) per CU
+    unsigned per_cu = 2;  // two 512-thread blocks (64 KiB of LDS each) are resident per CU
+    if (const char *e = getenv("SMH_RING_BLOCKS_PER_CU")) {  // tuning knob: more, shorter ranges than resident slots
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) per_cu = (unsigned)v;
+    }
+    unsigned blocks = per_cu * (unsigned)cus;
     blocks = (blocks + 7u) & ~7u;
     std::vector<uint32_t> cmin(n_tiles), cmax(n_tiles);
     if (n_tiles) {
@@ -641,6 +647,8 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
     const size_t vs = dtype_size(m->dtype);
     hipStream_t s = m->stream;
     void *r = nullptr, *p = nullptr, *ap = nullptr, *partials = nullptr, *sc = nullptr, *h_sc = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
     int rc = SMH_OK;
     size_t iters = 0;
     double rr = 0.0;
@@ -659,11 +667,34 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
         SMH_TRY(cg_begin(m->dtype, sc, r, n, partials, tol, iter_max, s));
         size_t launched = 0;
         int converged = 0;
+        // A batch of `check_every` iterations (7 kernels each) is captured ONCE into a hipGraph and replayed:
+        // for small systems the loop is launch-bound.  Iterations past convergence / iter_max are no-ops on the
+        // device, so whole batches can always be replayed.  (All workspaces were created by the SpMV above.)
+        if (iter_max > check_every && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int crc = SMH_OK;
+            for (size_t i = 0; i < check_every && crc == SMH_OK; ++i) {
+                crc = spmv_enqueue(m, p, n, ap, variant, s);
+                if (crc == SMH_OK) crc = cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, s);
+            }
+            hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (crc != SMH_OK || ce != hipSuccess || !graph ||
+                hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                graph_exec = nullptr;  // fall back to plain stream launches
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
         while (launched < iter_max) {
             size_t batch = iter_max - launched < check_every ? iter_max - launched : check_every;
-            for (size_t i = 0; i < batch; ++i) {
-                SMH_TRY(spmv_enqueue(m, p, n, ap, variant, s));                                          // :43
-                SMH_TRY(cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, s));                     // :45-59
+            if (graph_exec) {
+                SMH_HIP(hipGraphLaunch(graph_exec, s));
+                batch = check_every;
+            } else {
+                for (size_t i = 0; i < batch; ++i) {
+                    SMH_TRY(spmv_enqueue(m, p, n, ap, variant, s));                                      // :43
+                    SMH_TRY(cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, s));                 // :45-59
+                }
             }
             launched += batch;
             SMH_HIP(hipMemcpyAsync(h_sc, sc, cg_scalars_bytes(m->dtype), hipMemcpyDeviceToHost, s));
@@ -685,6 +716,8 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
     char keep[512];
     strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0;
     (void)hipStreamSynchronize(s);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
     (void)hipFree(r); (void)hipFree(p); (void)hipFree(ap); (void)hipFree(partials); (void)hipFree(sc);
     if (h_sc) (void)hipHostFree(h_sc);
     (void)hipGetLastError();

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Collect rocprofv3 PMC counters (one pass per counter group) for a quick_bench case.
+# Collect rocprofv3 PMC counters (one pass per counter group, never mixed with tracing) for a quick_bench case.
 # usage (on the GPU box): tools/pmc_sweep.sh <outdir> <quick_bench args...>
+# (A TA_*_STALLED / TCP_TCC_READ_REQ_LATENCY group hung the profiler on this pool once: not collected.)
 set -u
 OUT=$1; shift
 mkdir -p "$OUT"
@@ -9,11 +10,10 @@ i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
          "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES" \
          "TA_BUSY_avr TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
-         "TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
          "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/g$i" -- python3 tools/quick_bench.py "$@" > "$OUT/g$i.log" 2>&1
-  echo "group $i rc=$?"
+  timeout -k 5 150 rocprofv3 --pmc $C --output-format csv -d "$OUT/g$i" -- python3 tools/quick_bench.py "$@" > "$OUT/g$i.log" 2>&1
+  echo "group $i ($C) rc=$?"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, json
