@@ -8,8 +8,11 @@ A "step" is one pass of the hot path over the resident matrix: y = A.x with A, x
   N = 1  BASELINE configs[1]: SparseMatCRS<f32,u32>, 10,000,000 rows, 32 nnz/row, banded-stratified
          columns (DESIGN.md "Synthetic inputs"), kernel chosen by SMH_SPMV_AUTO (K1r, lanes 8).
   N > 1  weak scaling, BASELINE configs[4] shape: rank r owns rows [r*10M, (r+1)*10M) of an
-         (N*10M)-row matrix with global columns (SparseMatPar), step = local SpMV + RCCL all-gather
-         of the y slices into the full vector on every rank.
+         (N*10M)-row matrix with global columns (SparseMatPar), step = local SpMV + ONE RCCL exchange
+         that makes y usable as the next x on every rank.  --exchange allgather: all-gather of the y
+         slices (every rank gets the full vector); halo: every rank gets exactly the entries its block
+         references (for this banded matrix: 4096 entries from each neighbour, one all_to_all_single);
+         auto (default) picks halo when that is less than half of the vector.
 `value` = algorithmic bytes moved by all ranks / wall time of the K timed steps (max over ranks).
 Algorithmic bytes per rank and step: nnz*(4+4) + (rows+1)*4 + rows*4 [y] + x_ref*4, where x_ref is
 the number of distinct x entries the rank's rows can reference (rows + band width).
@@ -123,6 +126,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE size)")
     ap.add_argument("--variant", default="auto")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"],
+                    help="N>1: what a step exchanges after the local SpMV (auto: only the vector entries each "
+                         "rank's block references when that is less than half of the vector, else the all-gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # rocprofv3 --pmc child pass
@@ -165,6 +171,7 @@ def main():
     synth.gen_x(synth.SEED_X, n, np.float32, ptr=x.data_ptr())
     y = torch.zeros(n, dtype=torch.float32, device="cuda")
     par = SparseMatPar(world, n, n, rank, HipBlock(mat, args.variant))
+    exchange_mode = par.setup_window_exchange(x, args.exchange) if use_dist else "none"
     variant, lanes = mat.resolved_variant()
     _, ring_frac, ring_active, _, _ = mat.ring_plan()
     band = min(n, 256 * NNZ_PER_ROW)
@@ -189,7 +196,7 @@ def main():
         par.mvp_local(x, y_local)
         ev[i][1].record(stream)
         if use_dist:
-            dist.all_gather_into_tensor(y, y_local)
+            par.exchange_window(y)  # y becomes usable as the next x on this rank
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -214,9 +221,11 @@ def main():
         "config": {
             "workload": ("f32 CSR SpMV, %d rows x %d nnz/row, banded-stratified columns, 1xMI355X" % (rows, NNZ_PER_ROW))
             if world == 1 else
-            ("f32 CSR SpMV, %d rows (%d per GPU) x %d nnz/row, row-partitioned over %d GPUs, RCCL all-gather of y" % (n, rows, NNZ_PER_ROW, world)),
+            ("f32 CSR SpMV, %d rows (%d per GPU) x %d nnz/row, banded-stratified columns, row-partitioned over %d GPUs, "
+             "RCCL exchange of y per step: %s" % (n, rows, NNZ_PER_ROW, world, exchange_mode)),
             "rows_per_gpu": rows, "nnz_per_gpu": nnz, "index": "u32", "kernel": "%s lanes=%d ring=%s (ring rows %.3f)" % (variant, lanes, ring_active, ring_frac),
-            "parallelism": "rows/%d + allgather" % world if world > 1 else "single GPU",
+            "parallelism": "rows/%d + %s exchange (RCCL)" % (world, exchange_mode) if world > 1 else "single GPU",
+            "exchange": exchange_mode,
         },
         "gflops": 2.0 * nnz * world / (elapsed / args.steps) / 1e9,
         "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBPS * world),

@@ -96,6 +96,9 @@ size_t smh_crs_n_cols(const smh_crs *m);
 size_t smh_crs_nnz(const smh_crs *m);
 int smh_crs_dtype(const smh_crs *m);
 int smh_crs_max_row_len(const smh_crs *m, uint32_t *out);
+/* smallest / largest column index stored (0/0 for a matrix without entries): the part of x a
+ * row block references -- what SparseMatPar exchanges between ranks */
+int smh_crs_col_range(const smh_crs *m, uint32_t *min_out, uint32_t *max_out);
 /* SparseMatrix::scale (sparsemat_crs.rs:153-157): values *= a */
 int smh_crs_scale(smh_crs *m, double a);
 /* variant AUTO resolves to; lanes_out = lanes per row of the VECTOR kernel */

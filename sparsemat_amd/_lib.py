@@ -40,6 +40,7 @@ SIGNATURES = {
     "smh_crs_nnz": (_sz, [_vp]),
     "smh_crs_dtype": (_int, [_vp]),
     "smh_crs_max_row_len": (_int, [_vp, _u32p]),
+    "smh_crs_col_range": (_int, [_vp, _u32p, _u32p]),
     "smh_crs_scale": (_int, [_vp, C.c_double]),
     "smh_crs_resolved_variant": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "smh_crs_set_vector_lanes": (_int, [_vp, _int]),

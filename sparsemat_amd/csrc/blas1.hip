@@ -195,7 +195,7 @@ k_crs_stats(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, 
             CrsStats *__restrict__ st) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
-    uint32_t max_len = 0, max_col = 0, bad = 0;
+    uint32_t max_len = 0, max_col = 0, min_inv = 0, bad = 0;  // min_inv = ~min column (so that 0 is the identity)
     for (uint64_t r = tid; r < n_rows; r += nthreads) {
         const uint32_t a = off[r], b = off[r + 1];
         if (b < a) bad |= 1u;
@@ -204,6 +204,7 @@ k_crs_stats(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, 
     for (uint64_t k = tid; k < nnz; k += nthreads) {
         const uint32_t c = col[k];
         if (c > max_col) max_col = c;
+        if (~c > min_inv) min_inv = ~c;
     }
     if (tid == 0) {
         if (off[0] != 0u) bad |= 2u;
@@ -214,11 +215,13 @@ k_crs_stats(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, 
     for (int o = kWave / 2; o > 0; o >>= 1) {
         max_len = max(max_len, (uint32_t)__shfl_down(max_len, o, kWave));
         max_col = max(max_col, (uint32_t)__shfl_down(max_col, o, kWave));
+        min_inv = max(min_inv, (uint32_t)__shfl_down(min_inv, o, kWave));
         bad |= (uint32_t)__shfl_down(bad, o, kWave);
     }
     if ((threadIdx.x & (kWave - 1)) == 0) {
         atomicMax(&st->max_row_len, max_len);
         atomicMax(&st->max_col, max_col);
+        atomicMax(&st->min_col_inv, min_inv);
         if (bad) atomicOr(&st->bad, bad);
     }
 }

@@ -140,8 +140,11 @@ static int ensure_ring_plan(smh_crs *m) {
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    unsigned per_cu = 2;  // two 512-thread blocks (64 KiB of LDS each) are resident per CU
-    if (const char *e = getenv("SMH_RING_BLOCKS_PER_CU")) {  // tuning knob: more, shorter ranges than resident slots
+    // Two 512-thread blocks (64 KiB of LDS each) are resident per CU; the row range is cut into 4x as many
+    // blocks so that the hardware dispatcher evens out the tail (measured on C2, same box, steady state:
+    // 2/CU 0.4245 ms, 8/CU 0.404 ms, 24/CU 0.402 ms; x is then read ~2.7x instead of ~1.4x, from L2).
+    unsigned per_cu = 8;
+    if (const char *e = getenv("SMH_RING_BLOCKS_PER_CU")) {  // tuning knob
         const int v = atoi(e);
         if (v >= 1 && v <= 64) per_cu = (unsigned)v;
     }
@@ -243,6 +246,7 @@ static int finish_create(smh_crs *m, int validate) {
         SMH_TRY(rc);
         m->max_row_len = h_st.max_row_len;
         m->max_col = h_st.max_col;
+        m->min_col = m->nnz ? ~h_st.min_col_inv : 0u;
         m->have_stats = true;
         // a malformed row structure would send the kernels out of bounds: always refused
         if (h_st.bad & 1u) return fail(SMH_ERR_INVALID, "offset_rows is not monotone non-decreasing");
@@ -415,6 +419,13 @@ int smh_crs_dtype(const smh_crs *m) { return m ? m->dtype : -1; }
 int smh_crs_max_row_len(const smh_crs *m, uint32_t *out) {
     if (!m || !out) return fail(SMH_ERR_INVALID, "NULL argument");
     *out = m->max_row_len;
+    return SMH_OK;
+}
+
+int smh_crs_col_range(const smh_crs *m, uint32_t *min_out, uint32_t *max_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (min_out) *min_out = m->min_col;
+    if (max_out) *max_out = m->max_col;
     return SMH_OK;
 }
 

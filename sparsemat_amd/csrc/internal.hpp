@@ -75,6 +75,7 @@ int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, con
 struct CrsStats {
     uint32_t max_row_len;
     uint32_t max_col;
+    uint32_t min_col_inv;  // ~(smallest column)
     uint32_t bad;  // bit0: offsets not monotone, bit1: off[0]!=0, bit2: off[n]!=nnz
 };
 int launch_crs_stats(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t nnz, CrsStats *d_stats,
@@ -101,6 +102,7 @@ struct smh_crs {
     // statistics
     uint32_t max_row_len = 0;
     uint32_t max_col = 0;
+    uint32_t min_col = 0;
     uint32_t max_tile_entries = 0;  // most entries in any 256-row tile (K1s eligibility)
     bool have_stats = false;
     int forced_lanes = 0;

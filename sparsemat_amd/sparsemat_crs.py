@@ -133,6 +133,12 @@ class SparseMatCRS:
         check(lib().smh_crs_max_row_len(self._h, C.byref(out)))
         return out.value
 
+    def col_range(self):
+        """(smallest, largest) stored column index."""
+        lo, hi = C.c_uint32(), C.c_uint32()
+        check(lib().smh_crs_col_range(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
     def merge_table(self):
         n = lib().smh_crs_merge_tiles(self._h)
         rows = np.zeros(n + 1, dtype=np.uint32)

@@ -2,20 +2,28 @@
 
 Mirrors the reference's ``SparseMatPar<M>`` (sparsemat_par.rs:12-35, 71-140): ``n_blocks``
 sub-matrices of ``R = max_n_rows / n_blocks`` local rows each (:21), LOCAL row ids and GLOBAL
-column ids, every block multiplied against the full right-hand side and the results placed at
+column ids, every block multiplied against the right-hand side and the results placed at
 ``b * R`` -- the design its commented-out ``mvp_par`` sketches (:37-68).  Here: one process per
 GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI), block b lives on rank b, the local
-SpMV is the HIP kernel, and the one exchange step is an all-gather of the y slices so that every
-rank holds the full vector for the next product.
+SpMV is the HIP kernel, and there is ONE exchange step per product:
+
+* ``mvp``            -- all-gather of the y slices: every rank ends with the full vector (what the
+                        reference's sketch returns).
+* ``mvp_window``     -- every rank ends with its own slice plus exactly the part of the vector its
+                        block REFERENCES (its column interval [cmin, cmax]) -- all a following
+                        product needs.  For a banded matrix that is a few KiB from the two
+                        neighbours instead of (N-1)/N of the vector over per-link-bound xGMI rings;
+                        for a block that references everything it degenerates to the all-gather.
+                        One ``all_to_all_single`` with split sizes (zero for non-neighbours).
 
 Deviation (documented in DESIGN.md): the reference's ``get_block_and_row_id`` clamps the block
 id to ``n_blocks`` (an out-of-bounds index, sparsemat_par.rs:32) and so cannot address rows
 ``>= n_blocks*R``; here the remainder rows belong to the LAST block.
 
-The partition arithmetic and the gather layout are pure host logic, independent of where the
-local product runs; ``local`` is any object with ``n_rows`` and ``mvp_into(x, y)``.
-``HipBlock`` (the product) wraps a device-resident ``SparseMatCRS``; the CPU/gloo tests plug in
-their own checker block.
+The partition arithmetic, the exchange plan and the gather layout are pure host logic, independent
+of where the local product runs; ``local`` is any object with ``n_rows``, ``col_range()`` and
+``mvp_into(x, y)``.  ``HipBlock`` (the product) wraps a device-resident ``SparseMatCRS``; the
+CPU/gloo tests plug in their own checker block.
 """
 import numpy as np
 
@@ -53,6 +61,27 @@ def split_crs(n_rows, offset_rows, columns, values, n_blocks, b):
     return local_off, np.asarray(columns)[lo:hi], np.asarray(values)[lo:hi]
 
 
+def exchange_plan(n_blocks, n_rows, needs, rank):
+    """Who sends what for ``mvp_window``.  ``needs[q] = (lo, hi)``: rank q references vector entries
+    [lo, hi) (empty when lo >= hi).  Returns (send, recv): lists over peers q of the global range
+    [a, b) this rank sends to q (a piece of ITS OWN slice) / receives from q (a piece of q's slice)."""
+    my_b, my_e = block_range(n_blocks, n_rows, rank)
+    send, recv = [], []
+    for q in range(n_blocks):
+        qb, qe = block_range(n_blocks, n_rows, q)
+        if q == rank:
+            send.append((0, 0))
+            recv.append((0, 0))
+            continue
+        lo, hi = needs[q]
+        a, b = max(lo, my_b), min(hi, my_e)  # what q needs of my slice
+        send.append((a, b) if a < b else (0, 0))
+        lo, hi = needs[rank]
+        a, b = max(lo, qb), min(hi, qe)  # what I need of q's slice
+        recv.append((a, b) if a < b else (0, 0))
+    return send, recv
+
+
 class HipBlock:
     """One rank's sub-matrix on its GPU: a SparseMatCRS plus torch-tensor plumbing."""
 
@@ -60,6 +89,10 @@ class HipBlock:
         self.mat = mat
         self.variant = variant
         self.n_rows = mat.n_rows()
+
+    def col_range(self):
+        lo, hi = self.mat.col_range()
+        return (lo, hi + 1) if self.mat.n_non_zero_entries() else (0, 0)
 
     def mvp_into(self, x, y):
         import torch
@@ -84,6 +117,7 @@ class SparseMatPar:
         self._ragged = self._pad != self.n_rows_sub_matrix
         self._gather_buf = None
         self._y_local = None
+        self._plan = None  # (mode, send, recv, send_sizes, recv_sizes)
 
     @classmethod
     def with_sub_matrices(cls, n_blocks, max_n_rows, n_cols, rank, local, group=None):
@@ -102,28 +136,89 @@ class SparseMatPar:
         """This rank's slice: y[begin:end] = A_b . x (no communication)."""
         self.local.mvp_into(x, y_local)
 
+    # ---- exchange 1: all-gather of the slices (every rank gets the full vector) -----------------
+    def allgather(self, v):
+        """v holds this rank's slice at [begin,end): fill the rest from the other ranks."""
+        import torch
+        import torch.distributed as dist
+        if self.n_blocks == 1:
+            return v
+        if not self._ragged:
+            # in-place layout: rank b's slice already sits at b*R of the gathered vector
+            dist.all_gather_into_tensor(v, v[self.begin:self.end], group=self.group)
+            return v
+        # ragged last block: gather equal, padded counts, then compact
+        if self._gather_buf is None or self._gather_buf.dtype != v.dtype:
+            self._gather_buf = torch.zeros(self.n_blocks * self._pad, dtype=v.dtype, device=v.device)
+            self._y_local = torch.zeros(self._pad, dtype=v.dtype, device=v.device)
+        self._y_local[:self.end - self.begin] = v[self.begin:self.end]
+        dist.all_gather_into_tensor(self._gather_buf, self._y_local, group=self.group)
+        for b in range(self.n_blocks):
+            bb, be = block_range(self.n_blocks, self._n_rows, b)
+            v[bb:be] = self._gather_buf[b * self._pad:b * self._pad + (be - bb)]
+        return v
+
     def mvp(self, x, out=None):
         """y = A.x on every rank: local SpMV + all-gather of the slices into the full vector."""
         import torch
-        import torch.distributed as dist
         if out is None:
             out = torch.empty(self._n_rows, dtype=x.dtype, device=x.device)
+        self.local.mvp_into(x, out[self.begin:self.end])
+        return self.allgather(out)
+
+    # ---- exchange 2: only what each block references -------------------------------------------------
+    def setup_window_exchange(self, like, mode="auto"):
+        """Agree on the exchange plan (collective, once): every rank publishes the column interval its
+        block references.  mode "auto": neighbour pieces when they are less than half of the vector,
+        else the all-gather (a block that references everything gains nothing from a plan)."""
+        import torch
+        import torch.distributed as dist
+        lo, hi = self.local.col_range()
         if self.n_blocks == 1:
-            self.local.mvp_into(x, out)
-            return out
-        if not self._ragged:
-            # in-place layout: rank b's slice already sits at b*R of the gathered vector
-            self.local.mvp_into(x, out[self.begin:self.end])
-            dist.all_gather_into_tensor(out, out[self.begin:self.end], group=self.group)
-            return out
-        # ragged last block: gather equal, padded counts, then compact
-        if self._gather_buf is None or self._gather_buf.dtype != x.dtype:
-            self._gather_buf = torch.zeros(self.n_blocks * self._pad, dtype=x.dtype, device=x.device)
-            self._y_local = torch.zeros(self._pad, dtype=x.dtype, device=x.device)
-        self.local.mvp_into(x, self._y_local[:self.end - self.begin])
-        dist.all_gather_into_tensor(self._gather_buf, self._y_local, group=self.group)
-        r = self.n_rows_sub_matrix
-        for b in range(self.n_blocks):
-            bb, be = block_range(self.n_blocks, self._n_rows, b)
-            out[bb:be] = self._gather_buf[b * self._pad:b * self._pad + (be - bb)]
-        return out
+            self._plan = ("none", None, None, None, None)
+            return self._plan[0]
+        mine = torch.tensor([lo, hi], dtype=torch.int64, device=like.device)
+        everyone = torch.empty(2 * self.n_blocks, dtype=torch.int64, device=like.device)
+        dist.all_gather_into_tensor(everyone, mine, group=self.group)
+        needs = [(int(a), int(b)) for a, b in everyone.cpu().view(-1, 2).tolist()]
+        send, recv = exchange_plan(self.n_blocks, self._n_rows, needs, self.rank)
+        worst = 0
+        for q in range(self.n_blocks):  # the plan is global: every rank computes the same decision
+            _, rq = exchange_plan(self.n_blocks, self._n_rows, needs, q)
+            worst = max(worst, sum(b - a for a, b in rq))
+        use_halo = mode == "halo" or (mode == "auto" and worst * 2 < self._n_rows)
+        self._plan = ("halo" if use_halo else "allgather", send, recv,
+                      [b - a for a, b in send], [b - a for a, b in recv])
+        return self._plan[0]
+
+    def exchange_window(self, v):
+        """v holds this rank's slice at [begin,end): fetch the referenced entries owned by other ranks."""
+        import torch
+        import torch.distributed as dist
+        if self._plan is None:
+            raise RuntimeError("call setup_window_exchange() first")
+        mode, send, recv, send_sizes, recv_sizes = self._plan
+        if mode == "none":
+            return v
+        if mode == "allgather":
+            return self.allgather(v)
+        pieces = [v[a:b] for (a, b) in send if a < b]
+        sendbuf = torch.cat(pieces) if pieces else v.new_empty(0)
+        recvbuf = v.new_empty(sum(recv_sizes))
+        dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=recv_sizes, input_split_sizes=send_sizes,
+                               group=self.group)
+        pos = 0
+        for (a, b) in recv:
+            if a < b:
+                v[a:b] = recvbuf[pos:pos + (b - a)]
+                pos += b - a
+        return v
+
+    def mvp_window(self, x, out=None):
+        """Local SpMV into this rank's slice of ``out`` + exchange of the referenced entries: afterwards
+        ``out`` is valid on [begin,end) and on the block's column interval -- ready to be the next x."""
+        import torch
+        if out is None:
+            out = torch.zeros(self._n_rows, dtype=x.dtype, device=x.device)
+        self.local.mvp_into(x, out[self.begin:self.end])
+        return self.exchange_window(out)

@@ -149,41 +149,88 @@ from sparsemat_amd.sparsemat_par import SparseMatPar
 class CheckerBlock:  # test-only local product (the CPU oracle); the product's block is HipBlock
     def __init__(self, off, col, val):
         self.off, self.col, self.val, self.n_rows = off, col, val, len(off) - 1
+    def col_range(self):
+        return (int(self.col.min()), int(self.col.max()) + 1) if len(self.col) else (0, 0)
     def mvp_into(self, x, y):
         y.copy_(torch.from_numpy(oracle.spmv(self.off, self.col, self.val, x.numpy())))
 
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
-for n_rows in (64, 101):  # even split (in-place gather) and ragged last block (padded gather)
-    rng = np.random.default_rng(42)
-    n_cols = n_rows
+def make(n_rows, banded, rng):
     lens = rng.integers(0, 12, n_rows)
     off = np.zeros(n_rows + 1, np.uint32); np.cumsum(lens, out=off[1:])
-    col = rng.integers(0, n_cols, off[-1]).astype(np.uint32)
-    val = rng.uniform(-1, 1, off[-1]).astype(np.float32)
-    x = rng.uniform(-1, 1, n_cols).astype(np.float32)
-    lo, lc, lv = sparsemat_par.split_crs(n_rows, off, col, val, world, rank)
-    par = SparseMatPar.with_sub_matrices(world, n_rows, n_cols, rank, CheckerBlock(lo, lc, lv))
-    y_ref = oracle.spmv(off, col, val, x)
-    xt = torch.from_numpy(x.copy())
-    for it in range(3):  # iterate: the gathered vector feeds the next product (CG-style)
-        yt = par.mvp(xt)
-        assert yt.shape == (n_rows,)
-        assert np.array_equal(yt.numpy(), y_ref), (rank, n_rows, it)
-        xt = yt.clone(); y_ref = oracle.spmv(off, col, val, y_ref)
+    if banded:  # columns within +-3 of the row: a block references its slice + a 3-entry halo
+        rows = np.repeat(np.arange(n_rows), lens)
+        col = np.clip(rows + rng.integers(-3, 4, off[-1]), 0, n_rows - 1).astype(np.uint32)
+    else:
+        col = rng.integers(0, n_rows, off[-1]).astype(np.uint32)
+    val = rng.uniform(-0.3, 0.3, off[-1]).astype(np.float32)
+    return off, col, val
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+for n_rows in (64 * world, 64 * world + 37):  # even split (in-place gather) and ragged last block
+    for banded in (False, True):
+        rng = np.random.default_rng(42)
+        off, col, val = make(n_rows, banded, rng)
+        x = rng.uniform(-1, 1, n_rows).astype(np.float32)
+        lo, lc, lv = sparsemat_par.split_crs(n_rows, off, col, val, world, rank)
+        par = SparseMatPar.with_sub_matrices(world, n_rows, n_rows, rank, CheckerBlock(lo, lc, lv))
+        # (1) mvp: every rank ends with the full vector; iterate (the gathered vector feeds the next product)
+        y_ref = oracle.spmv(off, col, val, x)
+        xt = torch.from_numpy(x.copy())
+        for it in range(3):
+            yt = par.mvp(xt)
+            assert yt.shape == (n_rows,)
+            assert np.array_equal(yt.numpy(), y_ref), (rank, n_rows, it)
+            xt = yt.clone(); y_ref = oracle.spmv(off, col, val, y_ref)
+        # (2) mvp_window: own slice + the referenced interval only
+        mode = par.setup_window_exchange(xt)
+        assert mode == ("halo" if banded else "allgather"), (mode, banded)
+        clo, chi = par.local.col_range()
+        y_ref = oracle.spmv(off, col, val, x)
+        xt = torch.from_numpy(x.copy())
+        for it in range(3):
+            yt = par.mvp_window(xt)
+            got, want = yt.numpy(), y_ref
+            assert np.array_equal(got[par.begin:par.end], want[par.begin:par.end]), (rank, n_rows, banded, it)
+            assert np.array_equal(got[clo:chi], want[clo:chi]), ("window", rank, n_rows, banded, it)
+            xt = yt.clone(); y_ref = oracle.spmv(off, col, val, y_ref)
+        if banded:  # the plan really is neighbour-only
+            _, send, recv, ssz, rsz = par._plan
+            assert sum(rsz) <= 6 and all(sz == 0 for q, sz in enumerate(rsz) if abs(q - rank) > 1)
 dist.barrier()
 dist.destroy_process_group()
 print("rank %%d ok" %% rank)
 '''
 
 
-def test_sparsemat_par_gloo_world_size_2(tmp_path):
-    """N>1 path on CPU: 2 processes, gloo, local products by the checker block, all-gather layout."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_sparsemat_par_gloo(tmp_path, world):
+    """N>1 path on CPU: `world` processes, gloo, local products by the checker block; the all-gather
+    layout (even and ragged) and the referenced-window exchange (neighbour plan and its all-gather fallback)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29531 + world), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0] for p in procs]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o
+
+
+def test_exchange_plan_arithmetic():
+    n_blocks, n_rows = 4, 103  # R = 25, last block 28 rows
+    needs = [(0, 30), (20, 55), (45, 80), (70, 103)]
+    for rank in range(n_blocks):
+        send, recv = sparsemat_par.exchange_plan(n_blocks, n_rows, needs, rank)
+        b, e = sparsemat_par.block_range(n_blocks, n_rows, rank)
+        for q in range(n_blocks):
+            sa, sb = send[q]
+            qs, qr = sparsemat_par.exchange_plan(n_blocks, n_rows, needs, q)
+            assert (sa, sb) == qr[rank]  # what I send to q is what q expects from me
+            if sa < sb:
+                assert b <= sa and sb <= e  # a piece of MY slice
+        got = sorted((a, bb) for a, bb in recv if a < bb)
+        covered = set(range(b, e))
+        for a, bb in got:
+            covered |= set(range(a, bb))
+        assert set(range(*needs[rank])) <= covered  # slice + received pieces cover the referenced interval
