@@ -180,6 +180,27 @@ static int ensure_ring_plan(smh_crs *m) {
     return SMH_OK;
 }
 
+// K1s-w: per-tile column intervals, once per matrix
+static int ensure_stream_windows(smh_crs *m) {
+    if (m->stream_planned) return SMH_OK;
+    const size_t n_tiles = (m->n_rows + kStreamRows - 1) / kStreamRows;
+    if (n_tiles) {
+        uint32_t *d_count = nullptr, h_count = 0;
+        SMH_HIP(hipMalloc((void **)&m->d_stream_win, n_tiles * 8 * sizeof(uint32_t)));
+        SMH_HIP(hipMalloc((void **)&d_count, sizeof(uint32_t)));
+        int rc = launch_stream_windows(m->d_off, m->d_col, m->n_rows, m->d_stream_win, d_count, m->stream);
+        hipError_t e = hipSuccess;
+        if (rc == SMH_OK) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, m->stream);
+        if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);
+        (void)hipFree(d_count);
+        if (rc == SMH_OK && e != hipSuccess) rc = hip_fail(e, "stream window readback", __FILE__, __LINE__);
+        SMH_TRY(rc);
+        m->stream_win_fraction = (double)h_count / (double)n_tiles;
+    }
+    m->stream_planned = true;
+    return SMH_OK;
+}
+
 // does the VECTOR family run as K1r (LDS x-ring) for this matrix?
 static int vector_uses_ring(smh_crs *m, bool *out) {
     *out = false;
@@ -211,8 +232,21 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
         }
         case SMH_SPMV_SEQ:
             return launch_spmv_seq(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, s);
-        case SMH_SPMV_STREAM:
-            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, s);
+        case SMH_SPMV_STREAM: {
+            const uint32_t *win = nullptr;
+            if (m->use_stream_win == 1) {
+                SMH_TRY(ensure_stream_windows(m));
+                // measured (512^3 Laplacian): the windowed body is SLOWER (2.77 vs 1.80 ms: an extra barrier,
+                // 5 instead of 8 blocks per CU, as many window-load as gather instructions), so only on request
+                if (m->use_stream_win == 1) win = m->d_stream_win;
+            }
+            // rows per thread: 512-row tiles measured no better than 256-row tiles (1.86 vs 1.80 ms on the 512^3
+            // Laplacian), so one row per thread unless asked (SMH_STREAM_RPT=2, tuning knob)
+            int want = m->stream_rows_per_thread;
+            if (const char *e = getenv("SMH_STREAM_RPT")) want = atoi(e);
+            const int rpt = want == 2 && m->max_tile512_entries <= (uint32_t)kStreamCap ? 2 : 1;
+            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt, s);
+        }
         case SMH_SPMV_MERGE:
             SMH_TRY(ensure_merge_ws(m));
             return launch_spmv_merge(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->n_tiles,
@@ -234,10 +268,15 @@ static int finish_create(smh_crs *m, int validate) {
             // (reuse the first word of the scratch for the K1s tile statistic)
             if (e == hipSuccess && !(h_st.bad & 1u)) {
                 uint32_t mt = 0;
-                rc = launch_stream_max_tile(m->d_off, m->n_rows, &d_st->max_row_len, m->stream);
+                rc = launch_stream_max_tile(m->d_off, m->n_rows, kStreamRows, &d_st->max_row_len, m->stream);
                 if (rc == SMH_OK) e = hipMemcpyAsync(&mt, &d_st->max_row_len, sizeof mt, hipMemcpyDeviceToHost, m->stream);
                 if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);
                 m->max_tile_entries = mt;
+                if (rc == SMH_OK && e == hipSuccess)
+                    rc = launch_stream_max_tile(m->d_off, m->n_rows, 2 * kStreamRows, &d_st->max_row_len, m->stream);
+                if (rc == SMH_OK && e == hipSuccess) e = hipMemcpyAsync(&mt, &d_st->max_row_len, sizeof mt, hipMemcpyDeviceToHost, m->stream);
+                if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);
+                m->max_tile512_entries = mt;
             }
             if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
             if (e != hipSuccess) rc = hip_fail(e, "crs stats readback", __FILE__, __LINE__);
@@ -390,7 +429,8 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
-    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
+    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);
+    (void)hipFree(m->d_stream_win);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
     return SMH_OK;
@@ -440,6 +480,23 @@ int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out)
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (variant_out) *variant_out = resolve_variant(m, SMH_SPMV_AUTO);
     if (lanes_out) *lanes_out = auto_lanes(m);
+    return SMH_OK;
+}
+
+int smh_crs_set_stream_windows(smh_crs *m, int mode) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "window mode must be -1 (auto), 0 (off) or 1 (on)");
+    m->use_stream_win = mode;
+    return SMH_OK;
+}
+
+int smh_crs_stream_windows(smh_crs *m, double *fraction_out, uint32_t *table_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(ensure_stream_windows(m));
+    if (fraction_out) *fraction_out = m->stream_win_fraction;
+    const size_t n_tiles = (m->n_rows + kStreamRows - 1) / kStreamRows;
+    if (table_out && n_tiles)
+        SMH_HIP(hipMemcpy(table_out, m->d_stream_win, n_tiles * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SMH_OK;
 }
 

@@ -40,6 +40,7 @@ constexpr int kMergeTile = kBlock * kMergeItemsPerThread;  // merge items (rows 
 constexpr int kReducePartials = 1024;  // blocks of a stage-1 reduction
 constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
 constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
+constexpr int kStreamXWin = 3072;      // K1s-w: x entries of a tile's column intervals staged in LDS
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 // K1 / SEQ
@@ -55,8 +56,10 @@ int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const
                       const uint32_t *tile_nz, uint32_t *carry_row, void *carry_val, hipStream_t s);
 // K1s (CSR-stream for short rows)
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
-                       size_t n_rows, size_t nnz, bool padded, hipStream_t s);
-int launch_stream_max_tile(const uint32_t *off, size_t n_rows, uint32_t *d_out, hipStream_t s);
+                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rows_per_thread, hipStream_t s);
+int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,
+                          hipStream_t s);
+int launch_stream_max_tile(const uint32_t *off, size_t n_rows, size_t tile_rows, uint32_t *d_out, hipStream_t s);
 // K1r (LDS x-ring): inspector, host plan, kernel
 struct RingPhase {
     uint32_t row_begin, row_end;  // rows of this phase (row_begin is a multiple of 64)
@@ -104,6 +107,7 @@ struct smh_crs {
     uint32_t max_col = 0;
     uint32_t min_col = 0;
     uint32_t max_tile_entries = 0;  // most entries in any 256-row tile (K1s eligibility)
+    uint32_t max_tile512_entries = 0;  // ... in any 512-row tile (K1s with two rows per thread)
     bool have_stats = false;
     int forced_lanes = 0;
     int forced_chunks = 0;
@@ -111,6 +115,12 @@ struct smh_crs {
     size_t n_tiles = 0;
     uint32_t *d_tile_row = nullptr, *d_tile_nz = nullptr, *d_carry_row = nullptr;
     void *d_carry_val = nullptr;
+    // K1s-w window table (lazy)
+    bool stream_planned = false;
+    uint32_t *d_stream_win = nullptr;
+    double stream_win_fraction = 0.0;  // share of tiles whose columns fit 4 intervals of <= kStreamXWin entries
+    int use_stream_win = -1;           // -1/0 never (measured slower), 1 always
+    int stream_rows_per_thread = 0;    // 0 automatic (2 when every 512-row tile fits), 1 force one
     // K1r plan (lazy)
     bool ring_planned = false;
     unsigned ring_blocks = 0;

@@ -16,8 +16,14 @@
 //
 // Product rounded, then added in storage order: this is exactly the reference's `sum += rhs.get(j) * val`
 // -- K1s is BIT-EXACT against the reference loop (like the SEQ checker), not merely within tolerance.
-// A tile with more entries than the LDS stage holds (kStreamCap) is folded straight from global memory
-// by the same threads (correct for any matrix; AUTO only picks K1s when no tile overflows).
+//
+// x WINDOWS (K1s-w).  The gathers are what keeps the address path busy (7 stencil arms interleaved over the
+// lanes: ~14 cache lines per gather instruction).  An inspector (create time, one wave per tile) describes the
+// columns a tile references as up to 4 disjoint intervals (a stencil tile: the 3 planes it touches) of at
+// most kStreamXWin entries in total; the kernel then copies those intervals into LDS with coalesced loads
+// and gathers from LDS.  A tile without such a description (columns all over x) gathers from L2 as before,
+// and a tile with more entries than the LDS product stage holds is folded straight from global memory:
+// correct for any matrix, the tables only change speed.
 #include "internal.hpp"
 
 namespace smh {
@@ -33,96 +39,290 @@ __device__ __forceinline__ double st_mul(double a, double b) { return __dmul_rn(
 __device__ __forceinline__ float st_add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ double st_add(double a, double b) { return __dadd_rn(a, b); }
 
-template <typename T>
+// ---- inspector: up to 4 column intervals per tile -------------------------------------------------------
+// win[8*t + 2k], win[8*t + 2k + 1] = [lo, hi) of interval k (sorted, disjoint; hi == lo: unused).  All zero:
+// the tile has no window (gathers go to L2).
+__global__ void __launch_bounds__(kBlock)
+k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, uint64_t n_rows, uint64_t n_tiles,
+                 uint32_t *__restrict__ win, uint32_t *__restrict__ n_windowed) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    for (uint64_t t = wave; t < n_tiles; t += n_waves) {
+        const uint64_t r0 = t * kStreamRows, r1 = r0 + kStreamRows < n_rows ? r0 + kStreamRows : n_rows;
+        const uint64_t k0 = off[r0], k1 = off[r1];
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        bool ok = k1 > k0 && k1 - k0 <= (uint64_t)kStreamCap;
+        if (ok) {
+            uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;
+            for (uint64_t k = k0 + lane; k < k1; k += kWave) {
+                const uint32_t c = col[k];
+                cmin = min(cmin, c);
+                cmax = max(cmax, c);
+            }
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) {
+                cmin = min(cmin, (uint32_t)__shfl_xor(cmin, o, kWave));
+                cmax = max(cmax, (uint32_t)__shfl_xor(cmax, o, kWave));
+            }
+            const uint64_t span = (uint64_t)cmax - cmin + 1;
+            if (span <= (uint64_t)kStreamXWin) {
+                lo[0] = cmin; hi[0] = cmax + 1;
+            } else {
+                // occupancy of 64 equal buckets over [cmin, cmax]; the 3 widest empty runs split the columns
+                const uint64_t w = (span + 63) / 64;
+                unsigned long long occ = 0ull;
+                for (uint64_t k = k0 + lane; k < k1; k += kWave) occ |= 1ull << ((col[k] - cmin) / w);
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) occ |= (unsigned long long)__shfl_xor((long long)occ, o, kWave);
+                // every lane runs the same scalar scan (64 steps): top-3 gaps by length
+                int gs[3] = {-1, -1, -1}, gl[3] = {0, 0, 0};
+                int run_start = -1;
+                for (int b = 0; b <= 64; ++b) {
+                    const bool empty = b < 64 && !((occ >> b) & 1ull);
+                    if (empty) { if (run_start < 0) run_start = b; continue; }
+                    if (run_start >= 0) {
+                        int s0 = run_start, l0 = b - run_start;
+                        run_start = -1;
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                            if (l0 > gl[g]) { const int ts = gs[g], tl = gl[g]; gs[g] = s0; gl[g] = l0; s0 = ts; l0 = tl; }
+                    }
+                }
+                // bucket boundaries of the (up to) 4 segments, in ascending order
+                int cut_s[3], cut_e[3], nc = 0;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    if (gl[g] > 0) { cut_s[nc] = gs[g]; cut_e[nc] = gs[g] + gl[g]; ++nc; }
+                for (int a = 0; a < nc; ++a)          // tiny insertion sort by start
+                    for (int b2 = a + 1; b2 < nc; ++b2)
+                        if (cut_s[b2] < cut_s[a]) { int ts = cut_s[a], te = cut_e[a]; cut_s[a] = cut_s[b2]; cut_e[a] = cut_e[b2]; cut_s[b2] = ts; cut_e[b2] = te; }
+                int seg_b[4], seg_e[4];  // segments in bucket units [seg_b, seg_e)
+                int nseg = 0, cur = 0;
+                for (int a = 0; a < nc; ++a) { seg_b[nseg] = cur; seg_e[nseg] = cut_s[a]; ++nseg; cur = cut_e[a]; }
+                seg_b[nseg] = cur; seg_e[nseg] = 64; ++nseg;
+                // exact column bounds per segment
+                uint32_t smin[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, smax[4] = {0, 0, 0, 0};
+                for (uint64_t k = k0 + lane; k < k1; k += kWave) {
+                    const uint32_t c = col[k];
+                    const int b = (int)((c - cmin) / w);
+#pragma unroll
+                    for (int sgm = 0; sgm < 4; ++sgm)
+                        if (sgm < nseg && b >= seg_b[sgm] && b < seg_e[sgm]) { smin[sgm] = min(smin[sgm], c); smax[sgm] = max(smax[sgm], c); }
+                }
+                uint64_t total = 0;
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+#pragma unroll
+                    for (int o = kWave / 2; o > 0; o >>= 1) {
+                        smin[sgm] = min(smin[sgm], (uint32_t)__shfl_xor(smin[sgm], o, kWave));
+                        smax[sgm] = max(smax[sgm], (uint32_t)__shfl_xor(smax[sgm], o, kWave));
+                    }
+                    if (sgm < nseg && smin[sgm] <= smax[sgm]) { lo[sgm] = smin[sgm]; hi[sgm] = smax[sgm] + 1; total += hi[sgm] - lo[sgm]; }
+                }
+                ok = total <= (uint64_t)kStreamXWin;
+            }
+        }
+        if (lane < 8) {
+            const int k = lane >> 1;
+            win[8 * t + lane] = ok ? ((lane & 1) ? hi[k] : lo[k]) : 0u;
+        }
+        if (lane == 0 && ok) atomicAdd(n_windowed, 1u);  // integer count: exact
+    }
+}
+
+// ---- kernel ----------------------------------------------------------------------------------------------
+// RPT = rows per thread: a tile is RPT*256 consecutive rows (2 when every 512-row tile fits the LDS stage)
+template <typename T, bool XWIN, int RPT>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
-              uint64_t n_tiles) {
+              uint64_t n_tiles, const uint32_t *__restrict__ win) {
     __shared__ T s_prod[kStreamCap + kStreamCap / 32 + 8];
+    __shared__ T s_x[XWIN ? kStreamXWin : 1];
     // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of tiles
     const uint64_t q = n_tiles >> 3, rm = n_tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const uint64_t tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
-    const uint64_t r0 = tile * kStreamRows;
-    const uint64_t r1 = r0 + kStreamRows < n_rows ? r0 + kStreamRows : n_rows;
+    constexpr uint64_t TILE_ROWS = (uint64_t)kStreamRows * RPT;
+    const uint64_t r0 = tile * TILE_ROWS;
+    const uint64_t r1 = r0 + TILE_ROWS < n_rows ? r0 + TILE_ROWS : n_rows;
     const uint32_t tid = threadIdx.x;
-    const uint64_t r = r0 + tid;
-    const uint32_t o0 = off[r < r1 ? r : r1];
-    const uint32_t o1 = off[r + 1 < r1 ? r + 1 : r1];
+    uint32_t o0[RPT], o1[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
+        o0[rr] = off[r < r1 ? r : r1];
+        o1[rr] = off[r + 1 < r1 ? r + 1 : r1];
+    }
     const uint32_t k0 = off[r0], k1 = off[r1];  // tile-uniform: scalar loads
-    T sum = T(0);
+    T sum[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) sum[rr] = T(0);
     if (k1 - k0 <= (uint32_t)kStreamCap) {
+        // interval k of the window sits at s_x[b_k ..), b_k = total length of the intervals before it;
+        // a column c of interval k is at s_x[c - sh_k] with sh_k = lo_k - b_k
+        uint32_t lo1 = 0xFFFFFFFFu, lo2 = 0xFFFFFFFFu, lo3 = 0xFFFFFFFFu, sh0 = 0, sh1 = 0, sh2 = 0, sh3 = 0;
+        bool windowed = false;
+        if constexpr (XWIN) {
+            const uint32_t *w = win + 8 * tile;  // tile-uniform: scalar loads
+            const uint32_t a0 = w[0], e0 = w[1], a1 = w[2], e1 = w[3], a2 = w[4], e2 = w[5], a3 = w[6], e3 = w[7];
+            windowed = e0 > a0;
+            if (windowed) {
+                const uint32_t b1 = e0 - a0, b2 = b1 + (e1 - a1), b3 = b2 + (e2 - a2);
+                sh0 = a0;
+                if (e1 > a1) { lo1 = a1; sh1 = a1 - b1; }
+                if (e2 > a2) { lo2 = a2; sh2 = a2 - b2; }
+                if (e3 > a3) { lo3 = a3; sh3 = a3 - b3; }
+                for (uint32_t c = a0 + tid; c < e0; c += kBlock) s_x[c - sh0] = x[c];
+                for (uint32_t c = a1 + tid; c < e1; c += kBlock) s_x[c - sh1] = x[c];
+                for (uint32_t c = a2 + tid; c < e2; c += kBlock) s_x[c - sh2] = x[c];
+                for (uint32_t c = a3 + tid; c < e3; c += kBlock) s_x[c - sh3] = x[c];
+                __syncthreads();
+            }
+        }
         // dense run of aligned chunks; the arrays' last partial chunk is read entry by entry when the
         // arrays are not padded (nnz_readable = nnz rounded up for padded arrays)
-        for (uint64_t k = (uint64_t)(k0 & ~3u) + 4u * tid; k < k1; k += 4u * kBlock) {
-            uint32_t c[4];
-            T v[4];
-            if (k + 4 <= nnz_readable) {
-                const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(col + k));
-                c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
-                if constexpr (sizeof(T) == 4) {
-                    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(val + k));
-                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-                } else {
-                    const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k));
-                    const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k + 2));
-                    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-                }
-            } else {
+        // A tile holds <= kStreamCap entries = at most NIT chunks per thread: ALL of a thread's chunk loads are
+        // issued before the first gather (they sit in the memory queue together), then all gathers.
+        constexpr int NIT = kStreamCap / (4 * kBlock) + 1;
+        uint32_t c[NIT][4];
+        T v[NIT][4];
+        const uint64_t kbase = (uint64_t)(k0 & ~3u) + 4u * tid;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool in = k + e < nnz;
-                    c[e] = in ? col[k + e] : 0u;
-                    v[e] = in ? val[k + e] : T(0);
+        for (int it = 0; it < NIT; ++it) {
+            const uint64_t k = kbase + (uint64_t)it * (4u * kBlock);
+            if (k < k1) {
+                if (k + 4 <= nnz_readable) {
+                    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(col + k));
+                    c[it][0] = cc.x; c[it][1] = cc.y; c[it][2] = cc.z; c[it][3] = cc.w;
+                    if constexpr (sizeof(T) == 4) {
+                        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(val + k));
+                        v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+                    } else {
+                        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k));
+                        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k + 2));
+                        v[it][0] = a.x; v[it][1] = a.y; v[it][2] = b.x; v[it][3] = b.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool in = k + e < nnz;
+                        c[it][e] = in ? col[k + e] : 0u;
+                        v[it][e] = in ? val[k + e] : T(0);
+                    }
                 }
             }
+        }
+        T xv[NIT][4];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const uint64_t k = kbase + (uint64_t)it * (4u * kBlock);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint64_t i = k + e;
-                if (i >= k0 && i < k1) s_prod[skew((uint32_t)(i - k0))] = st_mul(x[c[e]], v[e]);
+                xv[it][e] = T(0);
+                if (i >= k0 && i < k1) {
+                    if (XWIN && windowed) {
+                        const uint32_t cc = c[it][e];
+                        const uint32_t sh = cc >= lo3 ? sh3 : (cc >= lo2 ? sh2 : (cc >= lo1 ? sh1 : sh0));
+                        xv[it][e] = s_x[cc - sh];
+                    } else {
+                        xv[it][e] = x[c[it][e]];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const uint64_t k = kbase + (uint64_t)it * (4u * kBlock);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint64_t i = k + e;
+                if (i >= k0 && i < k1) s_prod[skew((uint32_t)(i - k0))] = st_mul(xv[it][e], v[it][e]);
             }
         }
         __syncthreads();
-        // row r: storage order, one rounded add per entry (reference: sum += product)
-        uint32_t i = o0 - k0;
-        const uint32_t iend = o1 - k0;
-        for (; i + 4 <= iend; i += 4) {
-            const T p0 = s_prod[skew(i)], p1 = s_prod[skew(i + 1)], p2 = s_prod[skew(i + 2)], p3 = s_prod[skew(i + 3)];
-            sum = st_add(sum, p0);
-            sum = st_add(sum, p1);
-            sum = st_add(sum, p2);
-            sum = st_add(sum, p3);
+        // each row: storage order, one rounded add per entry (reference: sum += product)
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            uint32_t i = o0[rr] - k0;
+            const uint32_t iend = o1[rr] - k0;
+            T acc = T(0);
+            for (; i + 4 <= iend; i += 4) {
+                const T p0 = s_prod[skew(i)], p1 = s_prod[skew(i + 1)], p2 = s_prod[skew(i + 2)], p3 = s_prod[skew(i + 3)];
+                acc = st_add(acc, p0);
+                acc = st_add(acc, p1);
+                acc = st_add(acc, p2);
+                acc = st_add(acc, p3);
+            }
+            for (; i < iend; ++i) acc = st_add(acc, s_prod[skew(i)]);
+            sum[rr] = acc;
         }
-        for (; i < iend; ++i) sum = st_add(sum, s_prod[skew(i)]);
     } else {
         // oversize tile: fold from global memory (same order, same roundings)
-        for (uint64_t k = o0; k < o1; ++k) sum = st_add(sum, st_mul(x[col[k]], val[k]));
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            T acc = T(0);
+            for (uint64_t k = o0[rr]; k < o1[rr]; ++k) acc = st_add(acc, st_mul(x[col[k]], val[k]));
+            sum[rr] = acc;
+        }
     }
-    if (r < r1) y[r] = sum;
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
+        if (r < r1) y[r] = sum[rr];
+    }
+}
+
+template <typename T>
+static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
+                           size_t nnz, bool padded, const uint32_t *win, int rpt, hipStream_t s) {
+    const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
+    if (win) {  // the window table describes 256-row tiles
+        const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
+        hipLaunchKernelGGL((k_spmv_stream<T, true, 1>), dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col, val, x, y,
+                           (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win);
+    } else if (rpt == 2) {
+        const uint64_t n_tiles = (n_rows + 2 * kStreamRows - 1) / (2 * kStreamRows);
+        hipLaunchKernelGGL((k_spmv_stream<T, false, 2>), dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col, val, x, y,
+                           (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win);
+    } else {
+        const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
+        hipLaunchKernelGGL((k_spmv_stream<T, false, 1>), dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col, val, x, y,
+                           (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win);
+    }
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
 }
 
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
-                       size_t n_rows, size_t nnz, bool padded, hipStream_t s) {
+                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
-    const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
-    const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     if (dtype == SMH_F64)
-        hipLaunchKernelGGL(k_spmv_stream<double>, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col,
-                           (const double *)val, (const double *)x, (double *)y, (uint64_t)n_rows, (uint64_t)nnz, readable,
-                           n_tiles);
-    else
-        hipLaunchKernelGGL(k_spmv_stream<float>, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col,
-                           (const float *)val, (const float *)x, (float *)y, (uint64_t)n_rows, (uint64_t)nnz, readable,
-                           n_tiles);
+        return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win, rpt, s);
+    return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt, s);
+}
+
+int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,
+                          hipStream_t s) {
+    const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
+    SMH_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+    if (n_tiles == 0) return SMH_OK;
+    uint64_t blocks = (n_tiles * kWave + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles, win,
+                       d_count);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
 
 // largest number of entries in any 256-row tile (decides whether AUTO may use K1s)
 __global__ void __launch_bounds__(kBlock)
-k_stream_max_tile(const uint32_t *__restrict__ off, uint64_t n_rows, uint64_t n_tiles, uint32_t *__restrict__ out) {
+k_stream_max_tile(const uint32_t *__restrict__ off, uint64_t n_rows, uint64_t n_tiles, uint64_t tile_rows,
+                  uint32_t *__restrict__ out) {
     uint32_t m = 0;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r0 = t * kStreamRows, r1 = r0 + kStreamRows < n_rows ? r0 + kStreamRows : n_rows;
+        const uint64_t r0 = t * tile_rows, r1 = r0 + tile_rows < n_rows ? r0 + tile_rows : n_rows;
         const uint32_t e = off[r1] - off[r0];
         m = e > m ? e : m;
     }
@@ -131,13 +331,14 @@ k_stream_max_tile(const uint32_t *__restrict__ off, uint64_t n_rows, uint64_t n_
     if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);  // integer max: exact, order independent
 }
 
-int launch_stream_max_tile(const uint32_t *off, size_t n_rows, uint32_t *d_out, hipStream_t s) {
+int launch_stream_max_tile(const uint32_t *off, size_t n_rows, size_t tile_rows, uint32_t *d_out, hipStream_t s) {
     SMH_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t), s));
     if (n_rows == 0) return SMH_OK;
-    const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
+    const uint64_t n_tiles = (n_rows + tile_rows - 1) / tile_rows;
     uint64_t blocks = (n_tiles + kBlock - 1) / kBlock;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_stream_max_tile, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, (uint64_t)n_rows, n_tiles, d_out);
+    hipLaunchKernelGGL(k_stream_max_tile, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, (uint64_t)n_rows, n_tiles,
+                       (uint64_t)tile_rows, d_out);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }

@@ -111,6 +111,18 @@ class SparseMatCRS:
     def set_vector_lanes(self, lanes):
         check(lib().smh_crs_set_vector_lanes(self._h, lanes))
 
+    def set_stream_windows(self, mode):
+        """K1s-w (x intervals of a tile staged in LDS): -1 automatic, 0 off, 1 on."""
+        check(lib().smh_crs_set_stream_windows(self._h, mode))
+
+    def stream_windows(self):
+        """(fraction of tiles with a window, table[n_tiles, 4, 2] of [lo, hi) intervals)."""
+        frac = C.c_double()
+        n_tiles = (self.n_rows() + 255) // 256
+        table = np.zeros((n_tiles, 4, 2), dtype=np.uint32)
+        check(lib().smh_crs_stream_windows(self._h, C.byref(frac), table.ctypes.data if n_tiles else None))
+        return frac.value, table
+
     def set_vector_chunks(self, chunks):
         check(lib().smh_crs_set_vector_chunks(self._h, chunks))
 

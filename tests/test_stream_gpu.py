@@ -63,6 +63,74 @@ def test_stream_on_laplacians_and_borrowed_unpadded_arrays(gpu):
     assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
 
 
+def check_windows(m, off, col):
+    """Table invariants: intervals sorted, disjoint, <= 3072 entries in total, and they contain every
+    column the tile references; tiles without a description are all-zero."""
+    frac, table = m.stream_windows()
+    n_rows = len(off) - 1
+    n_win = 0
+    for t in range(len(table)):
+        r0, r1 = t * 256, min(n_rows, t * 256 + 256)
+        cols = col[off[r0]:off[r1]]
+        iv = [(int(a), int(b)) for a, b in table[t] if b > a]
+        if not iv:
+            assert not table[t].any()
+            continue
+        n_win += 1
+        assert len(cols) and len(cols) <= 4096
+        assert sum(b - a for a, b in iv) <= 3072
+        assert all(iv[i][1] <= iv[i + 1][0] for i in range(len(iv) - 1)), iv
+        assert table[t][0][1] > table[t][0][0]  # interval 0 is always used
+        inside = np.zeros(len(cols), bool)
+        for a, b in iv:
+            inside |= (cols >= a) & (cols < b)
+        assert inside.all(), (t, iv)
+    assert abs(frac - n_win / max(len(table), 1)) < 1e-12
+    return frac
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_stream_windows_table_and_bit_exact(gpu, dtype):
+    # 7-point Laplacian: 3 planes -> 3 intervals per tile
+    nx, ny, nz = 40, 36, 9
+    off, col, val = oracle.laplace3d(nx, ny, nz, dtype)
+    n = nx * ny * nz
+    x = oracle.gen_x(synth.SEED_X, n, dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    assert check_windows(m, off, col) == 1.0
+    y_ref = oracle.spmv(off, col, val, x)
+    for mode in (1, 0, -1):
+        m.set_stream_windows(mode)
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), mode
+    # mixed: narrow clusters, 5 clusters (too many intervals -> widest gaps win, may or may not fit), random rows
+    rng = np.random.default_rng(21)
+    n_rows, n_cols = 4000, 2_000_000
+    lens = rng.integers(0, 9, n_rows)
+    off = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = np.empty(int(off[-1]), np.uint32)
+    for i in range(n_rows):
+        a, b = off[i], off[i + 1]
+        t = i // 256
+        if t % 4 == 0:    # one cluster
+            col[a:b] = 5000 * t + rng.integers(0, 900, b - a)
+        elif t % 4 == 1:  # three far clusters
+            col[a:b] = rng.choice([1000, 700_000, 1_900_000], b - a) + rng.integers(0, 600, b - a)
+        elif t % 4 == 2:  # six clusters: cannot be described by 4 short intervals
+            col[a:b] = rng.choice([0, 300_000, 600_000, 900_000, 1_200_000, 1_500_000], b - a) + rng.integers(0, 700, b - a)
+        else:             # anywhere
+            col[a:b] = rng.integers(0, n_cols, b - a)
+    val = rng.uniform(-1, 1, len(col)).astype(dtype)
+    x = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    frac = check_windows(m, off, col)
+    assert 0.3 < frac < 0.8
+    y_ref = oracle.spmv(off, col, val, x)
+    for mode in (1, 0):
+        m.set_stream_windows(mode)
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), mode
+
+
 def test_stream_edge_shapes(gpu):
     f = np.float32
     m = sm.SparseMatCRS.from_raw_parts(5, 3, [0, 0, 0, 0, 0, 0], [], np.array([], f))

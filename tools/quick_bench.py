@@ -84,8 +84,11 @@ def main():
         m.set_ring(-1)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "merge")
         report("merge", B, med, mn)
-        med, mn = time_variant(m, xptr, nr, ybuf.ptr, "stream")
-        report("stream (K1s)", B, med, mn)
+        for mode, tag in ((0, "stream (K1s)"), (1, "stream (K1s-w)")):
+            m.set_stream_windows(mode)
+            med, mn = time_variant(m, xptr, nr, ybuf.ptr, "stream", reps=8 if case != "lap512" and not case.startswith("lap") else 20)
+            report(tag + " win=%.2f" % m.stream_windows()[0] if mode else tag, B, med, mn)
+        m.set_stream_windows(-1)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "auto")
         report("auto", B, med, mn)
         del m, xbuf, ybuf
