@@ -57,7 +57,8 @@ int current_device() {
 // defined in the kernel files
 size_t cg_scalars_bytes(int dtype);
 int cg_begin(int dtype, void *sc, const void *r, size_t n, void *partials, double tol, size_t iter_max, hipStream_t s);
-int cg_iter_tail(int dtype, void *sc, void *x, void *r, void *p, const void *ap, size_t n, void *partials, hipStream_t s);
+int cg_iter_tail(int dtype, void *sc, void *x, void *r, void *p, const void *ap, size_t n, void *partials,
+                 const void *dot_partials, uint32_t dot_count, hipStream_t s);
 void cg_read_scalars(int dtype, const void *host_copy, int *converged, uint64_t *iters, double *rr);
 int synth_x(int dtype, uint64_t seed, size_t begin, size_t n, void *x, hipStream_t s);
 int synth_fixed(int dtype, uint64_t seed, int pattern, size_t n, uint32_t k, size_t row_begin, size_t row_end,
@@ -212,8 +213,28 @@ static int vector_uses_ring(smh_crs *m, bool *out) {
     return SMH_OK;
 }
 
-// enqueue y = A x on stream s (device pointers)
-static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s) {
+// K1s configuration of this handle
+static int stream_rpt(const smh_crs *m) {
+    // rows per thread: 512-row tiles measured no better than 256-row tiles (1.86 vs 1.80 ms on the 512^3
+    // Laplacian), so one row per thread unless asked (SMH_STREAM_RPT=2, tuning knob)
+    int want = m->stream_rows_per_thread;
+    if (const char *e = getenv("SMH_STREAM_RPT")) want = atoi(e);
+    return want == 2 && m->max_tile512_entries <= (uint32_t)kStreamCap ? 2 : 1;
+}
+
+// Can y = A x also leave the partial sums of x.y (CG's p.Ap) in its epilogue?  Only the K1s kernel does;
+// returns the number of partials it would write (0: not fused -- run a separate dot).
+static size_t spmv_fused_dot_partials(const smh_crs *m, size_t x_len, int variant) {
+    if (const char *e = getenv("SMH_CG_FUSED_DOT")) {  // tuning knob: 0 = always the separate dot
+        if (atoi(e) == 0) return 0;
+    }
+    if (resolve_variant(m, variant) != SMH_SPMV_STREAM || m->n_rows != m->n_cols || x_len < m->n_rows) return 0;
+    return stream_tiles(m->n_rows, m->use_stream_win == 1 ? 1 : stream_rpt(m));
+}
+
+// enqueue y = A x on stream s (device pointers); dot_partials (optional, K1s only): see above
+static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s,
+                        void *dot_partials = nullptr) {
     if (m->nnz > 0 && (size_t)m->max_col >= x_len)
         return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, m->max_col);
     const int v = resolve_variant(m, variant);
@@ -240,12 +261,8 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
                 // 5 instead of 8 blocks per CU, as many window-load as gather instructions), so only on request
                 if (m->use_stream_win == 1) win = m->d_stream_win;
             }
-            // rows per thread: 512-row tiles measured no better than 256-row tiles (1.86 vs 1.80 ms on the 512^3
-            // Laplacian), so one row per thread unless asked (SMH_STREAM_RPT=2, tuning knob)
-            int want = m->stream_rows_per_thread;
-            if (const char *e = getenv("SMH_STREAM_RPT")) want = atoi(e);
-            const int rpt = want == 2 && m->max_tile512_entries <= (uint32_t)kStreamCap ? 2 : 1;
-            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt, s);
+            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win,
+                                      stream_rpt(m), dot_partials, s);
         }
         case SMH_SPMV_MERGE:
             SMH_TRY(ensure_merge_ws(m));
@@ -714,7 +731,7 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
     const size_t n = m->n_rows;
     const size_t vs = dtype_size(m->dtype);
     hipStream_t s = m->stream;
-    void *r = nullptr, *p = nullptr, *ap = nullptr, *partials = nullptr, *sc = nullptr, *h_sc = nullptr;
+    void *r = nullptr, *p = nullptr, *ap = nullptr, *partials = nullptr, *dot_partials = nullptr, *sc = nullptr, *h_sc = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int rc = SMH_OK;
@@ -726,6 +743,9 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
         SMH_HIP(hipMalloc(&p, vb));
         SMH_HIP(hipMalloc(&ap, vb));
         SMH_HIP(hipMalloc(&partials, (kReducePartials + 8) * vs));
+        // p.Ap: left in the SpMV epilogue when the kernel can (K1s), else a separate two-stage dot
+        const size_t n_dot = spmv_fused_dot_partials(m, n, variant);
+        if (n_dot) SMH_HIP(hipMalloc(&dot_partials, n_dot * vs));
         SMH_HIP(hipMalloc(&sc, cg_scalars_bytes(m->dtype)));
         SMH_HIP(hipHostMalloc(&h_sc, cg_scalars_bytes(m->dtype)));
         // r = b - A x  (:38) ; p = r.clone() (:39) ; rr = r.r (:40)
@@ -741,8 +761,9 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
         if (iter_max > check_every && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int crc = SMH_OK;
             for (size_t i = 0; i < check_every && crc == SMH_OK; ++i) {
-                crc = spmv_enqueue(m, p, n, ap, variant, s);
-                if (crc == SMH_OK) crc = cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, s);
+                crc = spmv_enqueue(m, p, n, ap, variant, s, dot_partials);
+                if (crc == SMH_OK)
+                    crc = cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, dot_partials, (uint32_t)n_dot, s);
             }
             hipError_t ce = hipStreamEndCapture(s, &graph);
             if (crc != SMH_OK || ce != hipSuccess || !graph ||
@@ -760,8 +781,8 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
                 batch = check_every;
             } else {
                 for (size_t i = 0; i < batch; ++i) {
-                    SMH_TRY(spmv_enqueue(m, p, n, ap, variant, s));                                      // :43
-                    SMH_TRY(cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, s));                 // :45-59
+                    SMH_TRY(spmv_enqueue(m, p, n, ap, variant, s, dot_partials));                        // :43
+                    SMH_TRY(cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, dot_partials, (uint32_t)n_dot, s));  // :45-59
                 }
             }
             launched += batch;
@@ -786,7 +807,7 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
     (void)hipStreamSynchronize(s);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
-    (void)hipFree(r); (void)hipFree(p); (void)hipFree(ap); (void)hipFree(partials); (void)hipFree(sc);
+    (void)hipFree(r); (void)hipFree(p); (void)hipFree(ap); (void)hipFree(partials); (void)hipFree(dot_partials); (void)hipFree(sc);
     if (h_sc) (void)hipHostFree(h_sc);
     (void)hipGetLastError();
     strncpy(g_err, keep, sizeof g_err);

@@ -55,6 +55,17 @@ __device__ __forceinline__ T cg_block_sum(T v, T *s_w) {
     return r;
 }
 
+// out[b] = sum of this block's strided share of in[0..n)   (first stage of folding many partial sums)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_sum_stage1(const T *__restrict__ in, uint64_t n, T *__restrict__ out) {
+    __shared__ T s_w[kBlock / kWave];
+    T acc = T(0);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        acc += in[i];
+    const T r = cg_block_sum<T>(acc, s_w);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
 template <typename T>
 __global__ void k_cg_init(CgScalars<T> *sc, double tol, uint64_t iter_max) {
     sc->rr = sc->rr_prev = sc->pap = sc->alpha = sc->beta = T(0);
@@ -210,13 +221,24 @@ int cg_begin(int dtype, void *sc, const void *r, size_t n, void *partials, doubl
 
 // everything of one iteration AFTER the SpMV Ap = A p
 template <typename T>
-static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T *partials, hipStream_t s) {
+static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T *partials, const T *dot_partials,
+                          uint32_t dot_count, hipStream_t s) {
     CgScalars<T> *sc = (CgScalars<T> *)scv;
     const unsigned rb = reduce_blocks(n);
     const bool vec = cg_aligned16(x) && cg_aligned16(r) && cg_aligned16(p) && cg_aligned16(ap);
-    // p . Ap
-    SMH_TRY(launch_dot(sizeof(T) == 8 ? SMH_F64 : SMH_F32, p, ap, n, partials, partials + kReducePartials, s));
-    hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, partials + kReducePartials, 1u);
+    // p . Ap: either the SpMV epilogue already left per-tile partials (fused), or a separate two-stage dot
+    if (dot_partials && dot_count > (uint32_t)kReducePartials) {
+        // many tiles: fold them with a full grid first (a single block folding 5e5 values costs ~0.6 ms)
+        const unsigned fb = reduce_blocks(dot_count);
+        hipLaunchKernelGGL(k_sum_stage1<T>, dim3(fb), dim3(kBlock), 0, s, dot_partials, (uint64_t)dot_count, partials);
+        SMH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, partials, fb);
+    } else if (dot_partials) {
+        hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, dot_partials, dot_count);
+    } else {
+        SMH_TRY(launch_dot(sizeof(T) == 8 ? SMH_F64 : SMH_F32, p, ap, n, partials, partials + kReducePartials, s));
+        hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, partials + kReducePartials, 1u);
+    }
     SMH_HIP(hipGetLastError());
     if (vec)
         hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, sc, x, r, p, ap, (uint64_t)n, partials);
@@ -236,10 +258,12 @@ static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T 
 }
 
 int cg_iter_tail(int dtype, void *sc, void *x, void *r, void *p, const void *ap, size_t n, void *partials,
-                 hipStream_t s) {
+                 const void *dot_partials, uint32_t dot_count, hipStream_t s) {
     if (dtype == SMH_F64)
-        return cg_iter_tail_t<double>(sc, (double *)x, (double *)r, (double *)p, (const double *)ap, n, (double *)partials, s);
-    return cg_iter_tail_t<float>(sc, (float *)x, (float *)r, (float *)p, (const float *)ap, n, (float *)partials, s);
+        return cg_iter_tail_t<double>(sc, (double *)x, (double *)r, (double *)p, (const double *)ap, n, (double *)partials,
+                                      (const double *)dot_partials, dot_count, s);
+    return cg_iter_tail_t<float>(sc, (float *)x, (float *)r, (float *)p, (const float *)ap, n, (float *)partials,
+                                 (const float *)dot_partials, dot_count, s);
 }
 
 // host view of the scalar block after a poll

@@ -56,7 +56,9 @@ int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const
                       const uint32_t *tile_nz, uint32_t *carry_row, void *carry_val, hipStream_t s);
 // K1s (CSR-stream for short rows)
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
-                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rows_per_thread, hipStream_t s);
+                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rows_per_thread,
+                       void *dot_partials /* optional: x.y per tile, stream_tiles() entries */, hipStream_t s);
+size_t stream_tiles(size_t n_rows, int rows_per_thread);
 int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,
                           hipStream_t s);
 int launch_stream_max_tile(const uint32_t *off, size_t n_rows, size_t tile_rows, uint32_t *d_out, hipStream_t s);

@@ -133,11 +133,13 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 
 // ---- kernel ----------------------------------------------------------------------------------------------
 // RPT = rows per thread: a tile is RPT*256 consecutive rows (2 when every 512-row tile fits the LDS stage)
-template <typename T, bool XWIN, int RPT>
+// DOT: also leave dot_partials[tile] = sum over the tile's rows of x[row] * y[row] (square matrices): the
+// p.Ap of a CG iteration falls out of the SpMV epilogue, in a fixed order (bitwise reproducible).
+template <typename T, bool XWIN, int RPT, bool DOT>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
-              uint64_t n_tiles, const uint32_t *__restrict__ win) {
+              uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials) {
     __shared__ T s_prod[kStreamCap + kStreamCap / 32 + 8];
     __shared__ T s_x[XWIN ? kStreamXWin : 1];
     // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of tiles
@@ -272,35 +274,63 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
         if (r < r1) y[r] = sum[rr];
     }
+    if constexpr (DOT) {
+        __shared__ T s_red[kBlock / kWave];
+        T d = T(0);
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
+            if (r < r1) d += x[r] * sum[rr];
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
+        if ((tid & (kWave - 1)) == 0) s_red[tid / kWave] = d;
+        __syncthreads();
+        if (tid == 0) {
+            T t = T(0);
+#pragma unroll
+            for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w];
+            dot_partials[tile] = t;
+        }
+    }
 }
 
 template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
-                           size_t nnz, bool padded, const uint32_t *win, int rpt, hipStream_t s) {
+                           size_t nnz, bool padded, const uint32_t *win, int rpt, T *dot_partials, hipStream_t s) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
+    const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
+    const dim3 grid((unsigned)n_tiles), block(kBlock);
+#define SMH_ST_LAUNCH(XW, R, D)                                                                                        \
+    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, (uint64_t)nnz, \
+                       readable, n_tiles, win, dot_partials)
     if (win) {  // the window table describes 256-row tiles
-        const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
-        hipLaunchKernelGGL((k_spmv_stream<T, true, 1>), dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col, val, x, y,
-                           (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win);
+        if (dot_partials) SMH_ST_LAUNCH(true, 1, true); else SMH_ST_LAUNCH(true, 1, false);
     } else if (rpt == 2) {
-        const uint64_t n_tiles = (n_rows + 2 * kStreamRows - 1) / (2 * kStreamRows);
-        hipLaunchKernelGGL((k_spmv_stream<T, false, 2>), dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col, val, x, y,
-                           (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win);
+        if (dot_partials) SMH_ST_LAUNCH(false, 2, true); else SMH_ST_LAUNCH(false, 2, false);
     } else {
-        const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
-        hipLaunchKernelGGL((k_spmv_stream<T, false, 1>), dim3((unsigned)n_tiles), dim3(kBlock), 0, s, off, col, val, x, y,
-                           (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win);
+        if (dot_partials) SMH_ST_LAUNCH(false, 1, true); else SMH_ST_LAUNCH(false, 1, false);
     }
+#undef SMH_ST_LAUNCH
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
 
+// tiles (= blocks = dot partials) of a K1s launch
+size_t stream_tiles(size_t n_rows, int rpt) {
+    const size_t rows = (size_t)kStreamRows * (rpt == 2 ? 2 : 1);
+    return (n_rows + rows - 1) / rows;
+}
+
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
-                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, hipStream_t s) {
+                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, void *dot_partials,
+                       hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
     if (dtype == SMH_F64)
-        return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win, rpt, s);
-    return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt, s);
+        return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
+                                       rpt, (double *)dot_partials, s);
+    return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
+                                  (float *)dot_partials, s);
 }
 
 int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,
