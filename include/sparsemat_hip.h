@@ -116,7 +116,8 @@ int smh_crs_stream_windows(smh_crs *m, double *fraction_out, uint32_t *table_out
 int smh_crs_set_vector_chunks(smh_crs *m, int chunks);
 /* K1r, the pipelined VECTOR kernel with an LDS-resident sliding window of x: mode -1 =
  * automatic (whenever lanes <= 8; rows whose column span exceeds the ring gather from L2),
- * 0 = plain K1, 1 = same as -1, 2 = the first, unpipelined K1r body */
+ * 0 = plain K1, 1 = same as -1.  The ring holds 16384 columns (64 KiB of f32 with two 512-thread
+ * blocks per CU, 128 KiB of f64 with one 1024-thread block per CU). */
 int smh_crs_set_ring(smh_crs *m, int mode);
 /* the K1r phase plan (integer structure, invariants checked in tests): phase_ptr_out needs
  * n_blocks+1 entries, phases_out 5 u32 per phase {row_begin,row_end,load_lo,load_hi,use_ring};

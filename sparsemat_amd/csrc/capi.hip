@@ -68,7 +68,7 @@ int synth_fill(int dtype, uint64_t seed, size_t n_cols, size_t row_begin, size_t
 size_t synth_laplace3d_nnz(size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end);
 int synth_laplace3d(int dtype, size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end, uint32_t *off,
                     uint32_t *col, void *val, hipStream_t s);
-void build_ring_plan(size_t n_rows, size_t elem_size, const uint32_t *cmin, const uint32_t *cmax, size_t n_blocks,
+void build_ring_plan(size_t n_rows, size_t ring_entries, const uint32_t *cmin, const uint32_t *cmax, size_t n_blocks,
                      std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases, double *ring_row_fraction);
 void synth_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf);
 void synth_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax, const uint32_t *cdf,
@@ -169,7 +169,7 @@ static int ensure_ring_plan(smh_crs *m) {
     }
     std::vector<uint32_t> phase_ptr;
     std::vector<RingPhase> phases;
-    build_ring_plan(m->n_rows, dtype_size(m->dtype), cmin.data(), cmax.data(), blocks, phase_ptr, phases, &m->ring_fraction);
+    build_ring_plan(m->n_rows, kRingEntries, cmin.data(), cmax.data(), blocks, phase_ptr, phases, &m->ring_fraction);
     SMH_HIP(hipMalloc((void **)&m->d_phase_ptr, phase_ptr.size() * sizeof(uint32_t)));
     SMH_HIP(hipMalloc((void **)&m->d_phases, (phases.size() + 1) * sizeof(RingPhase)));
     SMH_HIP(hipMemcpy(m->d_phase_ptr, phase_ptr.data(), phase_ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -242,9 +242,6 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
         case SMH_SPMV_VECTOR: {
             bool ring = false;
             SMH_TRY(vector_uses_ring(m, &ring));
-            if (ring && m->use_ring == 2)
-                return launch_spmv_ring(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->nnz,
-                                        m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
             if (ring)
                 // owned arrays are padded to a multiple of 4 entries; borrowed ones may end inside a 16-B chunk
                 return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz,
@@ -526,7 +523,7 @@ int smh_crs_set_vector_chunks(smh_crs *m, int chunks) {
 
 int smh_crs_set_ring(smh_crs *m, int mode) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
-    if (mode < -1 || mode > 2) return fail(SMH_ERR_INVALID, "ring mode must be -1 (auto), 0 (off), 1 (on) or 2 (on, unpipelined body)");
+    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "ring mode must be -1 (auto), 0 (plain K1) or 1 (K1r)");
     m->use_ring = mode;
     return SMH_OK;
 }

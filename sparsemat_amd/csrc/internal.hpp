@@ -38,6 +38,7 @@ constexpr int kBlock = 256;         // 4 waves: one per SIMD
 constexpr int kMergeItemsPerThread = 8;
 constexpr int kMergeTile = kBlock * kMergeItemsPerThread;  // merge items (rows + nnz) per tile
 constexpr int kReducePartials = 1024;  // blocks of a stage-1 reduction
+constexpr int kRingEntries = 16384;    // K1r: columns of x the LDS ring holds (64 KiB f32 / 128 KiB f64)
 constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
 constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
 constexpr int kStreamXWin = 3072;      // K1s-w: x entries of a tile's column intervals staged in LDS
@@ -70,9 +71,6 @@ struct RingPhase {
 };
 int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t n_tiles, uint32_t *cmin,
                      uint32_t *cmax, hipStream_t s);
-int launch_spmv_ring(int dtype, int lanes, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
-                     void *y, size_t nnz, unsigned n_blocks, const uint32_t *phase_ptr, const RingPhase *phases,
-                     hipStream_t s);
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
                       void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
                       const RingPhase *phases, hipStream_t s);

@@ -25,9 +25,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kRing2Threads = 512;
-constexpr int kRing2Bytes = 65536;
-constexpr int kRing2Waves = kRing2Threads / kWave;
+// The ring holds kRingEntries columns for either value type (the plan does not depend on T):
+//   f32: 64 KiB  -> 512-thread blocks, two resident per CU;
+//   f64: 128 KiB -> 1024-thread blocks, one resident per CU (same 16 waves per CU, <= 128 VGPRs).
+// LDS is dynamic (above the 64 KiB static limit for f64).
+template <typename T> struct Ring2Cfg { static constexpr int kThreads = sizeof(T) == 8 ? 1024 : 512; };
 #ifndef SMH_RING2_SB
 #define SMH_RING2_SB 2
 #endif
@@ -128,7 +130,7 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
                                              const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
                                              uint32_t nnz_lim, uint32_t lane) {
     constexpr int RPS = kWave / LANES;
-    constexpr uint32_t MASK = kRing2Bytes / sizeof(T) - 1;
+    constexpr uint32_t MASK = kRingEntries - 1;
     const uint32_t j = lane % LANES;
     T out = T(0);
 #pragma unroll
@@ -192,7 +194,7 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
     constexpr int SBMAX = sizeof(T) == 8 ? 1 : kRing2SB;  // f64 chunks take 12 VGPRs: one step per unit
     constexpr int SB = STEPS < SBMAX ? STEPS : SBMAX;
     constexpr int RU = SB * (kWave / LANES);                 // rows per unit
-    constexpr uint64_t STRIDE = (uint64_t)kRing2Waves * RU;  // rows between two units of a wave
+    constexpr uint64_t STRIDE = (uint64_t)(Ring2Cfg<T>::kThreads / kWave) * RU;  // rows between two units of a wave
     uint64_t base = rb + (uint64_t)wave * RU;
     if (base >= re) return;
     // 32-bit addressing inside the phase: everything is relative to the phase's first (aligned) entry
@@ -229,12 +231,14 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
 }
 
 template <typename T, int LANES, int CH>
-__global__ void __launch_bounds__(kRing2Threads, 4)  // 4 waves per SIMD = two 512-thread blocks per CU
+__global__ void __launch_bounds__(Ring2Cfg<T>::kThreads, 4)  // 4 waves per SIMD: 16 waves per CU for either dtype
 k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
              const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
              const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases) {
-    __shared__ T ring[kRing2Bytes / sizeof(T)];
-    constexpr uint32_t MASK = kRing2Bytes / sizeof(T) - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];  // kRingEntries * sizeof(T), dynamic
+    T *ring = reinterpret_cast<T *>(ring_raw);
+    constexpr uint32_t MASK = kRingEntries - 1;
+    constexpr int kRing2Threads = Ring2Cfg<T>::kThreads;
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);  // XCD-aware: neighbours share an L2
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -280,10 +284,20 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
         SMH_HIP(hipMemsetAsync(y, 0, n_rows * sizeof(T), s));
     } else {
         const uint64_t last_chunk = (nnz_lim - 1) & ~uint64_t(3);
-        dim3 grid(n_blocks), block(kRing2Threads);
-#define SMH_R2_LAUNCH(L, C)                                                                                          \
-    hipLaunchKernelGGL((k_spmv_ring2<T, L, C>), grid, block, 0, s, off, col, val, x, y, (uint32_t)nnz_lim, last_chunk, \
-                       phase_ptr, phases)
+        dim3 grid(n_blocks), block(Ring2Cfg<T>::kThreads);
+        constexpr size_t lds_bytes = (size_t)kRingEntries * sizeof(T);
+        // dynamic LDS above 64 KiB must be allowed per kernel (idempotent, cheap)
+#define SMH_R2_LAUNCH(L, C)                                                                                              \
+    do {                                                                                                                 \
+        static bool attr_set = false; /* once per instantiation (and never inside a stream capture) */                  \
+        if (!attr_set) {                                                                                                 \
+            SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C>),                           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                    \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_spmv_ring2<T, L, C>), grid, block, lds_bytes, s, off, col, val, x, y, (uint32_t)nnz_lim,   \
+                           last_chunk, phase_ptr, phases);                                                               \
+    } while (0)
         switch (lanes * 16 + chunks) {
             case 1 * 16 + 1: SMH_R2_LAUNCH(1, 1); break;
             case 1 * 16 + 2: SMH_R2_LAUNCH(1, 2); break;

@@ -8,14 +8,14 @@ from sparsemat_amd import synth
 from util import assert_spmv_close, random_crs
 
 pytestmark = pytest.mark.gpu
-RING_BYTES = 65536
+RING_ENTRIES = 16384
 
 
 def check_plan(m, off, col):
     """Every row is covered exactly once, in order, by its block's phases; a ring phase's window
     (what the ring holds after its load) contains every column its rows reference."""
     n_rows = len(off) - 1
-    ring = RING_BYTES // np.dtype(m.dtype).itemsize
+    ring = RING_ENTRIES  # same for f32 (64 KiB) and f64 (128 KiB of LDS)
     nb, frac, active, ptr, ph = m.ring_plan()
     assert nb % 8 == 0 and len(ptr) == nb + 1 and ptr[0] == 0 and ptr[-1] == len(ph)
     assert np.all(np.diff(ptr.astype(np.int64)) >= 0)
@@ -53,13 +53,13 @@ def test_ring_plan_and_parity_generated(gpu, dtype, pattern, n, k):
     off, col, val = m.raw_parts()
     x = oracle.gen_x(synth.SEED_X, n, dtype)
     frac, active = check_plan(m, off, col)
-    if pattern != synth.PATTERN_UNIFORM and not (dtype == np.float64 and pattern == synth.PATTERN_BANDED and k == 32):
+    if pattern != synth.PATTERN_UNIFORM:
         assert frac == 1.0 and active
     if pattern == synth.PATTERN_UNIFORM:
         assert frac == 0.0  # span of every tile exceeds the ring: all phases gather from L2
     for lanes in (1, 2, 4, 8):
         m.set_vector_lanes(lanes)
-        for ring in (1, 2, 0):
+        for ring in (1, 0):
             m.set_ring(ring)
             assert_spmv_close(m.mvp(x, variant="vector"), off, col, val, x, "lanes%d ring%d" % (lanes, ring))
 
