@@ -165,6 +165,15 @@ int smh_vec_xpby(smh_vec *p, double b, const smh_vec *r);
 int smh_vec_dot(const smh_vec *x, const smh_vec *y, double *out);
 int smh_vec_norm_squared(const smh_vec *x, double *out);
 int smh_vec_norm(const smh_vec *x, double *out); /* vector.rs:61-63 */
+/* The same kernels on raw device pointers with DEVICE-resident scalars, asynchronous on `stream`:
+ * the building blocks of the row-partitioned CG, whose scalars are all-reduced on the device.
+ * dot: *result_dev = x.y (type T; scratch_dev needs smh_blas_dot_scratch_bytes()).
+ * axpy: y += round(*a_dev * x) (linearsolver.rs:47,49).  xpby: p = round(*b_dev * p) + r (:58-59). */
+int smh_blas_dot_dev(smh_dtype dtype, const void *x_dev, const void *y_dev, size_t n, void *result_dev,
+                     void *scratch_dev, void *stream);
+size_t smh_blas_dot_scratch_bytes(void);
+int smh_blas_axpy_dev(smh_dtype dtype, void *y_dev, const void *a_dev, const void *x_dev, size_t n, void *stream);
+int smh_blas_xpby_dev(smh_dtype dtype, void *p_dev, const void *b_dev, const void *r_dev, size_t n, void *stream);
 /* SparseMatrix::mvp on device vectors; y is resized semantics-free: y.dim() must be n_rows */
 int smh_crs_spmv_vec(smh_crs *m, const smh_vec *x, smh_vec *y, int variant);
 

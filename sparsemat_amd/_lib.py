@@ -72,6 +72,10 @@ SIGNATURES = {
     "smh_vec_dot": (_int, [_vp, _vp, C.POINTER(C.c_double)]),
     "smh_vec_norm_squared": (_int, [_vp, C.POINTER(C.c_double)]),
     "smh_vec_norm": (_int, [_vp, C.POINTER(C.c_double)]),
+    "smh_blas_dot_dev": (_int, [_int, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "smh_blas_dot_scratch_bytes": (_sz, []),
+    "smh_blas_axpy_dev": (_int, [_int, _vp, _vp, _vp, _sz, _vp]),
+    "smh_blas_xpby_dev": (_int, [_int, _vp, _vp, _vp, _sz, _vp]),
     "smh_crs_spmv_vec": (_int, [_vp, _vp, _vp, _int]),
     "smh_cg_solve": (_int, [_vp, _vp, _sz, _vp, _sz, C.c_double, _sz, _int, C.POINTER(_sz),
                             C.POINTER(C.c_double)]),
@@ -108,6 +112,15 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -m sparsemat_amd.build` (hipcc, gfx950). "
                 "sparsemat_amd has no CPU fallback." % LIB_PATH)
+        import sys
+        if "torch" in sys.modules:
+            # PyTorch wheels bundle their own HIP runtime; if torch shares the process it must initialise before
+            # the system runtime this library links is loaded (otherwise torch later finds no device)
+            try:
+                if sys.modules["torch"].cuda.is_available():
+                    sys.modules["torch"].cuda.init()
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol

@@ -707,6 +707,30 @@ int smh_vec_norm(const smh_vec *x, double *out) {
     return SMH_OK;
 }
 
+// ---- BLAS-1 on raw device pointers with DEVICE-resident scalars (asynchronous) ------------------------
+// Building blocks of a solver whose scalars never visit the host (the multi-GPU CG all-reduces them on
+// the device between these calls).
+int smh_blas_dot_dev(smh_dtype dtype, const void *x_dev, const void *y_dev, size_t n, void *result_dev,
+                     void *scratch_dev, void *stream) {
+    if (!valid_dtype(dtype)) return fail(SMH_ERR_INVALID, "dtype must be SMH_F32 or SMH_F64");
+    if (!result_dev || !scratch_dev || (n && (!x_dev || !y_dev))) return fail(SMH_ERR_INVALID, "NULL device pointer");
+    return launch_dot(dtype, x_dev, y_dev, n, scratch_dev, result_dev, (hipStream_t)stream);
+}
+
+size_t smh_blas_dot_scratch_bytes(void) { return (size_t)(kReducePartials + 8) * sizeof(double); }
+
+int smh_blas_axpy_dev(smh_dtype dtype, void *y_dev, const void *a_dev, const void *x_dev, size_t n, void *stream) {
+    if (!valid_dtype(dtype)) return fail(SMH_ERR_INVALID, "dtype must be SMH_F32 or SMH_F64");
+    if (!a_dev || (n && (!x_dev || !y_dev))) return fail(SMH_ERR_INVALID, "NULL device pointer");
+    return launch_ew(dtype, Ew::Axpy, y_dev, x_dev, n, 0.0, a_dev, (hipStream_t)stream);
+}
+
+int smh_blas_xpby_dev(smh_dtype dtype, void *p_dev, const void *b_dev, const void *r_dev, size_t n, void *stream) {
+    if (!valid_dtype(dtype)) return fail(SMH_ERR_INVALID, "dtype must be SMH_F32 or SMH_F64");
+    if (!b_dev || (n && (!p_dev || !r_dev))) return fail(SMH_ERR_INVALID, "NULL device pointer");
+    return launch_ew(dtype, Ew::Xpby, p_dev, r_dev, n, 0.0, b_dev, (hipStream_t)stream);
+}
+
 int smh_crs_spmv_vec(smh_crs *m, const smh_vec *x, smh_vec *y, int variant) {
     if (!m || !x || !y) return fail(SMH_ERR_INVALID, "NULL handle");
     if (x->dtype != m->dtype || y->dtype != m->dtype) return fail(SMH_ERR_INVALID, "dtype mismatch");

@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _torch_first():
+    """This image's PyTorch bundles its own HIP runtime (ROCm 7.0) while hipcc links the system one (7.2):
+    when both live in one process PyTorch must initialise first (the other order leaves torch without a
+    device).  bench.py does the same."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
+_torch_first()  # at conftest import: before any test module can load libsparsemat_hip.so (collection-time skipifs do)
+
+
 def _gpu_count():
     try:
         import ctypes as C

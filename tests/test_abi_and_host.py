@@ -234,3 +234,66 @@ def test_exchange_plan_arithmetic():
         for a, bb in got:
             covered |= set(range(a, bb))
         assert set(range(*needs[rank])) <= covered  # slice + received pieces cover the referenced interval
+
+
+WORKER_CG = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import oracle
+from sparsemat_amd import sparsemat_par
+from sparsemat_amd.sparsemat_par import SparseMatPar
+from sparsemat_amd.linearsolver import ParConjugateGradient
+
+class CheckerBlock:
+    def __init__(self, off, col, val):
+        self.off, self.col, self.val, self.n_rows = off, col, val, len(off) - 1
+    def col_range(self):
+        return (int(self.col.min()), int(self.col.max()) + 1) if len(self.col) else (0, 0)
+    def mvp_into(self, x, y):
+        y.copy_(torch.from_numpy(oracle.spmv(self.off, self.col, self.val, x.numpy())))
+
+class CheckerOps:  # test-only vector engine: the oracle's DenseVec arithmetic on CPU tensors
+    def dot(self, x, y, out):
+        out[0] = float(oracle.dot(x.numpy(), y.numpy()))
+    def axpy(self, y, a, x):
+        y.copy_(torch.from_numpy(oracle.vec_axpy(y.numpy(), a.numpy()[0], x.numpy())))
+    def xpby(self, p, b, r):
+        p.copy_(torch.from_numpy(oracle.vec_xpby(p.numpy(), b.numpy()[0], r.numpy())))
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+nx, ny, nz = 9, 8, 7
+n = nx * ny * nz
+off, col, val = oracle.laplace3d(nx, ny, nz, np.float64)
+rng = np.random.default_rng(3)
+b = rng.uniform(-1, 1, n)
+x_ref, it_ref, rr_ref = oracle.cg(n, n, off, col, val, b, np.zeros(n), tol=1e-10, iter_max=400)
+lo, lc, lv = sparsemat_par.split_crs(n, off, col, val, world, rank)
+par = SparseMatPar.with_sub_matrices(world, n, n, rank, CheckerBlock(lo, lc, lv))
+assert par.setup_window_exchange(torch.zeros(1, dtype=torch.float64)) == "halo"  # 7-point stencil: neighbours only
+bl = torch.from_numpy(b[par.begin:par.end].copy())
+xl = torch.zeros(par.end - par.begin, dtype=torch.float64)
+cg = ParConjugateGradient(1e-10, 400, ops=CheckerOps())
+cg.solve(par, bl, xl)
+assert abs(cg.iterations - it_ref) <= 2, (cg.iterations, it_ref)
+assert np.sqrt(cg.r_norm_squared) < 1e-10
+np.testing.assert_allclose(xl.numpy(), x_ref[par.begin:par.end], rtol=0, atol=1e-8)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %%d ok" %% rank)
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_par_cg_gloo(tmp_path, world):
+    """Row-partitioned CG on CPU: halo exchange of p + two scalar all-reduces per iteration (gloo), local
+    arithmetic by the oracle; the result matches the oracle's single-process solve."""
+    script = tmp_path / "worker_cg.py"
+    script.write_text(WORKER_CG % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29551 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in o, o

@@ -147,3 +147,33 @@ def test_cg_panics_of_the_reference(gpu):
     assert e.value.status == _lib.SMH_ERR_DIM_MISMATCH and str(e.value) == "Matrix and vector size mismatch"
     with pytest.raises(oracle.OraclePanic):
         oracle.cg(2, 2, [0, 1, 2], [0, 1], np.array([1, 2], f), np.ones(3), np.zeros(2))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 1e-3)], ids=["f64", "f32"])
+def test_par_cg_single_rank_matches_oracle(gpu, dtype, tol):
+    """ParConjugateGradient (the row-partitioned recurrence, device scalars, smh_blas_*_dev kernels) with one
+    block: same iterates as the oracle up to the reduction order."""
+    import torch
+    from sparsemat_amd.linearsolver import ParConjugateGradient
+    from sparsemat_amd.sparsemat_par import HipBlock, SparseMatPar
+    nx = ny = nz = 12
+    n = nx * ny * nz
+    off, col, val = oracle.laplace3d(nx, ny, nz, dtype)
+    b = oracle.spmv(off, col, val, np.ones(n, dtype))
+    x_ref, it_ref, _ = oracle.cg(n, n, off, col, val, b, np.zeros(n, dtype), tol=tol, iter_max=500)
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    par = SparseMatPar(1, n, n, 0, HipBlock(m))
+    bt = torch.from_numpy(b).cuda()
+    xt = torch.zeros(n, dtype=bt.dtype, device="cuda")
+    cg = ParConjugateGradient(tol, 500)
+    cg.solve(par, bt, xt)
+    torch.cuda.synchronize()
+    assert abs(cg.iterations - it_ref) <= 2 and np.sqrt(cg.r_norm_squared) < tol
+    np.testing.assert_allclose(xt.cpu().numpy(), x_ref, rtol=0, atol=50 * tol)
+    # first iteration is bit-identical to the oracle's when the SpMV is a bit-exact kernel (AUTO = K1s here)
+    xt1 = torch.zeros(n, dtype=bt.dtype, device="cuda")
+    ParConjugateGradient(0.0, 1).solve(par, bt, xt1)
+    x1, _, _ = oracle.cg(n, n, off, col, val, b, np.zeros(n, dtype), tol=0.0, iter_max=1)
+    np.testing.assert_allclose(xt1.cpu().numpy(), x1, rtol=1e-6 if dtype == np.float32 else 1e-14)
+    with pytest.raises(sm.SparseMatPanic):
+        cg.solve(par, bt[:-1], xt)
