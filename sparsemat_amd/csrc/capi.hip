@@ -69,7 +69,8 @@ size_t synth_laplace3d_nnz(size_t nx, size_t ny, size_t nz, size_t row_begin, si
 int synth_laplace3d(int dtype, size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end, uint32_t *off,
                     uint32_t *col, void *val, hipStream_t s);
 void build_ring_plan(size_t n_rows, size_t ring_entries, const uint32_t *cmin, const uint32_t *cmax, size_t n_blocks,
-                     std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases, double *ring_row_fraction);
+                     uint32_t noring_mode, std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases,
+                     double *ring_row_fraction);
 void synth_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf);
 void synth_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax, const uint32_t *cdf,
                             uint32_t *lengths);
@@ -169,7 +170,14 @@ static int ensure_ring_plan(smh_crs *m) {
     }
     std::vector<uint32_t> phase_ptr;
     std::vector<RingPhase> phases;
-    build_ring_plan(m->n_rows, kRingEntries, cmin.data(), cmax.data(), blocks, phase_ptr, phases, &m->ring_fraction);
+    // Phases without a ring gather through L1/L2.  Bypassing L1 (nontemporal gathers, mode 2) was measured
+    // SLOWER on both kinds of such matrices (uniform columns 6.29 vs 5.48 ms, 512^3 Laplacian 3.77 vs 2.68 ms),
+    // so it stays a tuning knob.  The uniform case is bound by the per-CU L1 miss path (rocprofv3: TA busy 78 %,
+    // 71 % of wave cycles stalled on VMEM issue, ~59 G gathers/s) -- only column blocking would change that.
+    uint32_t noring_mode = 0;
+    if (const char *e = getenv("SMH_GATHER_NT")) noring_mode = atoi(e) ? 2u : 0u;
+    build_ring_plan(m->n_rows, kRingEntries, cmin.data(), cmax.data(), blocks, noring_mode, phase_ptr, phases,
+                    &m->ring_fraction);
     SMH_HIP(hipMalloc((void **)&m->d_phase_ptr, phase_ptr.size() * sizeof(uint32_t)));
     SMH_HIP(hipMalloc((void **)&m->d_phases, (phases.size() + 1) * sizeof(RingPhase)));
     SMH_HIP(hipMemcpy(m->d_phase_ptr, phase_ptr.data(), phase_ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -61,8 +61,10 @@ int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 // ---- host: phase plan -------------------------------------------------------------------------------
 // Greedy: a phase takes as many consecutive tiles as keep the union of their column spans within the
 // ring (ring_entries columns); what the ring already holds from the previous phase is not reloaded.
+// noring_mode: gather mode of phases that cannot use the ring (0 cached, 2 L1-bypassing global gathers).
 void build_ring_plan(size_t n_rows, size_t ring_entries, const uint32_t *cmin, const uint32_t *cmax, size_t n_blocks,
-                     std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases, double *ring_row_fraction) {
+                     uint32_t noring_mode, std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases,
+                     double *ring_row_fraction) {
     const uint64_t ring = ring_entries;
     const size_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
     const size_t tiles_per_block = (n_tiles + n_blocks - 1) / n_blocks;
@@ -82,7 +84,8 @@ void build_ring_plan(size_t n_rows, size_t ring_entries, const uint32_t *cmin, c
             if (!empty0 && umax + 1 - umin > ring) {
                 // span wider than the ring: one global-gather phase over the run of such tiles
                 while (e < t_end && cmin[e] <= cmax[e] && (uint64_t)cmax[e] + 1 - cmin[e] > ring) ++e;
-                RingPhase p{(uint32_t)(t * kTileRows), (uint32_t)std::min<uint64_t>((uint64_t)e * kTileRows, n_rows), 0, 0, 0};
+                RingPhase p{(uint32_t)(t * kTileRows), (uint32_t)std::min<uint64_t>((uint64_t)e * kTileRows, n_rows), 0, 0,
+                            noring_mode};
                 phases.push_back(p);
                 t = e;
                 continue;

@@ -124,7 +124,7 @@ __device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const uint32_t *
     }
 }
 
-template <typename T, int LANES, int CH, int SB, bool RING>
+template <typename T, int LANES, int CH, int SB, int GM>
 __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t base, uint64_t row_end,
                                              const uint32_t *__restrict__ colp, const T *__restrict__ valp,
                                              const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
@@ -150,7 +150,8 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
                 const uint32_t rel = 4u * (ch * LANES + j) + q;
                 const bool in = rel >= lo && rel < len;
                 T xv;
-                if constexpr (RING) xv = ring[u.c[t * CH + ch][q] & MASK];
+                if constexpr (GM == 1) xv = ring[u.c[t * CH + ch][q] & MASK];
+                else if constexpr (GM == 2) xv = __builtin_nontemporal_load(&x[in ? u.c[t * CH + ch][q] : 0u]);
                 else xv = x[in ? u.c[t * CH + ch][q] : 0u];
                 const T f = r2_fma(u.v[t * CH + ch][q], xv, sum);
                 sum = in ? f : sum;
@@ -165,7 +166,8 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
             for (int q = 0; q < 4; ++q) {
                 const bool in = rel + q < len;
                 T xv;
-                if constexpr (RING) xv = ring[cc[q] & MASK];
+                if constexpr (GM == 1) xv = ring[cc[q] & MASK];
+                else if constexpr (GM == 2) xv = __builtin_nontemporal_load(&x[in ? cc[q] : 0u]);
                 else xv = x[in ? cc[q] : 0u];
                 const T f = r2_fma(vv[q], xv, sum);
                 sum = in ? f : sum;
@@ -185,7 +187,7 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
     if (lane < (uint32_t)(SB * RPS) && row < row_end) y[row] = out;
 }
 
-template <typename T, int LANES, int CH, bool RING>
+template <typename T, int LANES, int CH, int GM>
 __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
                                            const T *__restrict__ val, const T *__restrict__ x, const T *ring,
                                            T *__restrict__ y, uint64_t rb, uint64_t re, uint32_t nnz_lim,
@@ -209,22 +211,22 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
     issue_unit<T, LANES, CH, SB>(A, colp, valp, kb, nnz_lim, last_rel, lane);
     for (;;) {
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         // program order = age order: offsets(+2) older than chunks(+1); both stay in flight under consume
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB>(B, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        consume_unit<T, LANES, CH, SB, GM>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         A.o0 = N.o0; A.o1 = N.o1;
         base += STRIDE;
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB>(A, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        consume_unit<T, LANES, CH, SB, GM>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         B.o0 = N.o0; B.o1 = N.o1;
         base += STRIDE;
     }
@@ -252,10 +254,14 @@ k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
                 ring[cidx & MASK] = x[cidx];
             __syncthreads();
         }
-        if (ph.use_ring)
-            phase_rows<T, LANES, CH, true>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+        // gather mode of the phase: 1 = LDS ring, 0 = L1/L2-cached global gathers, 2 = L1-bypassing (nt) global
+        // gathers for phases whose columns have no locality to keep in the 32 KiB L1
+        if (ph.use_ring == 1)
+            phase_rows<T, LANES, CH, 1>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+        else if (ph.use_ring == 2)
+            phase_rows<T, LANES, CH, 2>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
         else
-            phase_rows<T, LANES, CH, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 0>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
     }
 }
 
