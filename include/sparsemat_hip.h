@@ -57,8 +57,10 @@ typedef enum {
     SMH_SPMV_MERGE = 2,  /* K2: merge-path tiles, LDS-staged products, deterministic fix-up  */
     SMH_SPMV_SEQ = 3,    /* one lane per row, storage order, mul then add: bit-exact vs the */
                          /* reference loop sparsematrix.rs:146-158 (checker, not fast)      */
-    SMH_SPMV_STREAM = 4  /* K1s: short rows; dense entry stream, rounded products in LDS,   */
+    SMH_SPMV_STREAM = 4, /* K1s: short rows; dense entry stream, rounded products in LDS,   */
                          /* one thread folds a row in storage order: fast AND bit-exact     */
+    SMH_SPMV_COLBLOCK = 5 /* K2c: columns without locality and x larger than the L2s: the    */
+                         /* device copy is split into 2-MiB column blocks of x, y += A_b x  */
 } smh_spmv_variant;
 
 typedef struct smh_crs smh_crs; /* device-resident SparseMatCRS<T,u32>  (sparsemat_crs.rs:9-17) */
@@ -88,7 +90,9 @@ int smh_crs_create_dev(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz
                        const uint32_t *offset_rows_dev, const uint32_t *columns_dev,
                        const void *values_dev, int validate, smh_crs **out);
 int smh_crs_destroy(smh_crs *m);
-int smh_crs_update_values(smh_crs *m, const void *values_host); /* host mutated values: re-upload */
+/* host mutated values: re-upload.  values_host == NULL: the device values (borrowed arrays of
+ * smh_crs_create_dev) were changed in place -- derived copies (K2c) are rebuilt on next use */
+int smh_crs_update_values(smh_crs *m, const void *values_host);
 int smh_crs_download(const smh_crs *m, uint32_t *offset_rows, uint32_t *columns, void *values);
 /* n_rows :124-126, n_cols :128-130, n_non_zero_entries :132-134 */
 size_t smh_crs_n_rows(const smh_crs *m);
@@ -125,6 +129,17 @@ int smh_crs_set_ring(smh_crs *m, int mode);
 int smh_crs_ring_plan(smh_crs *m, uint32_t *n_blocks_out, size_t *n_phases_out,
                       double *ring_fraction_out, int *active_out, uint32_t *phase_ptr_out,
                       uint32_t *phases_out);
+
+/* K2c, the column-blocked copy (built on first use; integer structure, checked bit-exact in tests):
+ * block b holds the entries with column >> shift == b, as a CSR over all rows whose offsets
+ * offsets_out[b*(n_rows+1) + r] are absolute positions into columns_out / values_out [nnz]; inside a
+ * (row, block) pair the entries keep their storage order.  Call with NULL arrays for the sizes.
+ * span_fraction_out (may be NULL): mean column span of a 64-row tile / n_cols, the locality
+ * statistic AUTO uses (COLBLOCK when it exceeds 0.25 and x is larger than 8 MiB).              */
+int smh_crs_set_colblock_shift(smh_crs *m, uint32_t shift); /* block = 2^shift columns; 0 = 2 MiB of x */
+int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int *rows_per_thread_out,
+                     double *span_fraction_out, uint32_t *offsets_out, uint32_t *columns_out,
+                     void *values_out);
 
 /* SparseMatrix::mvp (sparsematrix.rs:146-158) == `A * v` (Mul, sparsematrix.rs:435-443):
  * y[0..n_rows) = A.x.  x_len is x.dim(); a column index >= x_len is SMH_ERR_INDEX_RANGE

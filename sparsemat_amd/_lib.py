@@ -14,8 +14,9 @@ SMH_OK = 0
 SMH_ERR_DIM_MISMATCH, SMH_ERR_NOT_SQUARE, SMH_ERR_INDEX_RANGE, SMH_ERR_INVALID = 1, 2, 3, 4
 SMH_ERR_HIP, SMH_ERR_OOM, SMH_ERR_NO_DEVICE, SMH_ERR_CAPACITY = 5, 6, 7, 8
 SMH_F32, SMH_F64 = 0, 1
-SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ, SPMV_STREAM = 0, 1, 2, 3, 4
-VARIANTS = {"auto": SPMV_AUTO, "vector": SPMV_VECTOR, "merge": SPMV_MERGE, "seq": SPMV_SEQ, "stream": SPMV_STREAM}
+SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ, SPMV_STREAM, SPMV_COLBLOCK = 0, 1, 2, 3, 4, 5
+VARIANTS = {"auto": SPMV_AUTO, "vector": SPMV_VECTOR, "merge": SPMV_MERGE, "seq": SPMV_SEQ, "stream": SPMV_STREAM,
+            "colblock": SPMV_COLBLOCK}
 
 _sz = C.c_size_t
 _vp = C.c_void_p
@@ -49,6 +50,8 @@ SIGNATURES = {
     "smh_crs_set_vector_chunks": (_int, [_vp, _int]),
     "smh_crs_set_ring": (_int, [_vp, _int]),
     "smh_crs_ring_plan": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(C.c_double), C.POINTER(_int), _vp, _vp]),
+    "smh_crs_set_colblock_shift": (_int, [_vp, C.c_uint32]),
+    "smh_crs_colblock": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(_int), C.POINTER(C.c_double), _vp, _vp, _vp]),
     "smh_crs_spmv": (_int, [_vp, _vp, _sz, _vp, _int]),
     "smh_crs_spmv_dev": (_int, [_vp, _vp, _sz, _vp, _int, _vp]),
     "smh_crs_merge_tiles": (_sz, [_vp]),

@@ -110,12 +110,40 @@ static int auto_chunks(const smh_crs *m) {
     return 1;
 }
 
+// K2c geometry: column blocks of 2 MiB of x
+// 2^19 columns: 2 MiB of f32 x.  f64 takes the same width (4 MiB of x, a whole L2): measured on C3, 20 blocks of
+// 2^19 run in 3.64 ms, 39 blocks of 2^18 in 5.08 ms -- the per-block sweeps of offsets and y (12 B + 8 B per row)
+// outweigh the better hit rate (profiles/r01_colblock_sweep.log)
+static uint32_t cb_shift_for(const smh_crs *m) { return m->cb_forced_shift ? m->cb_forced_shift : 19u; }
+static size_t cb_blocks_for(const smh_crs *m) {
+    const uint64_t w = 1ull << cb_shift_for(m);
+    const uint64_t b = ((uint64_t)m->n_cols + w - 1) / w;
+    return (size_t)(b ? b : 1);
+}
+// values changed (update_values / scale): the blocked copy is rebuilt on its next use
+static void drop_colblock(smh_crs *m) {
+    (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);
+    m->d_cb_off = m->d_cb_col = nullptr;
+    m->d_cb_val = nullptr;
+    m->cb_built = false;
+}
+// x too large for the L2s AND rows whose columns span a large part of it (statistic taken at create time for
+// matrices with more than 8 MiB of x): gathers would miss L1 and L2 -> column-blocked execution
+// (tools/experiment_gather.py, 4M rows x 32 uniform columns, f32: K1 / K2c at x = 4 MiB 0.80 / 0.68 ms, 8 MiB
+// 1.25 / 0.66 ms, 16 MiB 1.76 / 0.71 ms, 64 MiB 2.35 / 1.44 ms)
+constexpr size_t kColblockMinXBytes = 4u << 20;
+static bool wants_colblock(const smh_crs *m) {
+    const size_t b = cb_blocks_for(m);
+    return m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes && m->span_fraction > 0.25 && b >= 2 && b <= 128;
+}
+
 static int resolve_variant(const smh_crs *m, int variant) {
     if (variant != SMH_SPMV_AUTO) return variant;
+    if (wants_colblock(m)) return SMH_SPMV_COLBLOCK;
     const int lanes = auto_lanes(m);
-    // short rows (stencils, FEM): the dense CSR-stream kernel, as long as every 256-row tile fits its LDS stage
+    // short rows (stencils, FEM): the dense CSR-stream kernel (a tile denser than its LDS stage takes several passes)
     const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
-    if (mean <= 12.0 && m->max_row_len <= 64 && m->max_tile_entries <= (uint32_t)kStreamCap) return SMH_SPMV_STREAM;
+    if (mean <= 12.0 && m->max_row_len <= 64) return SMH_SPMV_STREAM;
     // skew test: the longest row needs >= 8 passes of a group sized for the mean row
     if ((uint64_t)m->max_row_len >= 8ull * 4ull * (uint64_t)lanes && m->max_row_len > 64) return SMH_SPMV_MERGE;
     return SMH_SPMV_VECTOR;
@@ -168,6 +196,13 @@ static int ensure_ring_plan(smh_crs *m) {
         (void)hipFree(d_min); (void)hipFree(d_max);
         SMH_TRY(rc);
     }
+    {  // locality statistic for AUTO: mean column span of a 64-row tile relative to n_cols
+        double acc = 0.0;
+        size_t used = 0;
+        for (size_t t = 0; t < n_tiles; ++t)
+            if (cmin[t] <= cmax[t]) { acc += (double)(cmax[t] - cmin[t]) + 1.0; ++used; }
+        m->span_fraction = used && m->n_cols ? acc / (double)used / (double)m->n_cols : 0.0;
+    }
     std::vector<uint32_t> phase_ptr;
     std::vector<RingPhase> phases;
     // Phases without a ring gather through L1/L2.  Bypassing L1 (nontemporal gathers, mode 2) was measured
@@ -207,6 +242,45 @@ static int ensure_stream_windows(smh_crs *m) {
         m->stream_win_fraction = (double)h_count / (double)n_tiles;
     }
     m->stream_planned = true;
+    return SMH_OK;
+}
+
+// K2c: build the column-blocked copy, once per matrix
+static int ensure_colblock(smh_crs *m) {
+    if (m->cb_built) return SMH_OK;
+    const size_t blocks = cb_blocks_for(m);
+    if (blocks == 0 || blocks > 128)
+        return fail(SMH_ERR_INVALID, "column-blocked variant: %zu column blocks (supported: 1..128)", blocks);
+    if ((uint64_t)blocks * (m->n_rows + 1) >= (1ull << 34)) return fail(SMH_ERR_OOM, "column-blocked offsets too large");
+    m->cb_shift = cb_shift_for(m);
+    SMH_TRY(build_colblock(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, m->cb_shift, blocks, &m->d_cb_off,
+                           &m->d_cb_col, &m->d_cb_val, m->stream));
+    m->cb_blocks = blocks;
+    // tile height of the K1s launches: the tallest of 2048/1024/512/256 rows whose busiest tile fits the LDS stage
+    uint32_t *d_max = nullptr;
+    SMH_HIP(hipMalloc((void **)&d_max, sizeof(uint32_t)));
+    int rpt = 8;
+    int rc = SMH_OK;
+    uint32_t worst = 0;
+    for (; rpt >= 1; rpt >>= 1) {
+        worst = 0;
+        for (size_t b = 0; b < blocks && rc == SMH_OK; ++b) {
+            uint32_t h = 0;
+            rc = launch_stream_max_tile(m->d_cb_off + b * (m->n_rows + 1), m->n_rows, (size_t)kStreamRows * rpt, d_max, m->stream);
+            if (rc == SMH_OK) {
+                hipError_t e = hipMemcpyAsync(&h, d_max, sizeof h, hipMemcpyDeviceToHost, m->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+                if (e != hipSuccess) rc = hip_fail(e, "colblock tile statistic", __FILE__, __LINE__);
+            }
+            worst = h > worst ? h : worst;
+        }
+        if (rc != SMH_OK || worst <= (uint32_t)kStreamCap || rpt == 1) break;
+    }
+    (void)hipFree(d_max);
+    SMH_TRY(rc);
+    m->cb_rpt = rpt < 1 ? 1 : rpt;
+    m->cb_single_pass = worst <= (uint32_t)kStreamCap;  // else 256-row tiles, several passes where needed
+    m->cb_built = true;
     return SMH_OK;
 }
 
@@ -266,8 +340,19 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
                 // 5 instead of 8 blocks per CU, as many window-load as gather instructions), so only on request
                 if (m->use_stream_win == 1) win = m->d_stream_win;
             }
-            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win,
-                                      stream_rpt(m), dot_partials, s);
+            // a 512-row tiling is only chosen when every such tile fits the LDS stage; the 256-row tiling takes
+            // tiles of any density (loop-free body when the create-time statistic says that none overflows)
+            const int rpt = win ? 1 : stream_rpt(m);
+            const bool single_pass = m->have_stats && (rpt == 2 || m->max_tile_entries <= (uint32_t)kStreamCap);
+            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt,
+                                      single_pass, dot_partials, s);
+        }
+        case SMH_SPMV_COLBLOCK: {
+            SMH_TRY(ensure_colblock(m));
+            for (size_t b = 0; b < m->cb_blocks; ++b)
+                SMH_TRY(launch_spmv_stream_block(m->dtype, m->d_cb_off + b * (m->n_rows + 1), m->d_cb_col, m->d_cb_val, x, y,
+                                                 m->n_rows, m->nnz, m->cb_rpt, m->cb_single_pass, b > 0, s));
+            return SMH_OK;
         }
         case SMH_SPMV_MERGE:
             SMH_TRY(ensure_merge_ws(m));
@@ -315,6 +400,9 @@ static int finish_create(smh_crs *m, int validate) {
         if (h_st.bad & 4u) return fail(SMH_ERR_INVALID, "offset_rows[n_rows] != nnz");
         if (validate && m->nnz > 0 && (size_t)h_st.max_col >= m->n_cols)
             return fail(SMH_ERR_INDEX_RANGE, "column index %u >= n_cols %zu", h_st.max_col, m->n_cols);
+        // x larger than the L2s: take the locality statistic AUTO needs (one pass over columns[]; it is the K1r
+        // inspector, so its plan is ready too)
+        if (m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes) SMH_TRY(ensure_ring_plan(m));
     }
     return SMH_OK;
 }
@@ -452,15 +540,17 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
     (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);
-    (void)hipFree(m->d_stream_win);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
+    (void)hipFree(m->d_stream_win);
+    (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
     return SMH_OK;
 }
 
 int smh_crs_update_values(smh_crs *m, const void *values_host) {
-    if (!m || !values_host) return fail(SMH_ERR_INVALID, "NULL argument");
-    if (m->nnz) SMH_HIP(hipMemcpy(m->d_val, values_host, m->nnz * dtype_size(m->dtype), hipMemcpyHostToDevice));
+    if (!m) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (m->nnz && values_host) SMH_HIP(hipMemcpy(m->d_val, values_host, m->nnz * dtype_size(m->dtype), hipMemcpyHostToDevice));
+    drop_colblock(m);
     return SMH_OK;
 }
 
@@ -494,7 +584,32 @@ int smh_crs_col_range(const smh_crs *m, uint32_t *min_out, uint32_t *max_out) {
 int smh_crs_scale(smh_crs *m, double a) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(launch_scale_values(m->dtype, m->d_val, m->nnz, a, m->stream));
+    if (m->cb_built) SMH_TRY(launch_scale_values(m->dtype, m->d_cb_val, m->nnz, a, m->stream));
     SMH_HIP(hipStreamSynchronize(m->stream));
+    return SMH_OK;
+}
+
+int smh_crs_set_colblock_shift(smh_crs *m, uint32_t shift) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (shift > 31) return fail(SMH_ERR_INVALID, "column block shift must be 0 (automatic) or 1..31");
+    if (shift != m->cb_forced_shift) drop_colblock(m);
+    m->cb_forced_shift = shift;
+    return SMH_OK;
+}
+
+int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int *rows_per_thread_out,
+                     double *span_fraction_out, uint32_t *offsets_out, uint32_t *columns_out, void *values_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(ensure_ring_plan(m));  // the locality statistic
+    SMH_TRY(ensure_colblock(m));
+    if (shift_out) *shift_out = m->cb_shift;
+    if (n_blocks_out) *n_blocks_out = m->cb_blocks;
+    if (rows_per_thread_out) *rows_per_thread_out = m->cb_rpt;
+    if (span_fraction_out) *span_fraction_out = m->span_fraction;
+    if (offsets_out)
+        SMH_HIP(hipMemcpy(offsets_out, m->d_cb_off, m->cb_blocks * (m->n_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (columns_out && m->nnz) SMH_HIP(hipMemcpy(columns_out, m->d_cb_col, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (values_out && m->nnz) SMH_HIP(hipMemcpy(values_out, m->d_cb_val, m->nnz * dtype_size(m->dtype), hipMemcpyDeviceToHost));
     return SMH_OK;
 }
 

@@ -58,11 +58,19 @@ int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const
 // K1s (CSR-stream for short rows)
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rows_per_thread,
+                       bool single_pass /* no tile holds more than kStreamCap entries */,
                        void *dot_partials /* optional: x.y per tile, stream_tiles() entries */, hipStream_t s);
 size_t stream_tiles(size_t n_rows, int rows_per_thread);
 int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,
                           hipStream_t s);
 int launch_stream_max_tile(const uint32_t *off, size_t n_rows, size_t tile_rows, uint32_t *d_out, hipStream_t s);
+// K2c (column-blocked CSR; each block runs the K1s kernel)
+int launch_spmv_stream_block(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
+                             size_t n_rows, size_t nnz_total, int rows_per_thread, bool single_pass, bool accumulate,
+                             hipStream_t s);
+int build_colblock(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz,
+                   uint32_t shift, size_t n_blocks, uint32_t **off2_out, uint32_t **col2_out, void **val2_out,
+                   hipStream_t s);
 // K1r (LDS x-ring): inspector, host plan, kernel
 struct RingPhase {
     uint32_t row_begin, row_end;  // rows of this phase (row_begin is a multiple of 64)
@@ -121,6 +129,16 @@ struct smh_crs {
     double stream_win_fraction = 0.0;  // share of tiles whose columns fit 4 intervals of <= kStreamXWin entries
     int use_stream_win = -1;           // -1/0 never (measured slower), 1 always
     int stream_rows_per_thread = 0;    // 0 automatic (2 when every 512-row tile fits), 1 force one
+    // K2c column-blocked copy (lazy)
+    bool cb_built = false;
+    uint32_t cb_forced_shift = 0;  // 0 automatic (2 MiB of x per block)
+    uint32_t cb_shift = 0;       // block width = 2^cb_shift columns
+    size_t cb_blocks = 0;
+    int cb_rpt = 1;              // rows per thread of the K1s launches (tile = 256*cb_rpt rows)
+    bool cb_single_pass = false; // no tile of any block exceeds the LDS stage
+    uint32_t *d_cb_off = nullptr, *d_cb_col = nullptr;
+    void *d_cb_val = nullptr;
+    double span_fraction = 0.0;  // mean column span of a 64-row tile / n_cols (1: no locality at all)
     // K1r plan (lazy)
     bool ring_planned = false;
     unsigned ring_blocks = 0;

@@ -21,9 +21,11 @@
 // lanes: ~14 cache lines per gather instruction).  An inspector (create time, one wave per tile) describes the
 // columns a tile references as up to 4 disjoint intervals (a stencil tile: the 3 planes it touches) of at
 // most kStreamXWin entries in total; the kernel then copies those intervals into LDS with coalesced loads
-// and gathers from LDS.  A tile without such a description (columns all over x) gathers from L2 as before,
-// and a tile with more entries than the LDS product stage holds is folded straight from global memory:
-// correct for any matrix, the tables only change speed.
+// and gathers from LDS.  A tile without such a description (columns all over x) gathers from L2 as before.
+//
+// ANY ROW LENGTH.  A tile with more entries than the LDS product stage holds (4096) is taken in several passes
+// over the stage; a row that straddles passes carries its accumulator, so the adds stay in storage order:
+// K1s is correct AND bit-exact for every matrix, the tables and the tile height only change speed.
 #include "internal.hpp"
 
 namespace smh {
@@ -135,7 +137,10 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // RPT = rows per thread: a tile is RPT*256 consecutive rows (2 when every 512-row tile fits the LDS stage)
 // DOT: also leave dot_partials[tile] = sum over the tile's rows of x[row] * y[row] (square matrices): the
 // p.Ap of a CG iteration falls out of the SpMV epilogue, in a fixed order (bitwise reproducible).
-template <typename T, bool XWIN, int RPT, bool DOT>
+// ACC: y += A x (the column-blocked variant K2c accumulates one column block per launch).
+// MULTI: tiles may hold more entries than the LDS stage (pass loop).  MULTI = false is the host's promise that no
+// tile does; the body is then loop-free and needs 70 instead of 90 VGPRs (f32: 7 instead of 5 waves per SIMD).
+template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
@@ -160,12 +165,12 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     T sum[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) sum[rr] = T(0);
-    if (k1 - k0 <= (uint32_t)kStreamCap) {
-        // interval k of the window sits at s_x[b_k ..), b_k = total length of the intervals before it;
-        // a column c of interval k is at s_x[c - sh_k] with sh_k = lo_k - b_k
-        uint32_t lo1 = 0xFFFFFFFFu, lo2 = 0xFFFFFFFFu, lo3 = 0xFFFFFFFFu, sh0 = 0, sh1 = 0, sh2 = 0, sh3 = 0;
-        bool windowed = false;
-        if constexpr (XWIN) {
+    // interval k of the window sits at s_x[b_k ..), b_k = total length of the intervals before it;
+    // a column c of interval k is at s_x[c - sh_k] with sh_k = lo_k - b_k
+    uint32_t lo1 = 0xFFFFFFFFu, lo2 = 0xFFFFFFFFu, lo3 = 0xFFFFFFFFu, sh0 = 0, sh1 = 0, sh2 = 0, sh3 = 0;
+    bool windowed = false;
+    if constexpr (XWIN) {
+        if (k1 - k0 <= (uint32_t)kStreamCap) {  // the inspector describes single-pass tiles only
             const uint32_t *w = win + 8 * tile;  // tile-uniform: scalar loads
             const uint32_t a0 = w[0], e0 = w[1], a1 = w[2], e1 = w[3], a2 = w[4], e2 = w[5], a3 = w[6], e3 = w[7];
             windowed = e0 > a0;
@@ -182,35 +187,47 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
                 __syncthreads();
             }
         }
-        // dense run of aligned chunks; the arrays' last partial chunk is read entry by entry when the
-        // arrays are not padded (nnz_readable = nnz rounded up for padded arrays)
-        // A tile holds <= kStreamCap entries = at most NIT chunks per thread: ALL of a thread's chunk loads are
-        // issued before the first gather (they sit in the memory queue together), then all gathers.
-        constexpr int NIT = kStreamCap / (4 * kBlock) + 1;
-        uint32_t c[NIT][4];
-        T v[NIT][4];
-        const uint64_t kbase = (uint64_t)(k0 & ~3u) + 4u * tid;
+    }
+    // The tile's entries [k0, k1) are taken in passes of <= kStreamCap entries (stencil/FEM tiles: one pass).  Per
+    // pass: a dense run of aligned chunks (the arrays' last partial chunk is read entry by entry when the arrays
+    // are not padded; nnz_readable = nnz rounded up for padded arrays).  A pass holds at most NIT chunks per
+    // thread: ALL of a thread's chunk loads are issued before the first gather (they sit in the memory queue
+    // together), then all gathers.  A row that straddles passes keeps its accumulator: the order of the adds is
+    // the storage order whatever the number of passes.
+    constexpr int NIT = kStreamCap / (4 * kBlock) + 1;
+    uint32_t ps = k0;
+    do {
+        const uint32_t pe = MULTI && k1 - ps > (uint32_t)kStreamCap ? ps + (uint32_t)kStreamCap : k1;
+        // everything per lane is a 32-bit position relative to the pass's aligned start `pa` (tile-uniform)
+        const uint64_t pa = (uint64_t)(ps & ~3u);
+        const uint32_t *__restrict__ colp = col + pa;
+        const T *__restrict__ valp = val + pa;
+        const uint32_t lo = ps & 3u, hi = pe - (uint32_t)pa;
+        const uint64_t rd64 = nnz_readable - pa, nn64 = nnz - pa;
+        const uint32_t rd = rd64 > 0x10000u ? 0x10000u : (uint32_t)rd64, nn = nn64 > 0x10000u ? 0x10000u : (uint32_t)nn64;
+        uint32_t c[NIT][4] = {};  // (initialised: no values carried around the pass loop)
+        T v[NIT][4] = {};
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const uint64_t k = kbase + (uint64_t)it * (4u * kBlock);
-            if (k < k1) {
-                if (k + 4 <= nnz_readable) {
-                    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(col + k));
+            const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
+            if (j < hi) {
+                if (j + 4 <= rd) {
+                    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(colp + j));
                     c[it][0] = cc.x; c[it][1] = cc.y; c[it][2] = cc.z; c[it][3] = cc.w;
                     if constexpr (sizeof(T) == 4) {
-                        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(val + k));
+                        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(valp + j));
                         v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
                     } else {
-                        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k));
-                        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k + 2));
+                        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(valp + j));
+                        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(valp + j + 2));
                         v[it][0] = a.x; v[it][1] = a.y; v[it][2] = b.x; v[it][3] = b.y;
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const bool in = k + e < nnz;
-                        c[it][e] = in ? col[k + e] : 0u;
-                        v[it][e] = in ? val[k + e] : T(0);
+                        const bool in = j + e < nn;
+                        c[it][e] = in ? colp[j + e] : 0u;
+                        v[it][e] = in ? valp[j + e] : T(0);
                     }
                 }
             }
@@ -218,12 +235,12 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         T xv[NIT][4];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const uint64_t k = kbase + (uint64_t)it * (4u * kBlock);
+            const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint64_t i = k + e;
+                const uint32_t i = j + e;
                 xv[it][e] = T(0);
-                if (i >= k0 && i < k1) {
+                if (i >= lo && i < hi) {
                     if (XWIN && windowed) {
                         const uint32_t cc = c[it][e];
                         const uint32_t sh = cc >= lo3 ? sh3 : (cc >= lo2 ? sh2 : (cc >= lo1 ? sh1 : sh0));
@@ -236,20 +253,20 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const uint64_t k = kbase + (uint64_t)it * (4u * kBlock);
+            const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint64_t i = k + e;
-                if (i >= k0 && i < k1) s_prod[skew((uint32_t)(i - k0))] = st_mul(xv[it][e], v[it][e]);
+                const uint32_t i = j + e;
+                if (i >= lo && i < hi) s_prod[skew(i - lo)] = st_mul(xv[it][e], v[it][e]);
             }
         }
         __syncthreads();
         // each row: storage order, one rounded add per entry (reference: sum += product)
 #pragma unroll
         for (int rr = 0; rr < RPT; ++rr) {
-            uint32_t i = o0[rr] - k0;
-            const uint32_t iend = o1[rr] - k0;
-            T acc = T(0);
+            uint32_t i = min(max(o0[rr], ps), pe) - ps;
+            const uint32_t iend = min(max(o1[rr], ps), pe) - ps;
+            T acc = sum[rr];
             for (; i + 4 <= iend; i += 4) {
                 const T p0 = s_prod[skew(i)], p1 = s_prod[skew(i + 1)], p2 = s_prod[skew(i + 2)], p3 = s_prod[skew(i + 3)];
                 acc = st_add(acc, p0);
@@ -260,19 +277,13 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             for (; i < iend; ++i) acc = st_add(acc, s_prod[skew(i)]);
             sum[rr] = acc;
         }
-    } else {
-        // oversize tile: fold from global memory (same order, same roundings)
-#pragma unroll
-        for (int rr = 0; rr < RPT; ++rr) {
-            T acc = T(0);
-            for (uint64_t k = o0[rr]; k < o1[rr]; ++k) acc = st_add(acc, st_mul(x[col[k]], val[k]));
-            sum[rr] = acc;
-        }
-    }
+        ps = pe;
+        if (MULTI && ps < k1) __syncthreads();  // the next pass overwrites the stage
+    } while (MULTI && ps < k1);
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
-        if (r < r1) y[r] = sum[rr];
+        if (r < r1) y[r] = ACC ? st_add(y[r], sum[rr]) : sum[rr];
     }
     if constexpr (DOT) {
         __shared__ T s_red[kBlock / kWave];
@@ -295,25 +306,72 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     }
 }
 
+// single_pass: the caller knows that no tile holds more than kStreamCap entries (statistic taken at create time)
 template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
-                           size_t nnz, bool padded, const uint32_t *win, int rpt, T *dot_partials, hipStream_t s) {
+                           size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
+                           hipStream_t s) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
-#define SMH_ST_LAUNCH(XW, R, D)                                                                                        \
-    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, (uint64_t)nnz, \
-                       readable, n_tiles, win, dot_partials)
-    if (win) {  // the window table describes 256-row tiles
-        if (dot_partials) SMH_ST_LAUNCH(true, 1, true); else SMH_ST_LAUNCH(true, 1, false);
-    } else if (rpt == 2) {
-        if (dot_partials) SMH_ST_LAUNCH(false, 2, true); else SMH_ST_LAUNCH(false, 2, false);
-    } else {
-        if (dot_partials) SMH_ST_LAUNCH(false, 1, true); else SMH_ST_LAUNCH(false, 1, false);
-    }
+#define SMH_ST_LAUNCH(XW, R, D, M)                                                                                       \
+    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
+                       (uint64_t)nnz, readable, n_tiles, win, dot_partials)
+#define SMH_ST_PICK(XW, R)                                                        \
+    do {                                                                          \
+        if (single_pass) {                                                        \
+            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, false); else SMH_ST_LAUNCH(XW, R, false, false); \
+        } else {                                                                  \
+            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, true); else SMH_ST_LAUNCH(XW, R, false, true);   \
+        }                                                                         \
+    } while (0)
+    if (win) SMH_ST_PICK(true, 1);  // the window table describes 256-row tiles
+    else if (rpt == 2) SMH_ST_PICK(false, 2);
+    else SMH_ST_PICK(false, 1);
+#undef SMH_ST_PICK
 #undef SMH_ST_LAUNCH
     SMH_HIP(hipGetLastError());
     return SMH_OK;
+}
+
+// K2c building block: one column block of the column-blocked copy, y (+)= A_b x.  `off` holds ABSOLUTE entry
+// positions into col/val (the blocks share one pair of arrays, padded to a multiple of 4 entries).
+template <typename T>
+static int launch_stream_block_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
+                                 size_t nnz_total, int rpt, bool single_pass, bool acc, hipStream_t s) {
+    const size_t rows = (size_t)kStreamRows * rpt;
+    const uint64_t n_tiles = (n_rows + rows - 1) / rows;
+    const uint64_t readable = (nnz_total + 3) & ~uint64_t(3);
+    const dim3 grid((unsigned)n_tiles), block(kBlock);
+#define SMH_SB_LAUNCH(R, A, M)                                                                                          \
+    hipLaunchKernelGGL((k_spmv_stream<T, false, R, false, A, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
+                       (uint64_t)nnz_total, readable, n_tiles, (const uint32_t *)nullptr, (T *)nullptr)
+#define SMH_SB_PICK(R)                                                                       \
+    do {                                                                                     \
+        if (single_pass) { if (acc) SMH_SB_LAUNCH(R, true, false); else SMH_SB_LAUNCH(R, false, false); } \
+        else             { if (acc) SMH_SB_LAUNCH(R, true, true);  else SMH_SB_LAUNCH(R, false, true);  } \
+    } while (0)
+    switch (rpt) {
+        case 1: SMH_SB_PICK(1); break;
+        case 2: SMH_SB_PICK(2); break;
+        case 4: SMH_SB_PICK(4); break;
+        case 8: SMH_SB_PICK(8); break;
+        default: return fail(SMH_ERR_INVALID, "K2c: rows per thread must be 1, 2, 4 or 8");
+    }
+#undef SMH_SB_PICK
+#undef SMH_SB_LAUNCH
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+int launch_spmv_stream_block(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
+                             size_t n_rows, size_t nnz_total, int rpt, bool single_pass, bool acc, hipStream_t s) {
+    if (n_rows == 0) return SMH_OK;
+    if (dtype == SMH_F64)
+        return launch_stream_block_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz_total,
+                                             rpt, single_pass, acc, s);
+    return launch_stream_block_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz_total, rpt,
+                                        single_pass, acc, s);
 }
 
 // tiles (= blocks = dot partials) of a K1s launch
@@ -323,14 +381,14 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 }
 
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
-                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, void *dot_partials,
-                       hipStream_t s) {
+                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
+                       void *dot_partials, hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
     if (dtype == SMH_F64)
         return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
-                                       rpt, (double *)dot_partials, s);
+                                       rpt, single_pass, (double *)dot_partials, s);
     return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
-                                  (float *)dot_partials, s);
+                                  single_pass, (float *)dot_partials, s);
 }
 
 int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,

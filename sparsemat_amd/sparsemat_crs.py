@@ -106,7 +106,27 @@ class SparseMatCRS:
     def resolved_variant(self):
         v, lanes = C.c_int(), C.c_int()
         check(lib().smh_crs_resolved_variant(self._h, C.byref(v), C.byref(lanes)))
-        return {1: "vector", 2: "merge", 3: "seq", 4: "stream"}[v.value], lanes.value
+        return {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock"}[v.value], lanes.value
+
+    def set_colblock_shift(self, shift):
+        """K2c: column blocks of 2**shift columns (0: automatic, 2 MiB of x)."""
+        check(lib().smh_crs_set_colblock_shift(self._h, shift))
+
+    def colblock(self, arrays=True):
+        """K2c column-blocked copy: dict(shift, n_blocks, rows_per_thread, span_fraction[, offsets[B, n_rows+1],
+        columns, values])."""
+        sh, nb, rpt, span = C.c_uint32(), C.c_size_t(), C.c_int(), C.c_double()
+        check(lib().smh_crs_colblock(self._h, C.byref(sh), C.byref(nb), C.byref(rpt), C.byref(span), None, None, None))
+        out = dict(shift=sh.value, n_blocks=nb.value, rows_per_thread=rpt.value, span_fraction=span.value)
+        if arrays:
+            nnz = self.n_non_zero_entries()
+            off = np.zeros((nb.value, self.n_rows() + 1), dtype=np.uint32)
+            col = np.zeros(nnz, dtype=np.uint32)
+            val = np.zeros(nnz, dtype=self._dtype)
+            check(lib().smh_crs_colblock(self._h, None, None, None, None, off.ctypes.data,
+                                         col.ctypes.data if nnz else None, val.ctypes.data if nnz else None))
+            out.update(offsets=off, columns=col, values=val)
+        return out
 
     def set_vector_lanes(self, lanes):
         check(lib().smh_crs_set_vector_lanes(self._h, lanes))

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--cases", default="banded,diag,uniform,powerlaw")
     ap.add_argument("--lanes", default="4,8,16")
+    ap.add_argument("--cb-shifts", default="", help="K2c column-block widths to time (log2 columns), e.g. 18,19,20")
     args = ap.parse_args()
     torch.cuda.init()
     n = args.rows
@@ -89,6 +90,16 @@ def main():
             med, mn = time_variant(m, xptr, nr, ybuf.ptr, "stream", reps=8 if case != "lap512" and not case.startswith("lap") else 20)
             report(tag + " win=%.2f" % m.stream_windows()[0] if mode else tag, B, med, mn)
         m.set_stream_windows(-1)
+        for shift in [int(v) for v in args.cb_shifts.split(",") if v]:
+            m.set_colblock_shift(shift)
+            try:
+                cb = m.colblock(arrays=False)
+            except sm.SparseMatPanic as e:  # more than 128 column blocks
+                print("  colblock 2^%d: %s" % (shift, e), flush=True)
+                continue
+            med, mn = time_variant(m, xptr, nr, ybuf.ptr, "colblock", reps=8)
+            report("colblock 2^%d x%d rpt%d" % (cb["shift"], cb["n_blocks"], cb["rows_per_thread"]), B, med, mn)
+        m.set_colblock_shift(0)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "auto")
         report("auto", B, med, mn)
         del m, xbuf, ybuf
