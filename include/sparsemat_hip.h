@@ -59,8 +59,8 @@ typedef enum {
                          /* reference loop sparsematrix.rs:146-158 (checker, not fast)      */
     SMH_SPMV_STREAM = 4, /* K1s: short rows; dense entry stream, rounded products in LDS,   */
                          /* one thread folds a row in storage order: fast AND bit-exact     */
-    SMH_SPMV_COLBLOCK = 5 /* K2c: columns without locality and x larger than the L2s: the    */
-                         /* device copy is split into 2-MiB column blocks of x, y += A_b x  */
+    SMH_SPMV_COLBLOCK = 5 /* K2c: columns without locality and x larger than an L2: the      */
+                         /* device copy is split into blocks of 2^19 columns, y += A_b x    */
 } smh_spmv_variant;
 
 typedef struct smh_crs smh_crs; /* device-resident SparseMatCRS<T,u32>  (sparsemat_crs.rs:9-17) */
@@ -135,8 +135,9 @@ int smh_crs_ring_plan(smh_crs *m, uint32_t *n_blocks_out, size_t *n_phases_out,
  * offsets_out[b*(n_rows+1) + r] are absolute positions into columns_out / values_out [nnz]; inside a
  * (row, block) pair the entries keep their storage order.  Call with NULL arrays for the sizes.
  * span_fraction_out (may be NULL): mean column span of a 64-row tile / n_cols, the locality
- * statistic AUTO uses (COLBLOCK when it exceeds 0.25 and x is larger than 8 MiB).              */
-int smh_crs_set_colblock_shift(smh_crs *m, uint32_t shift); /* block = 2^shift columns; 0 = 2 MiB of x */
+ * statistic AUTO uses (COLBLOCK when it exceeds 0.25 and x holds at least 4 MiB).  More than 128
+ * blocks (n_cols > 2^26 at the default width) is SMH_ERR_INVALID.                              */
+int smh_crs_set_colblock_shift(smh_crs *m, uint32_t shift); /* block = 2^shift columns; 0 = automatic (19) */
 int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int *rows_per_thread_out,
                      double *span_fraction_out, uint32_t *offsets_out, uint32_t *columns_out,
                      void *values_out);
