@@ -89,6 +89,24 @@ int smh_crs_create(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz,
 int smh_crs_create_dev(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz,
                        const uint32_t *offset_rows_dev, const uint32_t *columns_dev,
                        const void *values_dev, int validate, smh_crs **out);
+/* ---- assembly on the device ----------------------------------------
+ * smh_crs_assemble: replaces a stream of n_ops calls `mat.add_to(rows[k], cols[k], values[k])`
+ * (ops == NULL or ops[k] == 0; sparsematrix.rs:231-233) / `mat.set(...)` (ops[k] == 1; :226-228)
+ * on a SparseMatIndexList (get_mut sparsemat_indexlist.rs:158-164, push :45-53 over
+ * indexlist.rs:62-83) followed by `to_crs()` (sparsemat_indexlist.rs:61-63 ->
+ * sparsemat_crs.rs:24-50), with the identical result: n_rows = largest row + 1, n_cols =
+ * largest column + 1, one entry per distinct (row, column) in order of first appearance
+ * inside its row, value = left fold of the entry's operations in stream order from zero.
+ * Bit-exact, including the values.  n_ops == 0 gives the empty matrix (no rows);
+ * n_ops >= u32::MAX is SMH_ERR_CAPACITY (indexlist.rs:69).  The _dev form takes device arrays. */
+int smh_crs_assemble(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols,
+                     const void *values, const uint8_t *ops, smh_crs **out);
+int smh_crs_assemble_dev(smh_dtype dtype, size_t n_ops, const uint32_t *rows_dev,
+                         const uint32_t *cols_dev, const void *values_dev, const uint8_t *ops_dev,
+                         smh_crs **out);
+/* Sortable::sort_row (sparsemat_crs.rs:163-172) for every row: ascending columns, stable
+ * (duplicates of a column keep their storage order).  Sorts the handle's arrays in place. */
+int smh_crs_sort_rows(smh_crs *m);
 int smh_crs_destroy(smh_crs *m);
 /* host mutated values: re-upload.  values_host == NULL: the device values (borrowed arrays of
  * smh_crs_create_dev) were changed in place -- derived copies (K2c) are rebuilt on next use */

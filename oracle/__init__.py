@@ -97,6 +97,10 @@ def _declare(L):
         getattr(L, "orc_laplace2d_" + suf).restype = _sz
         getattr(L, "orc_laplace3d_" + suf).argtypes = [_sz, _sz, _sz, _u32p, _u32p, fp]
         getattr(L, "orc_laplace3d_" + suf).restype = _sz
+        getattr(L, "orc_assemble_" + suf).argtypes = [_sz, _u32p, _u32p, fp, C.POINTER(C.c_uint8), C.POINTER(_sz),
+                                                       C.POINTER(_sz), C.POINTER(_sz), _u32p, _u32p, fp]
+        getattr(L, "orc_crs_sort_rows_" + suf).argtypes = [_sz, _u32p, _u32p, fp]
+        getattr(L, "orc_crs_sort_rows_" + suf).restype = None
     L.orc_par_rows_per_block.argtypes = [_sz, _sz]
     L.orc_par_rows_per_block.restype = _sz
     L.orc_par_block_and_row.argtypes = [_sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]
@@ -349,3 +353,35 @@ def merge_path_search(offset_rows, nnz, diagonals):
     lib().orc_merge_path_search(len(off) - 1, nnz, _p(off, _u32p), len(d), _p(d, _u64p), _p(rows, _u32p),
                                 _p(nz, _u32p))
     return rows, nz
+
+
+def assemble(rows, cols, vals, ops=None):
+    """add_to / set stream on a SparseMatIndexList followed by to_crs() (sparsemat_indexlist.rs:61-63,158-164;
+    sparsemat_crs.rs:24-50).  ops[k]: 0 add_to, 1 set (None: all add_to).
+    Returns (n_rows, n_cols, offset_rows, columns, values)."""
+    vals = np.ascontiguousarray(vals)
+    suf, fp = _suf(vals.dtype)
+    rows, cols = _c(rows, np.uint32), _c(cols, np.uint32)
+    n = len(vals)
+    assert len(rows) == n and len(cols) == n
+    ops_a = None if ops is None else _c(ops, np.uint8)
+    max_rows = int(rows.max()) + 1 if n else 0
+    off = np.zeros(max_rows + 1, np.uint32)
+    col = np.zeros(max(n, 1), np.uint32)
+    val = np.zeros(max(n, 1), vals.dtype)
+    nr, nc, nnz = _sz(), _sz(), _sz()
+    _check(getattr(lib(), "orc_assemble_" + suf)(
+        n, _p(rows, _u32p), _p(cols, _u32p), _p(vals, fp),
+        None if ops_a is None else ops_a.ctypes.data_as(C.POINTER(C.c_uint8)),
+        C.byref(nr), C.byref(nc), C.byref(nnz), _p(off, _u32p), _p(col, _u32p), _p(val, fp)))
+    return nr.value, nc.value, off[:nr.value + 1].copy(), col[:nnz.value].copy(), val[:nnz.value].copy()
+
+
+def crs_sort_rows(offset_rows, columns, values):
+    """Sortable::sort_row (sparsemat_crs.rs:163-172) on every row; returns sorted copies (stable by column)."""
+    values = np.array(values, copy=True)
+    suf, fp = _suf(values.dtype)
+    off = _c(offset_rows, np.uint32)
+    col = np.array(columns, dtype=np.uint32, copy=True)
+    getattr(lib(), "orc_crs_sort_rows_" + suf)(len(off) - 1, _p(off, _u32p), _p(col, _u32p), _p(values, fp))
+    return col, values

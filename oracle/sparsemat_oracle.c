@@ -372,3 +372,102 @@ void orc_merge_path_search(size_t n_rows, size_t nnz, const uint32_t *offset_row
         nnz_out[t] = (uint32_t)(d - lo);
     }
 }
+
+/* ======================================================================= *
+ * Assembly: a stream of add_to / set calls on a SparseMatIndexList, then
+ * to_crs().  Follows the reference's containers step by step:
+ *   get_mut(i,j)  sparsemat_indexlist.rs:158-164: find_index, else push(i,j,0)
+ *   find_index    sparsemat_indexlist.rs:29-42: walk the row's list, first match
+ *   push          sparsemat_indexlist.rs:45-53 + IndexList::push indexlist.rs:62-83
+ *                 (pos_start grows to row+1, the new entry is appended to the
+ *                 END of the row's list; n_cols = max(n_cols, j+1))
+ *   add_to / set  sparsematrix.rs:231-233 / :226-228 (`+=` / `=` on the entry)
+ *   to_crs        sparsemat_indexlist.rs:61-63 -> sparsemat_crs.rs:24-50: rows
+ *                 0..n_rows, each row in list (= first-insertion) order; an
+ *                 index list without entries gives SparseMatCRS::new() (no rows).
+ * The reference walks to the tail of the row's list on every push
+ * (indexlist.rs:73-79); a per-row tail pointer gives the same list.
+ * ops[k]: 0 = add_to, 1 = set (NULL: all add_to).  Outputs: offset_rows needs
+ * max(row)+2 entries, columns/values n entries.  Returns ORC_OK.
+ * ======================================================================= */
+#define ORC_UNSET 0xFFFFFFFFu
+#define DEF_ASSEMBLE(SUF, T)                                                                        \
+    int orc_assemble_##SUF(size_t n, const uint32_t *rows, const uint32_t *cols, const T *vals,     \
+                           const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out,              \
+                           size_t *nnz_out, uint32_t *offset_rows, uint32_t *columns, T *values) {  \
+        size_t n_rows = 0, n_cols = 0, n_entries = 0;                                               \
+        for (size_t k = 0; k < n; ++k)                                                              \
+            if ((size_t)rows[k] + 1 > n_rows) n_rows = (size_t)rows[k] + 1;                         \
+        uint32_t *pos_start = (uint32_t *)malloc((n_rows + 1) * sizeof(uint32_t));                 \
+        uint32_t *tail = (uint32_t *)malloc((n_rows + 1) * sizeof(uint32_t));                       \
+        uint32_t *next = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));                            \
+        uint32_t *ecol = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));                            \
+        T *eval = (T *)malloc((n + 1) * sizeof(T));                                                 \
+        if (!pos_start || !tail || !next || !ecol || !eval) {                                       \
+            free(pos_start); free(tail); free(next); free(ecol); free(eval);                        \
+            return ORC_ERR_SIZE_MISMATCH;                                                           \
+        }                                                                                           \
+        for (size_t r = 0; r < n_rows; ++r) pos_start[r] = ORC_UNSET;                               \
+        for (size_t k = 0; k < n; ++k) {                                                            \
+            const uint32_t i = rows[k], j = cols[k];                                                \
+            uint32_t index = ORC_UNSET;                                                             \
+            for (uint32_t it = pos_start[i]; it != ORC_UNSET; it = next[it])                        \
+                if (ecol[it] == j) { index = it; break; }                                           \
+            if (index == ORC_UNSET) { /* push(i, j, T::zero()) */                                   \
+                if ((size_t)j + 1 > n_cols) n_cols = (size_t)j + 1;                                 \
+                index = (uint32_t)n_entries++;                                                      \
+                next[index] = ORC_UNSET;                                                            \
+                if (pos_start[i] == ORC_UNSET) pos_start[i] = index; else next[tail[i]] = index;    \
+                tail[i] = index;                                                                    \
+                ecol[index] = j;                                                                    \
+                eval[index] = (T)0;                                                                 \
+            }                                                                                       \
+            if (ops && ops[k]) eval[index] = vals[k]; else eval[index] = eval[index] + vals[k];     \
+        }                                                                                           \
+        size_t nnz = 0;                                                                             \
+        if (n_entries > 0) {                                                                        \
+            for (size_t r = 0; r < n_rows; ++r) {                                                   \
+                offset_rows[r] = (uint32_t)nnz;                                                     \
+                for (uint32_t it = pos_start[r]; it != ORC_UNSET; it = next[it]) {                  \
+                    columns[nnz] = ecol[it];                                                        \
+                    values[nnz] = eval[it];                                                         \
+                    ++nnz;                                                                          \
+                }                                                                                   \
+            }                                                                                       \
+            offset_rows[n_rows] = (uint32_t)nnz;                                                    \
+        } else {                                                                                    \
+            n_rows = 0;                                                                             \
+        }                                                                                           \
+        *n_rows_out = n_rows; *n_cols_out = n_cols; *nnz_out = nnz;                                 \
+        free(pos_start); free(tail); free(next); free(ecol); free(eval);                            \
+        return ORC_OK;                                                                              \
+    }
+
+DEF_ASSEMBLE(f32, float)
+DEF_ASSEMBLE(f64, double)
+
+/* Sortable::sort_row (sparsemat_crs.rs:163-172) applied to every row: the row's (column, value) pairs are
+ * sorted by column with slice::sort_by, a STABLE sort -- duplicates of a column keep their storage order.
+ * Insertion sort is stable and rows are short. */
+#define DEF_SORT_ROWS(SUF, T)                                                                       \
+    void orc_crs_sort_rows_##SUF(size_t n_rows, const uint32_t *offset_rows, uint32_t *columns,     \
+                                 T *values) {                                                       \
+        for (size_t r = 0; r < n_rows; ++r) {                                                       \
+            const size_t a = offset_rows[r], b = offset_rows[r + 1];                                \
+            for (size_t k = a + 1; k < b; ++k) {                                                    \
+                const uint32_t c = columns[k];                                                      \
+                const T v = values[k];                                                              \
+                size_t p = k;                                                                       \
+                while (p > a && columns[p - 1] > c) {                                               \
+                    columns[p] = columns[p - 1];                                                    \
+                    values[p] = values[p - 1];                                                      \
+                    --p;                                                                            \
+                }                                                                                   \
+                columns[p] = c;                                                                     \
+                values[p] = v;                                                                      \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+DEF_SORT_ROWS(f32, float)
+DEF_SORT_ROWS(f64, double)

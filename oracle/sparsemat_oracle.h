@@ -124,6 +124,20 @@ size_t orc_laplace3d_f32(size_t nx, size_t ny, size_t nz, uint32_t *offset_rows,
 size_t orc_laplace2d_f64(size_t nx, size_t ny, uint32_t *offset_rows, uint32_t *columns, double *values);
 size_t orc_laplace3d_f64(size_t nx, size_t ny, size_t nz, uint32_t *offset_rows, uint32_t *columns, double *values);
 
+/* ---- assembly: add_to/set stream on a SparseMatIndexList, then to_crs() ----
+ * sparsemat_indexlist.rs:29-53,61-63,158-164; indexlist.rs:62-83; sparsematrix.rs:226-233;
+ * sparsemat_crs.rs:24-50.  ops[k] 0 = add_to, 1 = set (NULL: all add_to).  offset_rows needs
+ * max(row)+2 entries, columns / values n entries. */
+int orc_assemble_f32(size_t n, const uint32_t *rows, const uint32_t *cols, const float *vals,
+                     const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
+                     uint32_t *offset_rows, uint32_t *columns, float *values);
+int orc_assemble_f64(size_t n, const uint32_t *rows, const uint32_t *cols, const double *vals,
+                     const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
+                     uint32_t *offset_rows, uint32_t *columns, double *values);
+/* Sortable::sort_row (sparsemat_crs.rs:163-172) on every row: stable by column */
+void orc_crs_sort_rows_f32(size_t n_rows, const uint32_t *offset_rows, uint32_t *columns, float *values);
+void orc_crs_sort_rows_f64(size_t n_rows, const uint32_t *offset_rows, uint32_t *columns, double *values);
+
 /* ---- merge-path coordinates (restates the build's own search) ---- */
 /* For diagonal d over (row_end_offsets = offset_rows+1 [n_rows]) x (0..nnz):
  * returns the row coordinate; the nnz coordinate is d - row. */

@@ -534,6 +534,72 @@ int smh_crs_create_dev(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz
     return SMH_OK;
 }
 
+// add_to / set stream -> CRS (assemble.hip).  `on_device`: the arrays are device pointers.
+static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols, const void *values,
+                           const uint8_t *ops, bool on_device, smh_crs **out) {
+    if (!out) return fail(SMH_ERR_INVALID, "NULL out pointer");
+    if (dtype != SMH_F32 && dtype != SMH_F64) return fail(SMH_ERR_INVALID, "unknown dtype %d", (int)dtype);
+    if (n_ops && (!rows || !cols || !values)) return fail(SMH_ERR_INVALID, "NULL operation array");
+    if (n_ops >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "Maximum number of %u entries reached", 0xFFFFFFFFu);
+    SMH_TRY(require_device());
+    smh_crs *m = new (std::nothrow) smh_crs();
+    if (!m) return fail(SMH_ERR_OOM, "host allocation failed");
+    m->dtype = dtype; m->owns = true;
+    m->device = current_device();
+    const size_t vs = dtype_size(dtype);
+    void *d_in[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto go = [&]() -> int {
+        if (n_ops == 0) {  // SparseMatCRS::new() (sparsemat_crs.rs:47-49): no rows at all
+            SMH_HIP(hipMalloc((void **)&m->d_off, sizeof(uint32_t)));
+            SMH_HIP(hipMemset(m->d_off, 0, sizeof(uint32_t)));
+            SMH_HIP(hipMalloc((void **)&m->d_col, 4 * sizeof(uint32_t)));
+            SMH_HIP(hipMalloc(&m->d_val, 4 * vs));
+            return finish_create(m, 0);
+        }
+        const uint32_t *d_rows = rows, *d_cols = cols;
+        const void *d_vals = values;
+        const uint8_t *d_ops = ops;
+        if (!on_device) {
+            SMH_HIP(hipMalloc(&d_in[0], n_ops * sizeof(uint32_t)));
+            SMH_HIP(hipMalloc(&d_in[1], n_ops * sizeof(uint32_t)));
+            SMH_HIP(hipMalloc(&d_in[2], n_ops * vs));
+            SMH_HIP(hipMemcpy(d_in[0], rows, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice));
+            SMH_HIP(hipMemcpy(d_in[1], cols, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice));
+            SMH_HIP(hipMemcpy(d_in[2], values, n_ops * vs, hipMemcpyHostToDevice));
+            if (ops) {
+                SMH_HIP(hipMalloc(&d_in[3], n_ops));
+                SMH_HIP(hipMemcpy(d_in[3], ops, n_ops, hipMemcpyHostToDevice));
+            }
+            d_rows = (const uint32_t *)d_in[0]; d_cols = (const uint32_t *)d_in[1]; d_vals = d_in[2]; d_ops = (const uint8_t *)d_in[3];
+        }
+        SMH_TRY(assemble_triplets(dtype, n_ops, d_rows, d_cols, d_vals, d_ops, &m->n_rows, &m->n_cols, &m->nnz, &m->d_off,
+                                  &m->d_col, &m->d_val, nullptr));
+        return finish_create(m, 0);
+    };
+    const int rc = go();
+    for (void *p : d_in) (void)hipFree(p);
+    if (rc != SMH_OK) { char keep[512]; strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0; smh_crs_destroy(m); strncpy(g_err, keep, sizeof g_err); return rc; }
+    *out = m;
+    return SMH_OK;
+}
+
+int smh_crs_assemble(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols, const void *values,
+                     const uint8_t *ops, smh_crs **out) {
+    return assemble_common(dtype, n_ops, rows, cols, values, ops, false, out);
+}
+
+int smh_crs_assemble_dev(smh_dtype dtype, size_t n_ops, const uint32_t *rows_dev, const uint32_t *cols_dev,
+                         const void *values_dev, const uint8_t *ops_dev, smh_crs **out) {
+    return assemble_common(dtype, n_ops, rows_dev, cols_dev, values_dev, ops_dev, true, out);
+}
+
+int smh_crs_sort_rows(smh_crs *m) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(sort_rows(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, m->stream));
+    drop_colblock(m);  // the blocked copy keeps storage order inside a (row, block) pair
+    return SMH_OK;
+}
+
 int smh_crs_destroy(smh_crs *m) {
     if (!m) return SMH_OK;
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }

@@ -110,7 +110,8 @@ static unsigned rows_grid(uint64_t n_rows) {
 }
 
 // in-place exclusive scan of `n` u32 on the device (chunk sums folded on the host: n/4096 values)
-int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s) {
+int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s, uint64_t *total_out) {
+    if (total_out) *total_out = 0;
     if (n == 0) return SMH_OK;
     const uint64_t chunks = (n + kScanChunk - 1) / kScanChunk;
     uint32_t *d_sums = nullptr;
@@ -129,6 +130,7 @@ int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s) {
             run += v;
         }
         if (run >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "Maximum number of %u entries reached", 0xFFFFFFFFu);
+        if (total_out) *total_out = run;
         SMH_HIP(hipMemcpyAsync(d_sums, h.data(), chunks * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)chunks), dim3(kBlock), 0, s, data, n, d_sums);
         SMH_HIP(hipGetLastError());
@@ -154,7 +156,7 @@ int build_colblock(int dtype, const uint32_t *off, const uint32_t *col, const vo
         SMH_HIP(hipMemsetAsync(off2, 0, total * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_cb_count, dim3(rows_grid(n_rows)), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, shift, off2);
         SMH_HIP(hipGetLastError());
-        SMH_TRY(device_exclusive_scan_u32(off2, total, s));
+        SMH_TRY(device_exclusive_scan_u32(off2, total, s, nullptr));
         SMH_HIP(hipMalloc((void **)&cur, total * sizeof(uint32_t)));
         SMH_HIP(hipMemcpyAsync(cur, off2, total * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         SMH_HIP(hipMalloc((void **)&col2, (nnz + 4) * sizeof(uint32_t)));

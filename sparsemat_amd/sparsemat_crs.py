@@ -53,6 +53,41 @@ class SparseMatCRS:
                                        C.byref(h)))
         return cls(h, dtype, keep)
 
+    @classmethod
+    def from_triplets(cls, rows, cols, values, ops=None):
+        """The CRS the reference ends up with after the call stream ``mat.add_to(rows[k], cols[k], values[k])``
+        (``ops[k] == 1``: ``mat.set(...)``) on a SparseMatIndexList and ``to_crs()``
+        (sparsemat_indexlist.rs:61-63,158-164; sparsemat_crs.rs:24-50) -- built on the device, bit-exact:
+        entries of a row in order of first appearance, duplicates folded in stream order."""
+        values = np.ascontiguousarray(values)
+        if values.dtype not in (np.float32, np.float64):
+            raise TypeError("the HIP path handles f32/f64 values only (got %s)" % values.dtype)
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        n = len(values)
+        if len(rows) != n or len(cols) != n:
+            raise _lib.SparseMatPanic(_lib.SMH_ERR_INVALID, "rows, cols and values differ in length")
+        ops_a = None if ops is None else np.ascontiguousarray(ops, dtype=np.uint8)
+        if ops_a is not None and len(ops_a) != n:
+            raise _lib.SparseMatPanic(_lib.SMH_ERR_INVALID, "ops and values differ in length")
+        h = C.c_void_p()
+        check(lib().smh_crs_assemble(_lib.dtype_code(values.dtype), n, rows.ctypes.data if n else None,
+                                     cols.ctypes.data if n else None, values.ctypes.data if n else None,
+                                     ops_a.ctypes.data if (ops_a is not None and n) else None, C.byref(h)))
+        return cls(h, values.dtype)
+
+    @classmethod
+    def from_device_triplets(cls, n_ops, rows_ptr, cols_ptr, vals_ptr, dtype, ops_ptr=None):
+        """``from_triplets`` over operation arrays that already live in HBM (raw device pointers)."""
+        h = C.c_void_p()
+        check(lib().smh_crs_assemble_dev(_lib.dtype_code(dtype), n_ops, C.c_void_p(rows_ptr), C.c_void_p(cols_ptr),
+                                         C.c_void_p(vals_ptr), C.c_void_p(ops_ptr or 0), C.byref(h)))
+        return cls(h, dtype)
+
+    def sort_rows(self):
+        """Sortable::sort_row (sparsemat_crs.rs:163-172) on every row: ascending columns, stable."""
+        check(lib().smh_crs_sort_rows(self._h))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

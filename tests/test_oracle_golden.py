@@ -81,6 +81,56 @@ def test_assembly_restatement_storage_order(case):
         assert len(val) / (n_rows * n_cols) == num / den
 
 
+def _ops_arrays(case, dt):
+    ops = case["ops"]
+    return ([o[1] for o in ops], [o[2] for o in ops], np.array([dt(float(o[3])) for o in ops], dtype=dt),
+            [1 if o[0] == "set" else 0 for o in ops])
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if "ops" in c and "SparseMatIndexList" in c["container"]
+                                  and "Par" not in c["container"]], ids=lambda c: c["name"])
+def test_c_assembly_oracle_reproduces_reference_crs(case):
+    """orc_assemble (the C restatement of the add_to/set stream + to_crs) against the CRS arrays the
+    reference's own tests pin (src/lib.rs:54-98, 36-52), bit for bit."""
+    dt = np.float32 if case["dtype"] == "f32" else np.float64
+    rows, cols, vals, ops = _ops_arrays(case, dt)
+    n_rows, n_cols, off, col, val = oracle.assemble(rows, cols, vals, ops)
+    crs = case["crs"]
+    assert (n_rows, n_cols) == (crs["n_rows"], crs["n_cols"])
+    assert list(off) == crs["offset_rows"] and list(col) == crs["columns"]
+    assert val.tobytes() == _values(case).tobytes()
+
+
+def test_c_assembly_oracle_matches_container_restatement():
+    """Random add_to/set streams: the C oracle equals the step-by-step Python container (IndexListMatrix),
+    incl. gaps (empty rows), -0.0 values and the empty stream; sort_rows equals a stable numpy sort."""
+    rng = np.random.default_rng(5)
+    for t in range(60):
+        dt = np.float32 if t % 2 else np.float64
+        n, n_r, n_c = int(rng.integers(0, 300)), int(rng.integers(1, 15)), int(rng.integers(1, 10))
+        rows, cols = rng.integers(0, n_r, n), rng.integers(0, n_c, n)
+        vals = rng.uniform(-1, 1, n).astype(dt)
+        vals[rng.random(n) < 0.1] = dt(-0.0)
+        ops = rng.integers(0, 2, n) if t % 3 else None
+        m = assembly.IndexListMatrix(dt)
+        for k in range(n):
+            (m.set if ops is not None and ops[k] else m.add_to)(int(rows[k]), int(cols[k]), vals[k])
+        n_rows, n_cols, off, col, val = oracle.assemble(rows, cols, vals, ops)
+        if n == 0:
+            assert (n_rows, n_cols, len(col)) == (0, 0, 0)
+            continue
+        e_rows, e_cols, e_off, e_col, e_val = m.to_crs_arrays()
+        assert (n_rows, n_cols) == (e_rows, e_cols)
+        assert np.array_equal(off, e_off) and np.array_equal(col, e_col)
+        assert val.tobytes() == e_val.tobytes()
+        s_col, s_val = oracle.crs_sort_rows(off, col, val)
+        for i in range(n_rows):
+            a, b = off[i], off[i + 1]
+            order = np.argsort(col[a:b], kind="stable")
+            assert np.array_equal(s_col[a:b], col[a:b][order])
+            assert s_val[a:b].tobytes() == val[a:b][order].tobytes()
+
+
 def test_oracle_cg_reproduces_reference_assert():
     """check_cg (src/lib.rs:36-52)."""
     case = [c for c in CASES if c["name"] == "check_cg"][0]
