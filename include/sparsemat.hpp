@@ -141,11 +141,61 @@ class SparseMatCRS {
     // `A * v` (sparsemat_ops! Mul<DenseVec>, sparsematrix.rs:435-443)
     friend DenseVec<T> operator*(const SparseMatCRS &a, const DenseVec<T> &v) { return a.mvp(v); }
 
+    // Sortable::sort_row (sparsemat_crs.rs:163-172) for every row: ascending columns, stable
+    void sort_rows() { detail::check(smh_crs_sort_rows(h_)); }
+    // the CRS arrays as stored (offset_rows, columns, values)
+    void raw_parts(std::vector<uint32_t> &offset_rows, std::vector<uint32_t> &columns, std::vector<T> &values) const {
+        offset_rows.assign(n_rows() + 1, 0u);
+        columns.assign(n_non_zero_entries(), 0u);
+        values.assign(n_non_zero_entries(), T(0));
+        detail::check(smh_crs_download(h_, offset_rows.data(), columns.data(), values.data()));
+    }
+
     smh_crs *handle() const { return h_; }
 
   private:
+    template <typename U> friend class SparseMatIndexList;
     SparseMatCRS() = default;
     smh_crs *h_ = nullptr;
+};
+
+// Assembly with the call surface of the reference's SparseMatIndexList (sparsemat_indexlist.rs): `add_to` /
+// `set` (sparsematrix.rs:231-233 / :226-228) are RECORDED (O(1) each, no list walk) and `to_crs()` (:61-63 ->
+// sparsemat_crs.rs:24-50) builds the identical CRS on the device with smh_crs_assemble: rows in order of first
+// appearance, duplicates folded in call order, bit for bit.
+template <typename T>
+class SparseMatIndexList {
+  public:
+    void add_to(size_t i, size_t j, T val) { record(i, j, val, 0); }
+    void set(size_t i, size_t j, T val) { record(i, j, val, 1); }
+    // SparseMatrix::get (sparsemat_indexlist.rs:148-155): value of (i, j), zero when absent.  Folds the
+    // recorded calls (O(calls)): meant for spot checks, as in the reference's tests.
+    T get(size_t i, size_t j) const {
+        T acc = T(0);
+        for (size_t k = 0; k < vals_.size(); ++k)
+            if (rows_[k] == i && cols_[k] == j) acc = ops_[k] ? vals_[k] : T(acc + vals_[k]);
+        return acc;
+    }
+    size_t n_rows() const { return n_rows_; }  // indexlist.rs:58-60
+    size_t n_cols() const { return n_cols_; }  // sparsemat_indexlist.rs:46-48
+    SparseMatCRS<T> to_crs() const {
+        SparseMatCRS<T> m;
+        detail::check(smh_crs_assemble(detail::dtype_of<T>::value, vals_.size(), rows_.data(), cols_.data(), vals_.data(),
+                                       ops_.data(), &m.h_));
+        return m;
+    }
+
+  private:
+    void record(size_t i, size_t j, T val, uint8_t op) {
+        if (i >= 0xFFFFFFFFull || j >= 0xFFFFFFFFull) throw Panic(SMH_ERR_CAPACITY, "index exceeds u32");
+        rows_.push_back((uint32_t)i); cols_.push_back((uint32_t)j); vals_.push_back(val); ops_.push_back(op);
+        if (i + 1 > n_rows_) n_rows_ = i + 1;
+        if (j + 1 > n_cols_) n_cols_ = j + 1;
+    }
+    std::vector<uint32_t> rows_, cols_;
+    std::vector<T> vals_;
+    std::vector<uint8_t> ops_;
+    size_t n_rows_ = 0, n_cols_ = 0;
 };
 
 // linearsolver.rs:12-61.  The reference keeps tol / iter_max private with only Default (1e-12, 10000);

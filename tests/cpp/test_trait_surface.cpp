@@ -37,6 +37,33 @@ int main() {
         auto y2 = a.mvp(std::vector<float>{2.0f, 4.8f, 1.2f});
         CHECK(std::fabs(y2[0] - 34.544f) <= 1e-5f * 34.544f);
     }
+    // check_sparsemat_indexlist (src/lib.rs:54-98), the call sequence itself: assembled on the device
+    {
+        SparseMatIndexList<float> sp;
+        sp.add_to(0, 1, 4.2f);
+        sp.add_to(1, 2, 4.12f);
+        sp.add_to(2, 2, 2.12f);
+        sp.add_to(1, 1, 1.12f);
+        sp.add_to(1, 1, 1.12f);
+        sp.add_to(0, 2, 0.12f);
+        sp.set(0, 0, 8.12f);
+        sp.set(0, 0, 7.12f);
+        CHECK(sp.get(0, 0) == 7.12f);        // assert_eq!(sp.get(0, 0), 7.12)
+        CHECK(sp.n_rows() == 3 && sp.n_cols() == 3);
+        auto a = sp.to_crs();
+        std::vector<uint32_t> off, col;
+        std::vector<float> val;
+        a.raw_parts(off, col, val);
+        CHECK((off == std::vector<uint32_t>{0, 3, 5, 6}));
+        CHECK((col == std::vector<uint32_t>{1, 2, 0, 2, 1, 2}));  // row 0 iterates (0,1),(0,2),(0,0): lib.rs:67-71
+        CHECK((val == std::vector<float>{4.2f, 0.12f, 7.12f, 4.12f, 2.24f, 2.12f}));
+        auto y = a.mvp(std::vector<float>{2.0f, 4.8f, 1.2f}, SMH_SPMV_STREAM);
+        CHECK(y[0] == 34.544f);              // assert_eq!(mvp.get(0), 34.544)
+        a.sort_rows();                       // sp.sort_row(i) for every row (lib.rs:94-98: "0 2.24 4.12 ")
+        a.raw_parts(off, col, val);
+        CHECK((col == std::vector<uint32_t>{0, 1, 2, 1, 2, 2}));
+        CHECK((val == std::vector<float>{7.12f, 4.2f, 0.12f, 2.24f, 4.12f, 2.12f}));
+    }
     // check_cg (src/lib.rs:36-52)
     {
         auto a = SparseMatCRS<double>::from_raw_parts(2, 2, {0, 2, 4}, {0, 1, 0, 1}, {4.0, 1.0, 1.0, 3.0});
