@@ -140,8 +140,18 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // ACC: y += A x (the column-blocked variant K2c accumulates one column block per launch).
 // MULTI: tiles may hold more entries than the LDS stage (pass loop).  MULTI = false is the host's promise that no
 // tile does; the body is then loop-free and needs 70 instead of 90 VGPRs (f32: 7 instead of 5 waves per SIMD).
+// A/B knob: waves per SIMD the register allocator must allow (0: no constraint).  Measured on the 512^3 Laplacian,
+// same box: unconstrained (68 VGPRs, 7 waves) 1.79 / 1.82 ms; 8 waves (64 VGPRs + 12 B/lane of scratch) 1.96 / 1.95 ms.
+#ifndef SMH_STREAM_MIN_WAVES
+#define SMH_STREAM_MIN_WAVES 0
+#endif
+#if SMH_STREAM_MIN_WAVES > 0
+#define SMH_STREAM_BOUNDS __launch_bounds__(kBlock, SMH_STREAM_MIN_WAVES)
+#else
+#define SMH_STREAM_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true>
-__global__ void __launch_bounds__(kBlock)
+__global__ void SMH_STREAM_BOUNDS
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
               uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials) {

@@ -90,3 +90,59 @@ def test_full_size_c2_properties(gpu):
     m.mvp_dev(x2.ptr, n, y2.ptr, "vector")
     sm.lib().smh_device_synchronize()
     assert np.array_equal(y2.download(np.float32, n), ys["vector"] * np.float32(2))
+
+
+def _run(m, xptr, n_x, variant, dtype):
+    ybuf = synth.DeviceBuffer(m.n_rows() * np.dtype(dtype).itemsize)
+    m.mvp_dev(xptr, n_x, ybuf.ptr, variant)
+    sm.lib().smh_device_synchronize()
+    return ybuf.download(dtype, m.n_rows())
+
+
+def test_full_size_c2_uniform_colblock_properties(gpu):
+    """C2 stress variant (10M rows x 32 uniform columns, f32) at full size: AUTO = column-blocked K2c; sampled row
+    blocks against the oracle (rows regenerated independently), the bit-exact K1s/SEQ pair agrees with it on the
+    samples bit for bit, K2c agrees with K1s on every row within the parity bound, linearity under x -> 2x."""
+    n, k = 10_000_000, 32
+    m = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_UNIFORM, n, k, np.float32)
+    assert m.resolved_variant()[0] == "colblock"
+    cb = m.colblock(arrays=False)
+    assert cb["n_blocks"] == 20 and cb["shift"] == 19 and cb["span_fraction"] > 0.9
+    xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
+    x = xbuf.download(np.float32, n)
+    y_cb = _run(m, xptr, n, "auto", np.float32)
+    y_st = _run(m, xptr, n, "stream", np.float32)
+    for rb in (0, 2047, 5_000_000, n - 2500):
+        re = min(n, rb + 2500)
+        off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_UNIFORM, n, k, np.float32, rb, re)
+        y_ref = oracle.spmv(off, col, val, x)
+        assert np.array_equal(y_st[rb:re].view(np.uint32), y_ref.view(np.uint32))  # multi-pass K1s: bit-exact
+        assert_spmv_close(y_cb[rb:re], off, col, val, x, "colblock rows %d.." % rb)
+    assert np.abs(y_cb.astype(np.float64) - y_st).max() < 5e-5  # sum|a x| ~ 8 per row
+    x2 = synth.DeviceBuffer(n * 4)
+    x2.upload(x * np.float32(2))
+    assert np.array_equal(_run(m, x2.ptr, n, "auto", np.float32), y_cb * np.float32(2))
+
+
+def test_full_size_c3_powerlaw_properties(gpu):
+    """BASELINE C3 (f64, 10M rows, power-law lengths 1..2048, uniform columns) at full size: K2c (AUTO), merge-path K2
+    and the bit-exact K1s agree on every row to 1e-12 of the row's scale; sampled rows against the oracle."""
+    n = 10_000_000
+    m = synth.crs_powerlaw(synth.SEED_MATRIX, n, n, np.float64)
+    assert m.resolved_variant()[0] == "colblock" and m.max_row_len() == 2048
+    xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float64)
+    x = xbuf.download(np.float64, n)
+    y_cb = _run(m, xptr, n, "auto", np.float64)
+    y_mg = _run(m, xptr, n, "merge", np.float64)
+    y_st = _run(m, xptr, n, "stream", np.float64)
+    # |row| <= 2048 entries of magnitude < 1: sum|a x| <= 2048; bound 1e-12 * 2048 covers every row
+    assert np.abs(y_cb - y_st).max() < 2.1e-9 and np.abs(y_mg - y_st).max() < 2.1e-9
+    off_all = synth.powerlaw_offsets(synth.SEED_MATRIX, n)
+    for rb in (0, 3_333_333, n - 4000):
+        re = min(n, rb + 4000)
+        off, col, val = oracle.gen_powerlaw(synth.SEED_MATRIX, n, n, np.float64, row_begin=rb, row_end=re)
+        assert np.array_equal(off, (off_all[rb:re + 1].astype(np.int64) - int(off_all[rb])).astype(np.uint32))
+        y_ref = oracle.spmv(off, col, val, x)
+        assert np.array_equal(y_st[rb:re].view(np.uint64), y_ref.view(np.uint64))
+        assert_spmv_close(y_cb[rb:re], off, col, val, x, "colblock rows %d.." % rb)
+        assert_spmv_close(y_mg[rb:re], off, col, val, x, "merge rows %d.." % rb)
