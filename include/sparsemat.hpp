@@ -138,6 +138,12 @@ class SparseMatCRS {
         detail::check(smh_crs_spmv(h_, rhs.data(), rhs.size(), y.data(), variant));
         return y;
     }
+    // SparseMatrix::inner_prod (sparsematrix.rs:161-171): lhs^T A rhs
+    T inner_prod(const DenseVec<T> &lhs, const DenseVec<T> &rhs) const {
+        double out = 0.0;
+        detail::check(smh_crs_inner_prod_vec(h_, lhs.handle(), rhs.handle(), SMH_SPMV_AUTO, &out));
+        return (T)out;
+    }
     // `A * v` (sparsemat_ops! Mul<DenseVec>, sparsematrix.rs:435-443)
     friend DenseVec<T> operator*(const SparseMatCRS &a, const DenseVec<T> &v) { return a.mvp(v); }
 

@@ -167,6 +167,12 @@ int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int 
 int smh_crs_spmv(smh_crs *m, const void *x_host, size_t x_len, void *y_host, int variant);
 int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant,
                      void *stream);
+/* SparseMatrix::inner_prod (sparsematrix.rs:161-171): lhs^T A rhs = sum over all entries of
+ * lhs[i] * a_ij * rhs[j].  lhs_len < n_rows or a column index >= rhs_len is SMH_ERR_INDEX_RANGE
+ * (the reference panics in densevec.rs:41).  Computed as dot(lhs, A rhs): one SpMV with the
+ * matrix's kernel plus a two-stage deterministic reduction (tolerance-level parity, like dot). */
+int smh_crs_inner_prod(smh_crs *m, const void *lhs_host, size_t lhs_len, const void *rhs_host,
+                       size_t rhs_len, int variant, double *out);
 /* merge-path tile table (integer structure, checked bit-exact in tests): tile t starts at
  * (row_out[t], nnz_out[t]); arrays need smh_crs_merge_tiles()+1 entries.                 */
 size_t smh_crs_merge_tiles(const smh_crs *m);
@@ -210,6 +216,8 @@ int smh_blas_axpy_dev(smh_dtype dtype, void *y_dev, const void *a_dev, const voi
 int smh_blas_xpby_dev(smh_dtype dtype, void *p_dev, const void *b_dev, const void *r_dev, size_t n, void *stream);
 /* SparseMatrix::mvp on device vectors; y is resized semantics-free: y.dim() must be n_rows */
 int smh_crs_spmv_vec(smh_crs *m, const smh_vec *x, smh_vec *y, int variant);
+/* SparseMatrix::inner_prod on device vectors (sparsematrix.rs:161-171) */
+int smh_crs_inner_prod_vec(smh_crs *m, const smh_vec *lhs, const smh_vec *rhs, int variant, double *out);
 
 /* ---- ConjugateGradient::solve (linearsolver.rs:27-61) -----------------------------------
  * Device-resident: SpMV + fused updates + reductions, scalars (alpha, beta, r.r) stay in

@@ -83,6 +83,8 @@ SIGNATURES = {
     "smh_blas_axpy_dev": (_int, [_int, _vp, _vp, _vp, _sz, _vp]),
     "smh_blas_xpby_dev": (_int, [_int, _vp, _vp, _vp, _sz, _vp]),
     "smh_crs_spmv_vec": (_int, [_vp, _vp, _vp, _int]),
+    "smh_crs_inner_prod": (_int, [_vp, _vp, _sz, _vp, _sz, _int, C.POINTER(C.c_double)]),
+    "smh_crs_inner_prod_vec": (_int, [_vp, _vp, _vp, _int, C.POINTER(C.c_double)]),
     "smh_cg_solve": (_int, [_vp, _vp, _sz, _vp, _sz, C.c_double, _sz, _int, C.POINTER(_sz),
                             C.POINTER(C.c_double)]),
     "smh_cg_solve_vec": (_int, [_vp, _vp, _vp, C.c_double, _sz, _int, _sz, C.POINTER(_sz),

@@ -888,6 +888,58 @@ int smh_vec_dot(const smh_vec *x, const smh_vec *y, double *out) {
     return SMH_OK;
 }
 
+// lhs^T (A rhs) on device vectors: y = A rhs with the matrix's own kernel into the handle's y staging, then the
+// two-stage dot with lhs.  (sparsematrix.rs:161-171 sums lhs_i * a_ij * rhs_j over all entries in storage order;
+// a parallel reduction regroups that sum, so parity is tolerance-level, like dot.)
+static int inner_prod_dev(smh_crs *m, const void *d_lhs, size_t lhs_len, const void *d_rhs, size_t rhs_len, int variant,
+                          double *out) {
+    if (!out) return fail(SMH_ERR_INVALID, "out is NULL");
+    *out = 0.0;
+    if (m->n_rows == 0 || m->nnz == 0) return SMH_OK;
+    if (lhs_len < m->n_rows)  // lhs.get(i) for every row: densevec.rs:41
+        return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %zu", lhs_len, m->n_rows - 1);
+    const size_t vs = dtype_size(m->dtype);
+    SMH_TRY(ensure_cap(&m->d_y, &m->d_y_cap, m->n_rows * vs));
+    SMH_TRY(spmv_enqueue(m, d_rhs, rhs_len, m->d_y, variant, m->stream));
+    void *scratch = nullptr;
+    SMH_TRY(reduce_scratch(&scratch));
+    char *res = (char *)scratch + kReducePartials * sizeof(double);
+    SMH_TRY(launch_dot(m->dtype, d_lhs, m->d_y, m->n_rows, scratch, res, m->stream));
+    double h64 = 0;
+    float h32 = 0;
+    if (m->dtype == SMH_F64) SMH_HIP(hipMemcpyAsync(&h64, res, sizeof h64, hipMemcpyDeviceToHost, m->stream));
+    else SMH_HIP(hipMemcpyAsync(&h32, res, sizeof h32, hipMemcpyDeviceToHost, m->stream));
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    *out = m->dtype == SMH_F64 ? h64 : (double)h32;
+    return SMH_OK;
+}
+
+int smh_crs_inner_prod_vec(smh_crs *m, const smh_vec *lhs, const smh_vec *rhs, int variant, double *out) {
+    if (!m || !lhs || !rhs) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (lhs->dtype != m->dtype || rhs->dtype != m->dtype) return fail(SMH_ERR_INVALID, "value types differ");
+    SMH_HIP(hipDeviceSynchronize());  // vectors may have pending work on other streams
+    return inner_prod_dev(m, lhs->d, lhs->n, rhs->d, rhs->n, variant, out);
+}
+
+int smh_crs_inner_prod(smh_crs *m, const void *lhs_host, size_t lhs_len, const void *rhs_host, size_t rhs_len, int variant,
+                       double *out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if ((lhs_len && !lhs_host) || (rhs_len && !rhs_host)) return fail(SMH_ERR_INVALID, "NULL host vector");
+    const size_t vs = dtype_size(m->dtype);
+    // rhs goes to the x staging; lhs to a scratch allocation of its own
+    SMH_TRY(ensure_cap(&m->d_x, &m->d_x_cap, rhs_len * vs));
+    void *d_lhs = nullptr;
+    SMH_HIP(hipMalloc(&d_lhs, (lhs_len ? lhs_len : 1) * vs));
+    auto go = [&]() -> int {
+        if (rhs_len) SMH_HIP(hipMemcpyAsync(m->d_x, rhs_host, rhs_len * vs, hipMemcpyHostToDevice, m->stream));
+        if (lhs_len) SMH_HIP(hipMemcpyAsync(d_lhs, lhs_host, lhs_len * vs, hipMemcpyHostToDevice, m->stream));
+        return inner_prod_dev(m, d_lhs, lhs_len, m->d_x, rhs_len, variant, out);
+    };
+    const int rc = go();
+    (void)hipFree(d_lhs);
+    return rc;
+}
+
 int smh_vec_norm_squared(const smh_vec *x, double *out) { return smh_vec_dot(x, x, out); }
 
 int smh_vec_norm(const smh_vec *x, double *out) {

@@ -231,6 +231,19 @@ class SparseMatCRS:
     def __mul__(self, rhs):
         return self.mvp(rhs)
 
+    def inner_prod(self, lhs, rhs, variant="auto"):
+        """SparseMatrix::inner_prod (sparsematrix.rs:161-171): lhs^T A rhs as a Python float."""
+        out = C.c_double()
+        var = _lib.VARIANTS[variant]
+        if isinstance(lhs, DenseVec) and isinstance(rhs, DenseVec):
+            check(lib().smh_crs_inner_prod_vec(self._h, lhs._h, rhs._h, var, C.byref(out)))
+            return out.value
+        a = np.ascontiguousarray(lhs, dtype=self._dtype)
+        b = np.ascontiguousarray(rhs, dtype=self._dtype)
+        check(lib().smh_crs_inner_prod(self._h, a.ctypes.data if a.size else None, a.size,
+                                       b.ctypes.data if b.size else None, b.size, var, C.byref(out)))
+        return out.value
+
     def mvp_dev(self, x_ptr, x_len, y_ptr, variant="auto", stream=None):
         """Asynchronous y = A.x on raw device pointers (stream: a hipStream_t value or None)."""
         check(lib().smh_crs_spmv_dev(self._h, C.c_void_p(x_ptr), x_len, C.c_void_p(y_ptr),

@@ -177,3 +177,42 @@ def test_par_cg_single_rank_matches_oracle(gpu, dtype, tol):
     np.testing.assert_allclose(xt1.cpu().numpy(), x1, rtol=1e-6 if dtype == np.float32 else 1e-14)
     with pytest.raises(sm.SparseMatPanic):
         cg.solve(par, bt[:-1], xt)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", ["laplace", "rect_ragged", "powerlaw"])
+def test_matrix_inner_prod(gpu, dtype, shape):
+    """SparseMatrix::inner_prod (sparsematrix.rs:161-171) = lhs^T A rhs: within eps * n-ish of the oracle's
+    sequential sum, relative to sum |lhs_i a_ij rhs_j| (a reduction: tolerance-level, like dot)."""
+    rng = np.random.default_rng({"laplace": 1, "rect_ragged": 2, "powerlaw": 3}[shape])
+    if shape == "laplace":
+        off, col, val = oracle.laplace3d(23, 17, 9, dtype)
+        n_rows = n_cols = 23 * 17 * 9
+    elif shape == "rect_ragged":
+        n_rows, n_cols = 7001, 2503
+        lens = rng.integers(0, 50, n_rows)
+        off = np.zeros(n_rows + 1, np.uint32)
+        np.cumsum(lens, out=off[1:])
+        col = rng.integers(0, n_cols, int(off[-1]), dtype=np.uint32)
+        val = rng.uniform(-1, 1, len(col)).astype(dtype)
+    else:
+        n_rows = n_cols = 40_000
+        off, col, val = oracle.gen_powerlaw(7, n_rows, n_cols, dtype)
+    lhs = rng.uniform(-1, 1, n_rows).astype(dtype)
+    rhs = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    ref = float(oracle.mat_inner_prod(off, col, val, lhs, rhs))
+    scale = float(oracle.mat_inner_prod(off, col, np.abs(val), np.abs(lhs), np.abs(rhs)))
+    tol = (1e-5 if dtype == np.float32 else 1e-12) * scale
+    got = m.inner_prod(lhs, rhs)
+    assert abs(got - ref) <= tol, (got, ref, scale)
+    got_v = m.inner_prod(sm.DenseVec.from_vec(lhs), sm.DenseVec.from_vec(rhs))
+    assert got_v == got  # same kernels, deterministic reduction: bitwise reproducible
+    for variant in ("stream", "merge", "vector"):
+        assert abs(m.inner_prod(lhs, rhs, variant=variant) - ref) <= tol, variant
+    # the reference panics (densevec.rs:41) when a vector is too short
+    with pytest.raises(sm.SparseMatPanic) as e:
+        m.inner_prod(lhs[:-1], rhs)
+    assert e.value.status == _lib.SMH_ERR_INDEX_RANGE
+    with pytest.raises(sm.SparseMatPanic):
+        m.inner_prod(lhs, rhs[:int(col.max())])
