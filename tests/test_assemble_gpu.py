@@ -129,3 +129,36 @@ def test_assemble_fem_like_stream(gpu):
     expect = oracle.assemble(rows, cols, vals)
     same_crs(m, expect)
     assert m.n_rows() == (g + 1) ** 3 and m.max_row_len() == 27
+
+
+def test_assemble_then_solve_on_device(gpu):
+    """The pipeline the reference's containers exist for: add_to stream -> to_crs -> ConjugateGradient::solve,
+    entirely behind the C ABI.  7-point Laplacian assembled edge by edge (every diagonal entry is the sum of up to
+    6 contributions of 1.0: exact in any order), solved for x* = 1."""
+    g, dtype = 20, np.float64
+    idx = np.arange(g ** 3).reshape(g, g, g)
+    pairs = []
+    for axis in range(3):
+        a = np.take(idx, np.arange(g - 1), axis=axis).ravel()
+        b = np.take(idx, np.arange(1, g), axis=axis).ravel()
+        pairs.append((a, b))
+    a = np.concatenate([p[0] for p in pairs])
+    b = np.concatenate([p[1] for p in pairs])
+    # per edge (a,b): A[a,a] += 1, A[b,b] += 1, A[a,b] -= 1, A[b,a] -= 1 ; plus a unit mass on the diagonal (SPD)
+    rows = np.concatenate([a, b, a, b, idx.ravel()])
+    cols = np.concatenate([a, b, b, a, idx.ravel()])
+    vals = np.concatenate([np.ones(len(a)), np.ones(len(a)), -np.ones(len(a)), -np.ones(len(a)), np.ones(g ** 3)]).astype(dtype)
+    order = np.random.default_rng(2).permutation(len(vals))  # element loops do not come sorted
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    m = sm.SparseMatCRS.from_triplets(rows, cols, vals)
+    n_rows, n_cols, off, col, val = oracle.assemble(rows, cols, vals)
+    same_crs(m, (n_rows, n_cols, off, col, val))
+    n = g ** 3
+    bvec = oracle.spmv(off, col, val, np.ones(n, dtype))
+    x_ref, it_ref, _ = oracle.cg(n, n, off, col, val, bvec, np.zeros(n, dtype), tol=1e-10, iter_max=500)
+    xd, bd = sm.DenseVec.from_vec(np.zeros(n, dtype)), sm.DenseVec.from_vec(bvec)
+    cg = sm.ConjugateGradient(1e-10, 500)
+    cg.solve(m, bd, xd)
+    assert abs(cg.iterations - it_ref) <= 2
+    np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=1e-8)
+    np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=1e-8)

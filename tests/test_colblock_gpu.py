@@ -126,3 +126,32 @@ def test_auto_picks_colblock_only_without_column_locality(gpu):
         m_b = synth.crs_fixed(synth.SEED_MATRIX, pattern, n, k, np.float32, 1_000_000, 1_000_000 + rows)
         assert m_b.resolved_variant()[0] == "vector", pattern
         assert m_b.colblock(arrays=False)["span_fraction"] < 0.05
+
+
+def test_cg_on_a_matrix_without_locality_runs_colblock(gpu):
+    """A randomly permuted 7-point Laplacian (SPD, 1.33 M rows: 10.6 MB of f64 x, columns all over it) resolves to
+    K2c; the device-resident CG (hipGraph replay of K2c launches) follows the oracle's iterates."""
+    g, dtype = 110, np.float64
+    n = g ** 3
+    off, col, val = oracle.laplace3d(g, g, g, dtype)
+    perm = np.random.default_rng(4).permutation(n).astype(np.uint32)   # new index of old row/column
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    lens = np.diff(off.astype(np.int64))
+    lens_p = lens[inv]                                                   # row r of P A P^T is old row inv[r]
+    off_p = np.zeros(n + 1, np.uint32)
+    np.cumsum(lens_p, out=off_p[1:])
+    src = (off[:-1].astype(np.int64)[inv])
+    gather = np.repeat(src - off_p[:-1].astype(np.int64), lens_p) + np.arange(int(off_p[-1]))
+    col_p, val_p = perm[col[gather]], val[gather]
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off_p, col_p, val_p)
+    assert m.resolved_variant()[0] == "colblock" and m.colblock(arrays=False)["n_blocks"] == 3
+    b = oracle.spmv(off_p, col_p, val_p, np.ones(n, dtype))
+    iters = 40
+    x_ref, it_ref, rr_ref = oracle.cg(n, n, off_p, col_p, val_p, b, np.zeros(n, dtype), tol=1e-30, iter_max=iters)
+    xd, bd = sm.DenseVec.from_vec(np.zeros(n, dtype)), sm.DenseVec.from_vec(b)
+    cg = sm.ConjugateGradient(1e-30, iters)
+    cg.solve(m, bd, xd)
+    assert cg.iterations == it_ref == iters
+    assert abs(cg.r_norm_squared - rr_ref) <= 1e-9 * rr_ref
+    np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=1e-10)
