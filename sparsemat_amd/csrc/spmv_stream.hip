@@ -142,6 +142,11 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // tile does; the body is then loop-free and needs 70 instead of 90 VGPRs (f32: 7 instead of 5 waves per SIMD).
 // A/B knob: waves per SIMD the register allocator must allow (0: no constraint).  Measured on the 512^3 Laplacian,
 // same box: unconstrained (68 VGPRs, 7 waves) 1.79 / 1.82 ms; 8 waves (64 VGPRs + 12 B/lane of scratch) 1.96 / 1.95 ms.
+// Two more experiments on that matrix, both dropped: (a) the tile's entry range from a compact, L2-resident boundary
+// table instead of off[] (1.845 / 1.869 vs 1.881 / 1.879 ms: within noise); (b) a plane-interleaved tile order per
+// XCD (tiles at one in-plane position of all planes back to back, so that the three uses of an x entry coincide):
+// 1.95 ms vs 1.82 ms -- the concurrently active tiles then stream from 64 distant regions per array.  rocprofv3
+// (profiles/r01_pmc_lap512_stream.json): L2 fetches 9.9 GB for 8.6 GB algorithmic reads, 87 % of wave cycles waiting.
 #ifndef SMH_STREAM_MIN_WAVES
 #define SMH_STREAM_MIN_WAVES 0
 #endif
