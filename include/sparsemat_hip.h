@@ -165,6 +165,10 @@ int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int 
  * (the reference panics in densevec.rs:41).  y has exactly n_rows entries (ret.set grows
  * it one row at a time, vector.rs:40-42 / densevec.rs:44-49); empty rows give 0.        */
 int smh_crs_spmv(smh_crs *m, const void *x_host, size_t x_len, void *y_host, int variant);
+/* Builds now what the first product with `variant` would build lazily (K1r phase plan, merge-path
+ * table, K2c blocked copy: device allocations and a synchronisation): call it before capturing
+ * smh_crs_spmv_dev into a hipGraph of your own.  Never needed for correctness otherwise.      */
+int smh_crs_prepare(smh_crs *m, int variant);
 int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant,
                      void *stream);
 /* SparseMatrix::inner_prod (sparsematrix.rs:161-171): lhs^T A rhs = sum over all entries of

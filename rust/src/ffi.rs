@@ -24,4 +24,14 @@ extern "C" {
     pub fn smh_cg_solve(m: *mut smh_crs, b_host: *const c_void, b_len: usize, x_host_inout: *mut c_void,
                         x_len: usize, tol: c_double, iter_max: usize, variant: c_int,
                         iters_out: *mut usize, rr_out: *mut c_double) -> c_int;
+    pub fn smh_crs_inner_prod(m: *mut smh_crs, lhs_host: *const c_void, lhs_len: usize, rhs_host: *const c_void,
+                              rhs_len: usize, variant: c_int, out: *mut c_double) -> c_int;
+    // add_to (ops[k] == 0 / ops null) or set (ops[k] == 1) stream -> the CRS `to_crs()` would return
+    pub fn smh_crs_assemble(dtype: c_int, n_ops: usize, rows: *const u32, cols: *const u32, values: *const c_void,
+                            ops: *const u8, out: *mut *mut smh_crs) -> c_int;
+    pub fn smh_crs_sort_rows(m: *mut smh_crs) -> c_int;
+    pub fn smh_crs_n_rows(m: *const smh_crs) -> usize;
+    pub fn smh_crs_n_cols(m: *const smh_crs) -> usize;
+    pub fn smh_crs_nnz(m: *const smh_crs) -> usize;
+    pub fn smh_crs_download(m: *const smh_crs, offset_rows: *mut u32, columns: *mut u32, values: *mut c_void) -> c_int;
 }

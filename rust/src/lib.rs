@@ -66,6 +66,62 @@ impl DeviceCrs {
     }
 }
 
+impl DeviceCrs {
+    /// `SparseMatrix::inner_prod` (src/sparsematrix.rs:161-171): lhs^T A rhs.
+    pub fn inner_prod<T: HipValue>(&self, lhs: &[T], rhs: &[T]) -> f64 {
+        let mut out = 0f64;
+        check(unsafe {
+            ffi::smh_crs_inner_prod(self.handle, lhs.as_ptr() as *const c_void, lhs.len(), rhs.as_ptr() as *const c_void,
+                                    rhs.len(), ffi::SMH_SPMV_AUTO, &mut out)
+        });
+        out
+    }
+
+    /// `sort_row(i)` for every row (src/sparsemat_crs.rs:163-172), on the device copy.
+    pub fn sort_rows(&mut self) {
+        check(unsafe { ffi::smh_crs_sort_rows(self.handle) });
+    }
+
+    /// The CRS arrays as stored on the device: (n_cols, offset_rows, columns, values) -- what
+    /// `SparseMatCRS::from_raw_parts` takes back on the Rust side.
+    pub fn raw_parts<T: HipValue + Default>(&self) -> (usize, Vec<u32>, Vec<u32>, Vec<T>) {
+        let nnz = unsafe { ffi::smh_crs_nnz(self.handle) };
+        let (mut off, mut col, mut val) = (vec![0u32; self.n_rows + 1], vec![0u32; nnz], vec![T::default(); nnz]);
+        check(unsafe { ffi::smh_crs_download(self.handle, off.as_mut_ptr(), col.as_mut_ptr(), val.as_mut_ptr() as *mut c_void) });
+        (unsafe { ffi::smh_crs_n_cols(self.handle) }, off, col, val)
+    }
+}
+
+/// Write-only recorder with the call surface of `SparseMatIndexList` assembly (src/sparsematrix.rs:226-233):
+/// `add_to` / `set` append in O(1) (no walk of the row's list, src/sparsemat_indexlist.rs:29-42), `to_crs`
+/// (src/sparsemat_indexlist.rs:61-63) assembles on the device -- same CRS, bit for bit: rows in order of first
+/// appearance, duplicates folded in call order.
+pub struct TripletStream<T: HipValue> {
+    rows: Vec<u32>,
+    cols: Vec<u32>,
+    vals: Vec<T>,
+    ops: Vec<u8>,
+}
+
+impl<T: HipValue> TripletStream<T> {
+    pub fn with_capacity(cap: usize) -> Self {
+        TripletStream { rows: Vec::with_capacity(cap), cols: Vec::with_capacity(cap), vals: Vec::with_capacity(cap), ops: Vec::with_capacity(cap) }
+    }
+    pub fn add_to(&mut self, i: usize, j: usize, val: T) { self.push(i, j, val, 0) }
+    pub fn set(&mut self, i: usize, j: usize, val: T) { self.push(i, j, val, 1) }
+    fn push(&mut self, i: usize, j: usize, val: T, op: u8) {
+        self.rows.push(i as u32); self.cols.push(j as u32); self.vals.push(val); self.ops.push(op);
+    }
+    pub fn to_crs(&self) -> DeviceCrs {
+        let mut handle = std::ptr::null_mut();
+        check(unsafe {
+            ffi::smh_crs_assemble(T::DTYPE, self.vals.len(), self.rows.as_ptr(), self.cols.as_ptr(),
+                                  self.vals.as_ptr() as *const c_void, self.ops.as_ptr(), &mut handle)
+        });
+        DeviceCrs { handle, n_rows: unsafe { ffi::smh_crs_n_rows(handle) } }
+    }
+}
+
 impl Drop for DeviceCrs {
     fn drop(&mut self) {
         unsafe { ffi::smh_crs_destroy(self.handle) };

@@ -57,6 +57,7 @@ SIGNATURES = {
     "smh_crs_colblock": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(_int), C.POINTER(C.c_double), _vp, _vp, _vp]),
     "smh_crs_spmv": (_int, [_vp, _vp, _sz, _vp, _int]),
     "smh_crs_spmv_dev": (_int, [_vp, _vp, _sz, _vp, _int, _vp]),
+    "smh_crs_prepare": (_int, [_vp, _int]),
     "smh_crs_merge_tiles": (_sz, [_vp]),
     "smh_crs_merge_tile_items": (_sz, [_vp]),
     "smh_crs_merge_table": (_int, [_vp, _vp, _vp]),

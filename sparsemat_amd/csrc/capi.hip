@@ -742,6 +742,21 @@ int smh_crs_set_vector_lanes(smh_crs *m, int lanes) {
     return SMH_OK;
 }
 
+int smh_crs_prepare(smh_crs *m, int variant) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    switch (resolve_variant(m, variant)) {
+        case SMH_SPMV_VECTOR: {
+            bool ring = false;
+            return vector_uses_ring(m, &ring);  // builds the K1r phase plan when the ring is used
+        }
+        case SMH_SPMV_MERGE: return ensure_merge_ws(m);
+        case SMH_SPMV_COLBLOCK: return ensure_colblock(m);
+        case SMH_SPMV_STREAM: return m->use_stream_win == 1 ? ensure_stream_windows(m) : SMH_OK;
+        case SMH_SPMV_SEQ: return SMH_OK;
+        default: return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);
+    }
+}
+
 int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant, void *stream) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (m->n_rows && (!y_dev || (m->nnz && !x_dev))) return fail(SMH_ERR_INVALID, "NULL device vector");

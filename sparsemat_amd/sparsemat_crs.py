@@ -244,6 +244,10 @@ class SparseMatCRS:
                                        b.ctypes.data if b.size else None, b.size, var, C.byref(out)))
         return out.value
 
+    def prepare(self, variant="auto"):
+        """Build the lazily created workspaces of ``variant`` now (before capturing mvp_dev into a hipGraph)."""
+        check(lib().smh_crs_prepare(self._h, _lib.VARIANTS[variant]))
+
     def mvp_dev(self, x_ptr, x_len, y_ptr, variant="auto", stream=None):
         """Asynchronous y = A.x on raw device pointers (stream: a hipStream_t value or None)."""
         check(lib().smh_crs_spmv_dev(self._h, C.c_void_p(x_ptr), x_len, C.c_void_p(y_ptr),
