@@ -11,15 +11,25 @@
 //   * the entry's value is the left fold of its operations in stream order, starting from T::zero():
 //     add_to: acc = acc + v, set: acc = v (one rounding per add).
 // Device formulation (integer structure bit-exact, values bit-exact -- the fold is sequential per entry):
-//   1. key = row << 32 | column, payload = stream position; STABLE radix sort (rocPRIM): the operations of an
-//      entry become one contiguous run, still in stream order;
-//   2. run heads flagged, exclusive scan -> dense entry ids; one thread per run folds it sequentially and
-//      records (row << 32 | first stream position, column, value);
-//   3. second stable sort on row << 32 | first position: rows ascending, first-appearance order inside a row;
-//   4. gather columns / values, row offsets from the sorted row ids.
+//   1. STABLE radix sort (rocPRIM) of the operations by row only (as few 8-bit passes as the row count needs),
+//      payload = column << 32 | stream position: a row's operations become contiguous, still in stream order;
+//   2a. SHORT ROWS (no row with more than 2048 operations -- every assembly stream: 27 x 8 operations per row for
+//      trilinear hexahedra): one thread REPLAYS one row exactly as the reference does -- find the column in the
+//      row's list (first 32 entries in LDS), else append -- so the list comes out in first-appearance order with
+//      the folded values and nothing else needs sorting; the per-row counts are scanned into the CRS offsets and
+//      the lists moved to their places with coalesced stores;
+//   2b. LONG ROWS (any stream is handled): segmented sort of the payload inside every row (rocPRIM takes long
+//      segments in several passes), run heads -> exclusive scan -> dense entry ids, one thread per run folds it
+//      sequentially, then a segmented sort of the entries of a row by first stream position.
+// Measured on 134 M operations of a 128^3-cell mesh (profiles/r01_assemble_bench.log): first version -- global
+// sorts on row << 32 | column and row << 32 | first position, 13 radix passes over 64-bit keys -- 19.8 ms; this
+// one 3 radix passes + the row replay (2.3 ms).
 // Also here: Sortable::sort_row (sparsemat_crs.rs:163-172; slice::sort_by is stable) for all rows at once --
-// one stable sort on row << 32 | column.
+// one segmented stable sort by column over the CRS offsets.
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include <chrono>
 
 #include "internal.hpp"
 
@@ -33,15 +43,30 @@ static unsigned grid_for(uint64_t n) {
     return (unsigned)(b ? b : 1);
 }
 
-// keys of the first sort + the matrix dimensions (integer max: exact, order independent)
+// sort key (row), payload (column << 32 | stream position) + the matrix dimensions (integer max: exact)
 __global__ void __launch_bounds__(kBlock)
-k_asm_keys(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ cols, uint64_t n, uint64_t *__restrict__ key,
-           uint32_t *__restrict__ idx, uint32_t *__restrict__ dims /* [0] max row, [1] max column */) {
+k_asm_keys(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ cols, uint64_t n, uint32_t *__restrict__ row_key,
+           uint64_t *__restrict__ cp, uint32_t *__restrict__ dims /* [0] max row, [1] max column */) {
     uint32_t mr = 0, mc = 0;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    const uint64_t n4 = (((uintptr_t)rows | (uintptr_t)cols) & 15u) ? 0 : n / 4;  // 16-B loads need aligned arrays
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (uint64_t)gridDim.x * blockDim.x) {
+        const u32x4 r = reinterpret_cast<const u32x4 *>(rows)[q], c = reinterpret_cast<const u32x4 *>(cols)[q];
+        const uint64_t k = 4 * q;
+        reinterpret_cast<u32x4 *>(row_key)[q] = r;
+        u64x2 a, b;
+        a.x = ((uint64_t)c.x << 32) | (uint32_t)k;       a.y = ((uint64_t)c.y << 32) | (uint32_t)(k + 1);
+        b.x = ((uint64_t)c.z << 32) | (uint32_t)(k + 2); b.y = ((uint64_t)c.w << 32) | (uint32_t)(k + 3);
+        reinterpret_cast<u64x2 *>(cp)[2 * q] = a;
+        reinterpret_cast<u64x2 *>(cp)[2 * q + 1] = b;
+        mr = max(max(mr, r.x), max(max(r.y, r.z), r.w));
+        mc = max(max(mc, c.x), max(max(c.y, c.z), c.w));
+    }
+    for (uint64_t k = 4 * n4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = rows[k], c = cols[k];
-        key[k] = ((uint64_t)r << 32) | c;
-        idx[k] = (uint32_t)k;
+        row_key[k] = r;
+        cp[k] = ((uint64_t)c << 32) | (uint32_t)k;
         mr = max(mr, r);
         mc = max(mc, c);
     }
@@ -50,23 +75,44 @@ k_asm_keys(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ cols,
         mr = max(mr, (uint32_t)__shfl_down(mr, o, kWave));
         mc = max(mc, (uint32_t)__shfl_down(mc, o, kWave));
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        atomicMax(&dims[0], mr);
-        atomicMax(&dims[1], mc);
+    // one pair of atomics per block (131 072 same-address atomics, one pair per wave, cost 1.5 ms on their own)
+    __shared__ uint32_t s_mr[kBlock / kWave], s_mc[kBlock / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_mr[threadIdx.x / kWave] = mr; s_mc[threadIdx.x / kWave] = mc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&dims[0], max(max(s_mr[0], s_mr[1]), max(s_mr[2], s_mr[3])));
+        atomicMax(&dims[1], max(max(s_mc[0], s_mc[1]), max(s_mc[2], s_mc[3])));
     }
+}
+
+// seg[r] = first position whose (sorted) row is >= r, r = 0..n_rows; seg[n_rows] = n
+__global__ void __launch_bounds__(kBlock)
+k_asm_segments(const uint32_t *__restrict__ row_s, uint64_t n, uint64_t n_rows, uint32_t *__restrict__ seg) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = row_s[p];
+        const uint64_t prev = p ? (uint64_t)row_s[p - 1] : ~uint64_t(0);
+        if (p == 0 || prev != r)
+            for (uint64_t q = p ? prev + 1 : 0; q <= r; ++q) seg[q] = (uint32_t)p;
+        if (p + 1 == n)
+            for (uint64_t q = r + 1; q <= n_rows; ++q) seg[q] = (uint32_t)n;
+    }
+}
+
+__device__ __forceinline__ bool run_head(const uint32_t *row_s, const uint64_t *cp_s, uint64_t k) {
+    return k == 0 || row_s[k] != row_s[k - 1] || (uint32_t)(cp_s[k] >> 32) != (uint32_t)(cp_s[k - 1] >> 32);
 }
 
 // operations brought into sorted order (coalesced writes; the fold then reads runs sequentially) + run heads
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_asm_heads(const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx, const T *__restrict__ vals,
+k_asm_heads(const uint32_t *__restrict__ row_s, const uint64_t *__restrict__ cp_s, const T *__restrict__ vals,
             const uint8_t *__restrict__ ops, uint64_t n, T *__restrict__ vals_s, uint8_t *__restrict__ ops_s,
             uint32_t *__restrict__ head) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t i = idx[k];
+        const uint32_t i = (uint32_t)cp_s[k];
         vals_s[k] = vals[i];
         if (ops) ops_s[k] = ops[i];
-        head[k] = (k == 0 || key[k] != key[k - 1]) ? 1u : 0u;
+        head[k] = run_head(row_s, cp_s, k) ? 1u : 0u;
     }
 }
 
@@ -74,13 +120,12 @@ k_asm_heads(const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx, 
 // which push created as T::zero(): sparsemat_indexlist.rs:160-162)
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_asm_fold(const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx, const T *__restrict__ vals_s,
+k_asm_fold(const uint32_t *__restrict__ row_s, const uint64_t *__restrict__ cp_s, const T *__restrict__ vals_s,
            const uint8_t *__restrict__ ops_s, const uint32_t *__restrict__ entry_id /* exclusive scan of heads */,
-           uint64_t n, uint64_t *__restrict__ ukey, uint32_t *__restrict__ uidx, uint32_t *__restrict__ ucol,
+           uint64_t n, uint32_t *__restrict__ first_pos, uint32_t *__restrict__ uidx, uint32_t *__restrict__ ucol,
            T *__restrict__ uval) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t me = key[k];
-        if (k > 0 && key[k - 1] == me) continue;  // not a run head
+        if (!run_head(row_s, cp_s, k)) continue;
         T acc = T(0);
         uint64_t j = k;
         do {
@@ -89,57 +134,145 @@ k_asm_fold(const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx, c
             else if constexpr (sizeof(T) == 4) acc = __fadd_rn(acc, v);
             else acc = __dadd_rn(acc, v);
             ++j;
-        } while (j < n && key[j] == me);
+        } while (j < n && !run_head(row_s, cp_s, j));
         const uint32_t u = entry_id[k];
-        ukey[u] = (me & 0xFFFFFFFF00000000ull) | idx[k];  // stable sort: idx[k] is the run's first stream position
+        first_pos[u] = (uint32_t)cp_s[k];  // the run is in stream order: its head is the first appearance
         uidx[u] = u;
-        ucol[u] = (uint32_t)me;
+        ucol[u] = (uint32_t)(cp_s[k] >> 32);
         uval[u] = acc;
     }
 }
 
-// entries in final order + row offsets from the sorted row ids
+// CRS offsets: entries before row r = run heads before the row's first operation
+__global__ void __launch_bounds__(kBlock)
+k_asm_offsets(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ entry_id, uint64_t n, uint64_t n_rows,
+              uint32_t n_entries, uint32_t *__restrict__ off) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = seg[r];
+        off[r] = p < n ? entry_id[p] : n_entries;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_asm_emit(const uint64_t *__restrict__ ukey_s, const uint32_t *__restrict__ uidx_s, const uint32_t *__restrict__ ucol,
-           const T *__restrict__ uval, uint64_t n_entries, uint64_t n_rows, uint32_t *__restrict__ off,
-           uint32_t *__restrict__ col, T *__restrict__ val) {
+k_asm_emit(const uint32_t *__restrict__ uidx_s, const uint32_t *__restrict__ ucol, const T *__restrict__ uval,
+           uint64_t n_entries, uint32_t *__restrict__ col, T *__restrict__ val) {
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_entries; p += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t u = uidx_s[p];
         col[p] = ucol[u];
         val[p] = uval[u];
-        const uint64_t r = ukey_s[p] >> 32;
-        const uint64_t prev = p ? (ukey_s[p - 1] >> 32) : ~uint64_t(0);  // rows (prev, r] start at p
-        if (p == 0 || prev != r)
-            for (uint64_t q = p ? prev + 1 : 0; q <= r; ++q) off[q] = (uint32_t)p;
-        if (p + 1 == n_entries)
-            for (uint64_t q = r + 1; q <= n_rows; ++q) off[q] = (uint32_t)n_entries;
     }
 }
 
-static int sort_pairs_u64_u32(const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
-                              unsigned end_bit, hipStream_t s) {
-    size_t bytes = 0;
-    SMH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, end_bit, s));
-    void *tmp = nullptr;
-    SMH_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
-    const hipError_t e = rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0u, end_bit, s);
-    const hipError_t e2 = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    SMH_HIP(e);
-    SMH_HIP(e2);
-    return SMH_OK;
+// ---- short rows: one thread replays one row -------------------------------------------------------------------
+// After the sort by row, a row's operations are contiguous and in stream order.  One thread walks them exactly
+// like the reference's get_mut (find the column in the row's list, else append): the list comes out in
+// first-appearance order with the folded values -- no further sorting.  The first kRowCap entries of the list
+// live in LDS (entry-major: conflict-free), longer lists continue in the row's own stretch of the global scratch
+// (a row never has more entries than operations).  Used when no row has more than kRowwiseMaxOps operations.
+template <typename T>
+__device__ __forceinline__ T asm_add(T a, T b) {  // one rounding, never contracted
+    if constexpr (sizeof(T) == 4) return __fadd_rn(a, b);
+    else return __dadd_rn(a, b);
 }
 
-static unsigned bits_for(uint32_t v) {  // bits needed to hold v
+constexpr int kRowBlock = 64;
+constexpr int kRowCap = 32;
+constexpr uint32_t kRowwiseMaxOps = 2048;
+
+template <typename T>
+__global__ void __launch_bounds__(kRowBlock)
+k_asm_rowwise(const uint32_t *__restrict__ seg, const uint64_t *__restrict__ cp_s, const T *__restrict__ vals,
+              const uint8_t *__restrict__ ops, uint64_t n_rows, uint32_t *lcol, T *lval, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t s_col[kRowCap][kRowBlock];
+    __shared__ T s_val[kRowCap][kRowBlock];
+    const uint32_t t = threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * kRowBlock + t;
+    if (r >= n_rows) return;  // (no barriers in this kernel)
+    const uint64_t a = seg[r], b = seg[r + 1];
+    uint32_t cnt = 0;
+    for (uint64_t j = a; j < b; ++j) {
+        const uint64_t e = cp_s[j];
+        const uint32_t c = (uint32_t)(e >> 32), i = (uint32_t)e;
+        const T v = vals[i];
+        const bool set = ops && ops[i];
+        uint32_t f = cnt;  // find_index (sparsemat_indexlist.rs:29-42): first match in list order
+        const uint32_t lim = cnt < (uint32_t)kRowCap ? cnt : (uint32_t)kRowCap;
+        for (uint32_t q = 0; q < lim; ++q)
+            if (s_col[q][t] == c) { f = q; break; }
+        if (f == cnt && cnt > (uint32_t)kRowCap)
+            for (uint32_t q = kRowCap; q < cnt; ++q)
+                if (lcol[a + q] == c) { f = q; break; }
+        if (f < cnt) {  // add_to: `+=`, set: `=` (sparsematrix.rs:226-233)
+            if (f < (uint32_t)kRowCap) s_val[f][t] = set ? v : asm_add(s_val[f][t], v);
+            else lval[a + f] = set ? v : asm_add(lval[a + f], v);
+        } else {  // push(i, j, T::zero()) then the operation (sparsemat_indexlist.rs:158-164)
+            const T nv = set ? v : asm_add(T(0), v);
+            if (cnt < (uint32_t)kRowCap) { s_col[cnt][t] = c; s_val[cnt][t] = nv; }
+            else { lcol[a + cnt] = c; lval[a + cnt] = nv; }
+            ++cnt;
+        }
+    }
+    const uint32_t lim = cnt < (uint32_t)kRowCap ? cnt : (uint32_t)kRowCap;
+    for (uint32_t q = 0; q < lim; ++q) { lcol[a + q] = s_col[q][t]; lval[a + q] = s_val[q][t]; }
+    counts[r] = cnt;
+    if (r + 1 == n_rows) counts[n_rows] = 0;
+}
+
+// row r's list (at seg[r] in the scratch) -> its place in the CRS arrays
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_asm_row_emit(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ off, const uint32_t *__restrict__ lcol,
+               const T *__restrict__ lval, uint64_t n_rows, uint32_t *__restrict__ col, T *__restrict__ val) {
+    // a block moves the lists of 256 consecutive rows: the output range is walked densely (coalesced stores), the
+    // row of an output position found by bisection of the block's 257 offsets held in LDS
+    __shared__ uint32_t s_off[kBlock + 1], s_seg[kBlock];
+    const uint64_t n_groups = (n_rows + kBlock - 1) / kBlock;
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t r0 = g * kBlock, r1 = r0 + kBlock < n_rows ? r0 + kBlock : n_rows;
+        const uint32_t nr = (uint32_t)(r1 - r0);
+        __syncthreads();  // (the previous group's tables are no longer read)
+        if (threadIdx.x < nr) s_seg[threadIdx.x] = seg[r0 + threadIdx.x];
+        if (threadIdx.x <= nr) s_off[threadIdx.x] = off[r0 + threadIdx.x];
+        if (threadIdx.x == 0 && nr == (uint32_t)kBlock) s_off[kBlock] = off[r1];
+        __syncthreads();
+        const uint32_t base = s_off[0], total = s_off[nr] - base;
+        for (uint32_t p = threadIdx.x; p < total; p += kBlock) {
+            uint32_t lo = 0, hi = nr;  // last row with s_off[row] - base <= p
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_off[mid] - base <= p) lo = mid; else hi = mid;
+            }
+            const uint64_t src = (uint64_t)s_seg[lo] + (p - (s_off[lo] - base));
+            col[(uint64_t)base + p] = lcol[src];
+            val[(uint64_t)base + p] = lval[src];
+        }
+    }
+}
+
+static unsigned bits_for(uint64_t v) {  // bits needed to hold v
     unsigned b = 1;
-    while (b < 32 && (v >> b)) ++b;
+    while (b < 64 && (v >> b)) ++b;
     return b;
 }
 
+// rocPRIM calls: query the temporary storage, allocate, run, synchronise, free
+#define SMH_ROCPRIM(call_with_tmp)                                     \
+    do {                                                               \
+        size_t bytes = 0;                                              \
+        void *tmp = nullptr;                                           \
+        SMH_HIP(call_with_tmp);                                        \
+        SMH_HIP(hipMalloc(&tmp, bytes ? bytes : 16));                  \
+        const hipError_t e1 = (call_with_tmp);                         \
+        const hipError_t e2 = hipStreamSynchronize(s);                 \
+        (void)hipFree(tmp);                                            \
+        SMH_HIP(e1);                                                   \
+        SMH_HIP(e2);                                                   \
+    } while (0)
+
 // device buffers freed on scope exit
 struct Scratch {
-    void *p[16] = {};
+    void *p[20] = {};
     int n = 0;
     template <typename U> int alloc(U **out, size_t count) {
         SMH_HIP(hipMalloc((void **)out, (count ? count : 1) * sizeof(U)));
@@ -153,61 +286,127 @@ template <typename T>
 static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, const T *vals, const uint8_t *ops,
                       size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out, uint32_t **col_out,
                       T **val_out, hipStream_t s) {
-    Scratch tmp;
-    uint64_t *key = nullptr, *key_s = nullptr, *ukey = nullptr, *ukey_s = nullptr;
-    uint32_t *idx = nullptr, *idx_s = nullptr, *head = nullptr, *dims = nullptr, *uidx = nullptr, *uidx_s = nullptr, *ucol = nullptr;
-    T *vals_s = nullptr, *uval = nullptr;
+    // SMH_ASSEMBLE_TIMING=1: wall time of every stage on stderr (development aid)
+    static const bool timing = getenv("SMH_ASSEMBLE_TIMING") && atoi(getenv("SMH_ASSEMBLE_TIMING")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[assemble] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    Scratch tmp_bufs;
+    uint32_t *dims = nullptr, *row_key = nullptr, *row_s = nullptr, *seg = nullptr, *head = nullptr;
+    uint64_t *cp = nullptr, *cp_s = nullptr;
+    T *vals_s = nullptr;
     uint8_t *ops_s = nullptr;
-    SMH_TRY(tmp.alloc(&dims, 2));
+    SMH_TRY(tmp_bufs.alloc(&dims, 2));
     SMH_HIP(hipMemsetAsync(dims, 0, 2 * sizeof(uint32_t), s));
-    SMH_TRY(tmp.alloc(&key, n));
-    SMH_TRY(tmp.alloc(&key_s, n));
-    SMH_TRY(tmp.alloc(&idx, n));
-    SMH_TRY(tmp.alloc(&idx_s, n));
-    hipLaunchKernelGGL(k_asm_keys, dim3(grid_for(n)), dim3(kBlock), 0, s, rows, cols, n, key, idx, dims);
+    SMH_TRY(tmp_bufs.alloc(&row_key, n));
+    SMH_TRY(tmp_bufs.alloc(&row_s, n));
+    SMH_TRY(tmp_bufs.alloc(&cp, n));
+    SMH_TRY(tmp_bufs.alloc(&cp_s, n));
+    lap("scratch allocation");
+    hipLaunchKernelGGL(k_asm_keys, dim3(grid_for(n) < 4096u ? grid_for(n) : 4096u), dim3(kBlock), 0, s, rows, cols, n, row_key, cp, dims);
     SMH_HIP(hipGetLastError());
+    lap("keys");
     uint32_t h_dims[2];
     SMH_HIP(hipMemcpyAsync(h_dims, dims, sizeof h_dims, hipMemcpyDeviceToHost, s));
     SMH_HIP(hipStreamSynchronize(s));
     const uint64_t n_rows = (uint64_t)h_dims[0] + 1, n_cols = (uint64_t)h_dims[1] + 1;
-    const unsigned row_bits = bits_for(h_dims[0]);
-    SMH_TRY(sort_pairs_u64_u32(key, key_s, idx, idx_s, n, 32 + row_bits, s));
-    // runs
-    SMH_TRY(tmp.alloc(&head, n));
-    SMH_TRY(tmp.alloc(&vals_s, n));
-    if (ops) SMH_TRY(tmp.alloc(&ops_s, n));
-    hipLaunchKernelGGL((k_asm_heads<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, key_s, idx_s, vals, ops, n, vals_s, ops_s, head);
+    // 1. by row (stable): cp_s holds the rows' operations in stream order
+    SMH_ROCPRIM(rocprim::radix_sort_pairs(tmp, bytes, row_key, row_s, cp, cp_s, (size_t)n, 0u, bits_for(h_dims[0]), s));
+    lap("sort by row");
+    // 2. inside every row by (column, stream position); output back into `cp`
+    SMH_TRY(tmp_bufs.alloc(&seg, n_rows + 1));
+    hipLaunchKernelGGL(k_asm_segments, dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, n, n_rows, seg);
+    SMH_HIP(hipGetLastError());
+    // longest row (in operations) decides the route
+    uint32_t max_ops = 0;
+    SMH_TRY(launch_stream_max_tile(seg, n_rows, 1, dims, s));
+    SMH_HIP(hipMemcpyAsync(&max_ops, dims, sizeof max_ops, hipMemcpyDeviceToHost, s));
+    SMH_HIP(hipStreamSynchronize(s));
+    static const bool allow_rowwise = !(getenv("SMH_ASSEMBLE_ROWWISE") && atoi(getenv("SMH_ASSEMBLE_ROWWISE")) == 0);
+    if (allow_rowwise && max_ops <= kRowwiseMaxOps) {
+        // short rows: one thread replays a row; lists land in `row_key` (columns) / a value scratch at seg[r]
+        uint32_t *lcol = row_key;  // dead after the sort
+        T *lval = nullptr;
+        SMH_TRY(tmp_bufs.alloc(&lval, n));
+        uint32_t *off = nullptr, *col = nullptr;
+        T *val = nullptr;
+        uint64_t n_entries = 0;
+        lap("segments, longest row");
+        auto go = [&]() -> int {
+            SMH_HIP(hipMalloc((void **)&off, (n_rows + 1) * sizeof(uint32_t)));
+            hipLaunchKernelGGL((k_asm_rowwise<T>), dim3((unsigned)((n_rows + kRowBlock - 1) / kRowBlock)), dim3(kRowBlock), 0, s, seg, cp_s,
+                               vals, ops, n_rows, lcol, lval, off);
+            SMH_HIP(hipGetLastError());
+            lap("row replay");
+            SMH_TRY(device_exclusive_scan_u32(off, n_rows + 1, s, &n_entries));  // counts -> CRS offsets
+            SMH_HIP(hipMalloc((void **)&col, (n_entries + 4) * sizeof(uint32_t)));
+            SMH_HIP(hipMalloc((void **)&val, (n_entries + 4) * sizeof(T)));
+            SMH_HIP(hipMemsetAsync(col + n_entries, 0, 4 * sizeof(uint32_t), s));
+            SMH_HIP(hipMemsetAsync(val + n_entries, 0, 4 * sizeof(T), s));
+            lap("offsets, result allocation");
+            hipLaunchKernelGGL((k_asm_row_emit<T>), dim3(grid_for(n_rows)), dim3(kBlock), 0, s, seg, off, lcol, lval, n_rows, col, val);
+            SMH_HIP(hipGetLastError());
+            SMH_HIP(hipStreamSynchronize(s));
+            lap("emit");
+            return SMH_OK;
+        };
+        const int rc = go();
+        if (rc != SMH_OK) {
+            (void)hipFree(off); (void)hipFree(col); (void)hipFree(val);
+            return rc;
+        }
+        *n_rows_out = (size_t)n_rows; *n_cols_out = (size_t)n_cols; *nnz_out = (size_t)n_entries;
+        *off_out = off; *col_out = col; *val_out = val;
+        return SMH_OK;
+    }
+    // long rows: segmented sorts (rocPRIM takes long segments in several passes)
+    SMH_ROCPRIM(rocprim::segmented_radix_sort_keys(tmp, bytes, cp_s, cp, (unsigned)n, (unsigned)n_rows, seg, seg + 1, 0u,
+                                                   32u + bits_for(h_dims[1]), s));
+    const uint64_t *runs = cp;  // (row_s[k], runs[k]) ascending in (row, column, stream position)
+    // 3. runs -> entries
+    SMH_TRY(tmp_bufs.alloc(&head, n));
+    SMH_TRY(tmp_bufs.alloc(&vals_s, n));
+    if (ops) SMH_TRY(tmp_bufs.alloc(&ops_s, n));
+    hipLaunchKernelGGL((k_asm_heads<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, runs, vals, ops, n, vals_s, ops_s, head);
     SMH_HIP(hipGetLastError());
     uint64_t n_entries = 0;
     SMH_TRY(device_exclusive_scan_u32(head, n, s, &n_entries));
-    // (key, idx) are free again: reuse them for the second sort's inputs
-    ukey = key;
-    uidx = idx;
-    SMH_TRY(tmp.alloc(&ucol, n_entries));
-    SMH_TRY(tmp.alloc(&uval, n_entries));
-    hipLaunchKernelGGL((k_asm_fold<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, key_s, idx_s, vals_s, ops_s, head, n, ukey, uidx,
+    uint32_t *first_pos = nullptr, *first_pos_s = nullptr, *uidx = nullptr, *uidx_s = nullptr, *ucol = nullptr;
+    T *uval = nullptr;
+    SMH_TRY(tmp_bufs.alloc(&first_pos, n_entries));
+    SMH_TRY(tmp_bufs.alloc(&first_pos_s, n_entries));
+    SMH_TRY(tmp_bufs.alloc(&uidx, n_entries));
+    SMH_TRY(tmp_bufs.alloc(&uidx_s, n_entries));
+    SMH_TRY(tmp_bufs.alloc(&ucol, n_entries));
+    SMH_TRY(tmp_bufs.alloc(&uval, n_entries));
+    hipLaunchKernelGGL((k_asm_fold<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, runs, vals_s, ops_s, head, n, first_pos, uidx,
                        ucol, uval);
     SMH_HIP(hipGetLastError());
-    SMH_HIP(hipStreamSynchronize(s));
-    ukey_s = key_s;  // the first sort's outputs are dead after the fold
-    uidx_s = idx_s;
-    SMH_TRY(sort_pairs_u64_u32(ukey, ukey_s, uidx, uidx_s, n_entries, 32 + row_bits, s));
     // result arrays (owned by the caller; padded like smh_crs_create's)
     uint32_t *off = nullptr, *col = nullptr;
     T *val = nullptr;
-    auto emit = [&]() -> int {
+    auto finish = [&]() -> int {
         SMH_HIP(hipMalloc((void **)&off, (n_rows + 1) * sizeof(uint32_t)));
         SMH_HIP(hipMalloc((void **)&col, (n_entries + 4) * sizeof(uint32_t)));
         SMH_HIP(hipMalloc((void **)&val, (n_entries + 4) * sizeof(T)));
         SMH_HIP(hipMemsetAsync(col + n_entries, 0, 4 * sizeof(uint32_t), s));
         SMH_HIP(hipMemsetAsync(val + n_entries, 0, 4 * sizeof(T), s));
-        hipLaunchKernelGGL((k_asm_emit<T>), dim3(grid_for(n_entries)), dim3(kBlock), 0, s, ukey_s, uidx_s, ucol, uval, n_entries,
-                           n_rows, off, col, val);
+        hipLaunchKernelGGL(k_asm_offsets, dim3(grid_for(n_rows + 1)), dim3(kBlock), 0, s, seg, head, n, n_rows, (uint32_t)n_entries, off);
+        SMH_HIP(hipGetLastError());
+        // 4. first-appearance order inside every row
+        SMH_ROCPRIM(rocprim::segmented_radix_sort_pairs(tmp, bytes, first_pos, first_pos_s, uidx, uidx_s, (unsigned)n_entries,
+                                                        (unsigned)n_rows, off, off + 1, 0u, bits_for(n - 1), s));
+        hipLaunchKernelGGL((k_asm_emit<T>), dim3(grid_for(n_entries)), dim3(kBlock), 0, s, uidx_s, ucol, uval, n_entries, col, val);
         SMH_HIP(hipGetLastError());
         SMH_HIP(hipStreamSynchronize(s));
         return SMH_OK;
     };
-    const int rc = emit();
+    const int rc = finish();
     if (rc != SMH_OK) {
         (void)hipFree(off); (void)hipFree(col); (void)hipFree(val);
         return rc;
@@ -230,18 +429,8 @@ int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t 
 
 // ---- sort_row for every row --------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_sortrows_keys(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, uint64_t n_rows, uint64_t nnz,
-                uint64_t *__restrict__ key, uint32_t *__restrict__ idx) {
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (uint64_t)gridDim.x * blockDim.x) {
-        // row of entry k: the last r with off[r] <= k
-        uint64_t lo = 0, hi = n_rows;
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if ((uint64_t)off[mid] <= k) lo = mid; else hi = mid;
-        }
-        key[k] = (lo << 32) | col[k];
-        idx[k] = (uint32_t)k;
-    }
+k_iota(uint32_t *__restrict__ idx, uint64_t n) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) idx[k] = (uint32_t)k;
 }
 
 template <typename T>
@@ -251,27 +440,22 @@ k_sortrows_gather(const uint32_t *__restrict__ idx_s, const T *__restrict__ val,
         val_s[k] = val[idx_s[k]];
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_sortrows_cols(const uint64_t *__restrict__ key_s, uint64_t nnz, uint32_t *__restrict__ col) {
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (uint64_t)gridDim.x * blockDim.x)
-        col[k] = (uint32_t)key_s[k];
-}
-
-int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n_rows, size_t nnz, hipStream_t s) {
+int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n_rows, size_t nnz, uint32_t max_col,
+              hipStream_t s) {
     if (nnz == 0 || n_rows == 0) return SMH_OK;
-    Scratch tmp;
-    uint64_t *key = nullptr, *key_s = nullptr;
-    uint32_t *idx = nullptr, *idx_s = nullptr;
-    void *val_s = nullptr;
+    Scratch tmp_bufs;
+    uint32_t *col_s = nullptr, *idx = nullptr, *idx_s = nullptr;
+    char *val_s = nullptr;
     const size_t vs = dtype_size(dtype);
-    SMH_TRY(tmp.alloc(&key, nnz));
-    SMH_TRY(tmp.alloc(&key_s, nnz));
-    SMH_TRY(tmp.alloc(&idx, nnz));
-    SMH_TRY(tmp.alloc(&idx_s, nnz));
-    SMH_TRY(tmp.alloc((char **)&val_s, nnz * vs));
-    hipLaunchKernelGGL(k_sortrows_keys, dim3(grid_for(nnz)), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, (uint64_t)nnz, key, idx);
+    SMH_TRY(tmp_bufs.alloc(&col_s, nnz));
+    SMH_TRY(tmp_bufs.alloc(&idx, nnz));
+    SMH_TRY(tmp_bufs.alloc(&idx_s, nnz));
+    SMH_TRY(tmp_bufs.alloc(&val_s, nnz * vs));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(nnz)), dim3(kBlock), 0, s, idx, (uint64_t)nnz);
     SMH_HIP(hipGetLastError());
-    SMH_TRY(sort_pairs_u64_u32(key, key_s, idx, idx_s, nnz, 32 + bits_for((uint32_t)(n_rows - 1)), s));
+    // the CRS offsets are the segments; stable, so duplicates of a column keep their storage order
+    SMH_ROCPRIM(rocprim::segmented_radix_sort_pairs(tmp, bytes, col, col_s, idx, idx_s, (unsigned)nnz, (unsigned)n_rows, off, off + 1,
+                                                    0u, bits_for(max_col), s));
     if (dtype == SMH_F64)
         hipLaunchKernelGGL((k_sortrows_gather<double>), dim3(grid_for(nnz)), dim3(kBlock), 0, s, idx_s, (const double *)val,
                            (uint64_t)nnz, (double *)val_s);
@@ -279,8 +463,7 @@ int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n
         hipLaunchKernelGGL((k_sortrows_gather<float>), dim3(grid_for(nnz)), dim3(kBlock), 0, s, idx_s, (const float *)val,
                            (uint64_t)nnz, (float *)val_s);
     SMH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_sortrows_cols, dim3(grid_for(nnz)), dim3(kBlock), 0, s, key_s, (uint64_t)nnz, col);
-    SMH_HIP(hipGetLastError());
+    SMH_HIP(hipMemcpyAsync(col, col_s, nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     SMH_HIP(hipMemcpyAsync(val, val_s, nnz * vs, hipMemcpyDeviceToDevice, s));
     SMH_HIP(hipStreamSynchronize(s));
     return SMH_OK;

@@ -595,7 +595,7 @@ int smh_crs_assemble_dev(smh_dtype dtype, size_t n_ops, const uint32_t *rows_dev
 
 int smh_crs_sort_rows(smh_crs *m) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
-    SMH_TRY(sort_rows(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, m->stream));
+    SMH_TRY(sort_rows(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, m->max_col, m->stream));
     drop_colblock(m);  // the blocked copy keeps storage order inside a (row, block) pair
     return SMH_OK;
 }

@@ -75,7 +75,8 @@ int build_colblock(int dtype, const uint32_t *off, const uint32_t *col, const vo
 int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t *cols, const void *vals, const uint8_t *ops,
                       size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out, uint32_t **col_out,
                       void **val_out, hipStream_t s);
-int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n_rows, size_t nnz, hipStream_t s);
+int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n_rows, size_t nnz, uint32_t max_col,
+              hipStream_t s);
 // K1r (LDS x-ring): inspector, host plan, kernel
 struct RingPhase {
     uint32_t row_begin, row_end;  // rows of this phase (row_begin is a multiple of 64)
