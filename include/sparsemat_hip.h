@@ -139,7 +139,10 @@ int smh_crs_set_vector_chunks(smh_crs *m, int chunks);
 /* K1r, the pipelined VECTOR kernel with an LDS-resident sliding window of x: mode -1 =
  * automatic (whenever lanes <= 8; rows whose column span exceeds the ring gather from L2),
  * 0 = plain K1, 1 = same as -1.  The ring holds 16384 columns (64 KiB of f32 with two 512-thread
- * blocks per CU, 128 KiB of f64 with one 1024-thread block per CU). */
+ * blocks per CU, 128 KiB of f64 with one 1024-thread block per CU).  When at least a quarter of
+ * the rows run in ring phases the handle also keeps a u16 array with the low halves of the
+ * columns (2 bytes per entry, built on first use): ring phases only need `column mod 16384` and
+ * stream that array instead of the u32 columns (same arithmetic, bitwise identical results). */
 int smh_crs_set_ring(smh_crs *m, int mode);
 /* the K1r phase plan (integer structure, invariants checked in tests): phase_ptr_out needs
  * n_blocks+1 entries, phases_out 5 u32 per phase {row_begin,row_end,load_lo,load_hi,use_ring};

@@ -292,6 +292,20 @@ static int vector_uses_ring(smh_crs *m, bool *out) {
     // the pipelined body also wins without the ring (its global-gather phases), so it is the default
     // whenever its lane widths apply; mode 0 keeps the plain K1 kernel selectable
     *out = true;
+    // 16-bit columns for the ring phases: a ring slot is `column mod 16384`, so the low half of a column is all a
+    // ring phase reads -- 6 instead of 8 bytes per f32 entry from HBM.  One extra 2-byte-per-entry array, built once.
+    int want = m->use_col16;
+    if (const char *e = getenv("SMH_RING_COL16")) want = atoi(e) ? 1 : 0;  // tuning knob
+    const bool use16 = want == 1 || (want < 0 && m->ring_fraction >= 0.25);
+    if (use16 && !m->d_col16 && m->nnz) {
+        const size_t n_out = ((m->nnz + 3) & ~size_t(3)) + 4;
+        SMH_HIP(hipMalloc((void **)&m->d_col16, n_out * sizeof(uint16_t)));
+        SMH_TRY(launch_narrow_columns(m->d_col, m->nnz, m->d_col16, n_out, m->stream));
+        SMH_HIP(hipStreamSynchronize(m->stream));
+    } else if (!use16 && m->d_col16) {
+        (void)hipFree(m->d_col16);
+        m->d_col16 = nullptr;
+    }
     return SMH_OK;
 }
 
@@ -326,8 +340,8 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
             SMH_TRY(vector_uses_ring(m, &ring));
             if (ring)
                 // owned arrays are padded to a multiple of 4 entries; borrowed ones may end inside a 16-B chunk
-                return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz,
-                                         m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
+                return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_col16, m->d_val, x, y, m->n_rows,
+                                         m->nnz, m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
             return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, s);
         }
         case SMH_SPMV_SEQ:
@@ -597,6 +611,8 @@ int smh_crs_sort_rows(smh_crs *m) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(sort_rows(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, m->max_col, m->stream));
     drop_colblock(m);  // the blocked copy keeps storage order inside a (row, block) pair
+    (void)hipFree(m->d_col16);  // the 16-bit column array follows the storage order too: rebuilt on next use
+    m->d_col16 = nullptr;
     return SMH_OK;
 }
 
@@ -605,7 +621,7 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
-    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);
+    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16);
     (void)hipFree(m->d_stream_win);
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();

@@ -85,9 +85,12 @@ struct RingPhase {
 };
 int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t n_tiles, uint32_t *cmin,
                      uint32_t *cmax, hipStream_t s);
-int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
-                      void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
-                      const RingPhase *phases, hipStream_t s);
+// col16 (optional): the low halves of the columns, padded with zeros to a multiple of 4 entries plus one chunk; ring
+// phases then stream 2 instead of 4 bytes per column
+int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
+                      const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
+                      const uint32_t *phase_ptr, const RingPhase *phases, hipStream_t s);
+int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size_t n_out, hipStream_t s);
 // structure statistics / validation
 struct CrsStats {
     uint32_t max_row_len;
@@ -153,6 +156,8 @@ struct smh_crs {
     uint32_t *d_phase_ptr = nullptr;
     smh::RingPhase *d_phases = nullptr;
     int use_ring = -1;  // -1 automatic, 0 never, 1 always (when lanes <= 8), 2 always with the first K1r body
+    uint16_t *d_col16 = nullptr;  // K1r: 16-bit column array for the ring phases (lazy; null: not used)
+    int use_col16 = -1;           // -1 automatic (when at least a quarter of the rows are ring rows), 0 never, 1 always
     // staging for the host-pointer API (lazy, reused)
     void *d_x = nullptr, *d_y = nullptr;
     size_t d_x_cap = 0, d_y_cap = 0;

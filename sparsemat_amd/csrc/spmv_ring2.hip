@@ -22,6 +22,7 @@
 namespace smh {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -56,12 +57,20 @@ struct Unit {
 
 // colp/valp are wave-uniform (SGPR) base pointers of the phase's first chunk, rel a 32-bit element offset
 // from it: hipcc emits the saddr form `global_load_dwordx4 v, v_off, s[base]`, one address VGPR per load
-template <typename T>
-__device__ __forceinline__ void load_chunk_nb(const uint32_t *__restrict__ colp, const T *__restrict__ valp, uint32_t rel,
+// C16: colp points into the 16-bit column array (the low halves of the columns: all a ring phase needs, since the
+// ring slot of a column is `column mod 16384`) -- a chunk of 4 columns is then one 8-byte load instead of 16 bytes
+template <typename T, bool C16>
+__device__ __forceinline__ void load_chunk_nb(const void *__restrict__ colp, const T *__restrict__ valp, uint32_t rel,
                                               uint32_t (&c)[4], T (&v)[4]) {
-    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(
-        reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 4u)));
-    c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+    if constexpr (C16) {
+        const u32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(
+            reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 2u)));
+        c[0] = cc.x & 0xFFFFu; c[1] = cc.x >> 16; c[2] = cc.y & 0xFFFFu; c[3] = cc.y >> 16;
+    } else {
+        const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(
+            reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 4u)));
+        c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+    }
     if constexpr (sizeof(T) == 4) {
         const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
             reinterpret_cast<const char *>(valp) + SMH_R2_OFF(rel, 4u)));
@@ -105,8 +114,8 @@ __device__ __forceinline__ void row_bounds(uint32_t o0, uint32_t o1, int t, uint
 }
 
 // A lane group covers 4*LANES*CH entry slots of its row per pass: chunk (ch, j) = slots [4*(ch*LANES+j), +4)
-template <typename T, int LANES, int CH, int SB>
-__device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const uint32_t *__restrict__ colp,
+template <typename T, int LANES, int CH, int SB, bool C16>
+__device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const void *__restrict__ colp,
                                            const T *__restrict__ valp, uint32_t kb, uint32_t nnz_lim, uint32_t last_rel,
                                            uint32_t lane) {
     const uint32_t j = lane % LANES;
@@ -119,14 +128,14 @@ __device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const uint32_t *
         for (int ch = 0; ch < CH; ++ch) {
             uint32_t rel = (s & ~3u) - kb + 4u * (ch * LANES + j);
             rel = rel < last_rel ? rel : last_rel;  // lanes without work re-read a valid chunk (masked later)
-            load_chunk_nb<T>(colp, valp, rel, u.c[t * CH + ch], u.v[t * CH + ch]);
+            load_chunk_nb<T, C16>(colp, valp, rel, u.c[t * CH + ch], u.v[t * CH + ch]);
         }
     }
 }
 
-template <typename T, int LANES, int CH, int SB, int GM>
+template <typename T, int LANES, int CH, int SB, int GM, bool C16>
 __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t base, uint64_t row_end,
-                                             const uint32_t *__restrict__ colp, const T *__restrict__ valp,
+                                             const void *__restrict__ colp, const T *__restrict__ valp,
                                              const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
                                              uint32_t nnz_lim, uint32_t lane) {
     constexpr int RPS = kWave / LANES;
@@ -161,7 +170,7 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
         for (uint32_t rel = 4u * (CH * LANES + j); rel < len; rel += 4u * LANES) {
             uint32_t cc[4];
             T vv[4];
-            load_chunk_nb<T>(colp, valp, sa - kb + rel, cc, vv);
+            load_chunk_nb<T, C16>(colp, valp, sa - kb + rel, cc, vv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool in = rel + q < len;
@@ -187,8 +196,9 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
     if (lane < (uint32_t)(SB * RPS) && row < row_end) y[row] = out;
 }
 
-template <typename T, int LANES, int CH, int GM>
-__device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
+// col: the 32-bit column array, or (C16) the 16-bit one
+template <typename T, int LANES, int CH, int GM, bool C16>
+__device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, const void *__restrict__ col,
                                            const T *__restrict__ val, const T *__restrict__ x, const T *ring,
                                            T *__restrict__ y, uint64_t rb, uint64_t re, uint32_t nnz_lim,
                                            uint64_t last_chunk, uint32_t wave, uint32_t lane) {
@@ -203,39 +213,41 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
     uint32_t kb = __builtin_amdgcn_readfirstlane(off[rb]) & ~3u;
     kb = kb < (uint32_t)last_chunk ? kb : (uint32_t)last_chunk;
     const uint32_t last_rel = (uint32_t)last_chunk - kb;
-    const uint32_t *colp = col + kb;
+    const void *colp = reinterpret_cast<const char *>(col) + (size_t)kb * (C16 ? 2u : 4u);
     const T *valp = val + kb;
     Unit<T, SB * CH> A, B, N;  // N: only its offsets are used (the unit after next)
     load_offsets(A, off, base, re, lane);
     load_offsets(B, off, base + STRIDE, re, lane);
-    issue_unit<T, LANES, CH, SB>(A, colp, valp, kb, nnz_lim, last_rel, lane);
+    issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
     for (;;) {
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM, C16>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         // program order = age order: offsets(+2) older than chunks(+1); both stay in flight under consume
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
-        issue_unit<T, LANES, CH, SB>(B, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        issue_unit<T, LANES, CH, SB, C16>(B, colp, valp, kb, nnz_lim, last_rel, lane);
+        consume_unit<T, LANES, CH, SB, GM, C16>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         A.o0 = N.o0; A.o1 = N.o1;
         base += STRIDE;
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM, C16>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
-        issue_unit<T, LANES, CH, SB>(A, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
+        consume_unit<T, LANES, CH, SB, GM, C16>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         B.o0 = N.o0; B.o1 = N.o1;
         base += STRIDE;
     }
 }
 
-template <typename T, int LANES, int CH>
+// C16: ring phases stream the 16-bit column array `col16` (6 instead of 8 bytes per f32 entry); phases with global
+// gathers need whole columns and keep reading `col`
+template <typename T, int LANES, int CH, bool C16>
 __global__ void __launch_bounds__(Ring2Cfg<T>::kThreads, 4)  // 4 waves per SIMD: 16 waves per CU for either dtype
-k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
-             const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
+k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint16_t *__restrict__ col16,
+             const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
              const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];  // kRingEntries * sizeof(T), dynamic
     T *ring = reinterpret_cast<T *>(ring_raw);
@@ -257,11 +269,12 @@ k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
         // gather mode of the phase: 1 = LDS ring, 0 = L1/L2-cached global gathers, 2 = L1-bypassing (nt) global
         // gathers for phases whose columns have no locality to keep in the 32 KiB L1
         if (ph.use_ring == 1)
-            phase_rows<T, LANES, CH, 1>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 1, C16>(off, C16 ? (const void *)col16 : (const void *)col, val, x, ring, y, ph.row_begin,
+                                             ph.row_end, nnz_lim, last_chunk, wave, lane);
         else if (ph.use_ring == 2)
-            phase_rows<T, LANES, CH, 2>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 2, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
         else
-            phase_rows<T, LANES, CH, 0>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 0, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
     }
 }
 
@@ -279,10 +292,26 @@ __global__ void k_ring2_tail(const uint32_t *__restrict__ off, const uint32_t *_
     }
 }
 
+// col16[k] = low half of col[k] (k < nnz), zero padding up to the next multiple of 4 entries and one chunk beyond
+__global__ void __launch_bounds__(kBlock)
+k_narrow_columns(const uint32_t *__restrict__ col, uint64_t nnz, uint64_t n_out, uint16_t *__restrict__ col16) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_out; k += (uint64_t)gridDim.x * blockDim.x)
+        col16[k] = k < nnz ? (uint16_t)col[k] : (uint16_t)0;
+}
+
+int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size_t n_out, hipStream_t s) {
+    if (n_out == 0) return SMH_OK;
+    uint64_t blocks = (n_out + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_narrow_columns, dim3((unsigned)blocks), dim3(kBlock), 0, s, col, (uint64_t)nnz, (uint64_t)n_out, col16);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
 template <typename T>
-static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y,
-                          size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
-                          const RingPhase *phases, hipStream_t s) {
+static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16, const T *val,
+                          const T *x, T *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
+                          const uint32_t *phase_ptr, const RingPhase *phases, hipStream_t s) {
     // entries the streaming kernel may touch: everything when the arrays are padded to a multiple of 4,
     // else only whole chunks (the rest goes to k_ring2_tail)
     const uint64_t nnz_lim = padded ? nnz : (nnz & ~uint64_t(3));
@@ -293,16 +322,20 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
         dim3 grid(n_blocks), block(Ring2Cfg<T>::kThreads);
         constexpr size_t lds_bytes = (size_t)kRingEntries * sizeof(T);
         // dynamic LDS above 64 KiB must be allowed per kernel (idempotent, cheap)
-#define SMH_R2_LAUNCH(L, C)                                                                                              \
+#define SMH_R2_LAUNCH1(L, C, N)                                                                                          \
     do {                                                                                                                 \
         static bool attr_set = false; /* once per instantiation (and never inside a stream capture) */                  \
         if (!attr_set) {                                                                                                 \
-            SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C>),                           \
+            SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C, N>),                        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                    \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_spmv_ring2<T, L, C>), grid, block, lds_bytes, s, off, col, val, x, y, (uint32_t)nnz_lim,   \
-                           last_chunk, phase_ptr, phases);                                                               \
+        hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N>), grid, block, lds_bytes, s, off, col, col16, val, x, y,            \
+                           (uint32_t)nnz_lim, last_chunk, phase_ptr, phases);                                            \
+    } while (0)
+#define SMH_R2_LAUNCH(L, C)                                            \
+    do {                                                               \
+        if (col16) SMH_R2_LAUNCH1(L, C, true); else SMH_R2_LAUNCH1(L, C, false); \
     } while (0)
         switch (lanes * 16 + chunks) {
             case 1 * 16 + 1: SMH_R2_LAUNCH(1, 1); break;
@@ -316,6 +349,7 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
                 return fail(SMH_ERR_INVALID, "ring kernel: unsupported (lanes per row, chunks per lane) = (%d, %d)", lanes, chunks);
         }
 #undef SMH_R2_LAUNCH
+#undef SMH_R2_LAUNCH1
         SMH_HIP(hipGetLastError());
     }
     if (nnz_lim != nnz) {
@@ -325,15 +359,15 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
     return SMH_OK;
 }
 
-int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const void *val, const void *x,
-                      void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks, const uint32_t *phase_ptr,
-                      const RingPhase *phases, hipStream_t s) {
+int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
+                      const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
+                      const uint32_t *phase_ptr, const RingPhase *phases, hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
     if (dtype == SMH_F64)
-        return launch_ring2_t<double>(lanes, chunks, off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz,
-                                      padded, n_blocks, phase_ptr, phases, s);
-    return launch_ring2_t<float>(lanes, chunks, off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded,
-                                 n_blocks, phase_ptr, phases, s);
+        return launch_ring2_t<double>(lanes, chunks, off, col, col16, (const double *)val, (const double *)x, (double *)y, n_rows,
+                                      nnz, padded, n_blocks, phase_ptr, phases, s);
+    return launch_ring2_t<float>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x, (float *)y, n_rows, nnz,
+                                 padded, n_blocks, phase_ptr, phases, s);
 }
 
 }  // namespace smh

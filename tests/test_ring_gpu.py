@@ -95,6 +95,20 @@ def test_ring_mixed_phases_random(gpu, dtype):
         y = m.mvp(x, variant="vector")
         assert_spmv_close(y, off, col, val, x, "mixed lanes%d" % lanes)
         assert np.array_equal(y, m.mvp(x, variant="vector")), "ring kernel is bitwise reproducible"
+        # ring phases stream 16-bit columns (low halves; columns here go up to 300 000): the very same arithmetic
+        import os
+        try:
+            os.environ["SMH_RING_COL16"] = "0"
+            y32 = m.mvp(x, variant="vector")
+            os.environ["SMH_RING_COL16"] = "1"
+            y16 = m.mvp(x, variant="vector")
+        finally:
+            os.environ.pop("SMH_RING_COL16", None)
+        assert np.array_equal(y32, y) and np.array_equal(y16, y)
+    # sort_rows reorders the columns: the 16-bit copy must follow
+    m.sort_rows()
+    s_col, s_val = oracle.crs_sort_rows(off, col, val)
+    assert_spmv_close(m.mvp(x, variant="vector"), off, s_col, s_val, x, "after sort_rows")
 
 
 def test_ring_small_and_edge_shapes(gpu):
