@@ -147,6 +147,10 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // XCD (tiles at one in-plane position of all planes back to back, so that the three uses of an x entry coincide):
 // 1.95 ms vs 1.82 ms -- the concurrently active tiles then stream from 64 distant regions per array.  rocprofv3
 // (profiles/r01_pmc_lap512_stream.json): L2 fetches 9.9 GB for 8.6 GB algorithmic reads, 87 % of wave cycles waiting.
+// (c) 16-bit column codes (interval << 14 | offset, four column intervals per tile from the inspector, decoded with
+// three selects and an add): 25 % less HBM traffic, yet 1.88-1.93 ms against 1.63-1.69 ms with the u32 columns on one
+// box (profiles/r01_ab_stream_col16_codes_dropped.log) -- this kernel is bound by latency and instruction issue, not
+// by bytes (unlike K1r, where the same idea pays: the ring slot needs no decode at all).
 #ifndef SMH_STREAM_MIN_WAVES
 #define SMH_STREAM_MIN_WAVES 0
 #endif
