@@ -159,12 +159,15 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 #else
 #define SMH_STREAM_BOUNDS __launch_bounds__(kBlock)
 #endif
-template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true>
+// CAP: entries of the LDS product stage (a pass).  (A CAP = 2048 body for sparse tiles -- 44 instead of 68 VGPRs, 8
+// waves per SIMD, half the LDS -- was measured on the 512^3 Laplacian: 1.84 / 1.79 ms against 1.82 / 1.66 ms: occupancy
+// is not what limits this kernel either.)
+template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap>
 __global__ void SMH_STREAM_BOUNDS
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
               uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials) {
-    __shared__ T s_prod[kStreamCap + kStreamCap / 32 + 8];
+    __shared__ T s_prod[CAP + CAP / 32 + 8];
     __shared__ T s_x[XWIN ? kStreamXWin : 1];
     // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of tiles
     const uint64_t q = n_tiles >> 3, rm = n_tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -213,10 +216,10 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     // thread: ALL of a thread's chunk loads are issued before the first gather (they sit in the memory queue
     // together), then all gathers.  A row that straddles passes keeps its accumulator: the order of the adds is
     // the storage order whatever the number of passes.
-    constexpr int NIT = kStreamCap / (4 * kBlock) + 1;
+    constexpr int NIT = CAP / (4 * kBlock) + 1;
     uint32_t ps = k0;
     do {
-        const uint32_t pe = MULTI && k1 - ps > (uint32_t)kStreamCap ? ps + (uint32_t)kStreamCap : k1;
+        const uint32_t pe = MULTI && k1 - ps > (uint32_t)CAP ? ps + (uint32_t)CAP : k1;
         // everything per lane is a 32-bit position relative to the pass's aligned start `pa` (tile-uniform)
         const uint64_t pa = (uint64_t)(ps & ~3u);
         const uint32_t *__restrict__ colp = col + pa;
