@@ -232,7 +232,7 @@ static int ensure_stream_windows(smh_crs *m) {
         uint32_t *d_count = nullptr, h_count = 0;
         SMH_HIP(hipMalloc((void **)&m->d_stream_win, n_tiles * 8 * sizeof(uint32_t)));
         SMH_HIP(hipMalloc((void **)&d_count, sizeof(uint32_t)));
-        int rc = launch_stream_windows(m->d_off, m->d_col, m->n_rows, m->d_stream_win, d_count, m->stream);
+        int rc = launch_stream_windows(m->d_off, m->d_col, m->n_rows, false, m->d_stream_win, d_count, m->stream);
         hipError_t e = hipSuccess;
         if (rc == SMH_OK) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, m->stream);
         if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);
@@ -282,6 +282,43 @@ static int ensure_colblock(smh_crs *m) {
     m->cb_single_pass = worst <= (uint32_t)kStreamCap;  // else 256-row tiles, several passes where needed
     m->cb_built = true;
     return SMH_OK;
+}
+
+// K1s: 16-bit column codes, once per matrix.  Kept only when EVERY tile has a description (stencils, bands): the kernel
+// variant then has no per-tile branch; any other matrix streams its u32 columns as before and nothing stays allocated.
+static int ensure_stream_codes(smh_crs *m) {
+    if (m->stream_coded) return SMH_OK;
+    m->stream_coded = true;
+    const size_t n_tiles = (m->n_rows + kStreamRows - 1) / kStreamRows;
+    if (n_tiles == 0 || m->nnz == 0) return SMH_OK;
+    uint32_t *d_count = nullptr, h_count = 0;
+    SMH_HIP(hipMalloc((void **)&m->d_stream_cwin, n_tiles * 8 * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&d_count, sizeof(uint32_t)));
+    int rc = launch_stream_windows(m->d_off, m->d_col, m->n_rows, true, m->d_stream_cwin, d_count, m->stream);
+    hipError_t e = hipSuccess;
+    if (rc == SMH_OK) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, m->stream);
+    if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(d_count);
+    if (rc == SMH_OK && e != hipSuccess) rc = hip_fail(e, "stream code table readback", __FILE__, __LINE__);
+    SMH_TRY(rc);
+    if ((size_t)h_count != n_tiles) {  // some tile's columns need more than 4 intervals of 16384
+        (void)hipFree(m->d_stream_cwin);
+        m->d_stream_cwin = nullptr;
+        return SMH_OK;
+    }
+    const size_t n_out = ((m->nnz + 3) & ~size_t(3)) + 4;
+    SMH_HIP(hipMalloc((void **)&m->d_stream_code, n_out * sizeof(uint16_t)));
+    SMH_HIP(hipMemsetAsync(m->d_stream_code, 0, n_out * sizeof(uint16_t), m->stream));
+    SMH_TRY(launch_stream_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, m->d_stream_code, m->stream));
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    return SMH_OK;
+}
+
+static void drop_stream_codes(smh_crs *m) {
+    (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
+    m->d_stream_cwin = nullptr;
+    m->d_stream_code = nullptr;
+    m->stream_coded = false;
 }
 
 // does the VECTOR family run as K1r (LDS x-ring) for this matrix?
@@ -358,8 +395,19 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
             // tiles of any density (loop-free body when the create-time statistic says that none overflows)
             const int rpt = win ? 1 : stream_rpt(m);
             const bool single_pass = m->have_stats && (rpt == 2 || m->max_tile_entries <= (uint32_t)kStreamCap);
+            // 16-bit column codes when every tile's columns fall into <= 4 intervals of <= 16384 (stencils, bands)
+            const uint16_t *code = nullptr;
+            const uint32_t *cwin = nullptr;
+            const char *c16_env = getenv("SMH_STREAM_C16");  // tuning knob: 0 = always the u32 columns
+            // (single-pass tiles only: on dense multi-pass tiles -- banded C2 through K1s -- the decode costs more than
+            // the bytes save, 0.83 vs 0.80 ms)
+            if (!(c16_env && atoi(c16_env) == 0) && !win && rpt == 1 && single_pass) {
+                SMH_TRY(ensure_stream_codes(m));
+                code = m->d_stream_code;
+                cwin = m->d_stream_code ? m->d_stream_cwin : nullptr;
+            }
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt,
-                                      single_pass, dot_partials, s);
+                                      single_pass, dot_partials, code, cwin, s);
         }
         case SMH_SPMV_COLBLOCK: {
             SMH_TRY(ensure_colblock(m));
@@ -611,8 +659,9 @@ int smh_crs_sort_rows(smh_crs *m) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(sort_rows(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, m->max_col, m->stream));
     drop_colblock(m);  // the blocked copy keeps storage order inside a (row, block) pair
-    (void)hipFree(m->d_col16);  // the 16-bit column array follows the storage order too: rebuilt on next use
+    (void)hipFree(m->d_col16);  // the 16-bit column arrays follow the storage order too: rebuilt on next use
     m->d_col16 = nullptr;
+    drop_stream_codes(m);
     return SMH_OK;
 }
 
@@ -622,7 +671,7 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
     (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16);
-    (void)hipFree(m->d_stream_win);
+    (void)hipFree(m->d_stream_win); (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
@@ -767,7 +816,7 @@ int smh_crs_prepare(smh_crs *m, int variant) {
         }
         case SMH_SPMV_MERGE: return ensure_merge_ws(m);
         case SMH_SPMV_COLBLOCK: return ensure_colblock(m);
-        case SMH_SPMV_STREAM: return m->use_stream_win == 1 ? ensure_stream_windows(m) : SMH_OK;
+        case SMH_SPMV_STREAM: return m->use_stream_win == 1 ? ensure_stream_windows(m) : ensure_stream_codes(m);
         case SMH_SPMV_SEQ: return SMH_OK;
         default: return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);
     }

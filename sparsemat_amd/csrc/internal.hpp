@@ -42,6 +42,7 @@ constexpr int kRingEntries = 16384;    // K1r: columns of x the LDS ring holds (
 constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
 constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
 constexpr int kStreamXWin = 3072;      // K1s-w: x entries of a tile's column intervals staged in LDS
+constexpr int kStreamCodeWidth = 16384;  // K1s 16-bit column codes: columns per interval (14 bits) x 4 intervals
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 // K1 / SEQ
@@ -59,10 +60,14 @@ int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rows_per_thread,
                        bool single_pass /* no tile holds more than kStreamCap entries */,
-                       void *dot_partials /* optional: x.y per tile, stream_tiles() entries */, hipStream_t s);
+                       void *dot_partials /* optional: x.y per tile, stream_tiles() entries */,
+                       const uint16_t *code, const uint32_t *cwin /* optional: 16-bit column codes + their interval table */,
+                       hipStream_t s);
 size_t stream_tiles(size_t n_rows, int rows_per_thread);
-int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,
-                          hipStream_t s);
+int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, bool for_codes, uint32_t *win,
+                          uint32_t *d_count, hipStream_t s);
+int launch_stream_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint16_t *code,
+                        hipStream_t s);
 int launch_stream_max_tile(const uint32_t *off, size_t n_rows, size_t tile_rows, uint32_t *d_out, hipStream_t s);
 // K2c (column-blocked CSR; each block runs the K1s kernel)
 int launch_spmv_stream_block(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
@@ -138,6 +143,10 @@ struct smh_crs {
     double stream_win_fraction = 0.0;  // share of tiles whose columns fit 4 intervals of <= kStreamXWin entries
     int use_stream_win = -1;           // -1/0 never (measured slower), 1 always
     int stream_rows_per_thread = 0;    // 0 automatic (2 when every 512-row tile fits), 1 force one
+    // K1s 16-bit column codes (lazy; kept only when every tile has a description)
+    bool stream_coded = false;         // inspected
+    uint32_t *d_stream_cwin = nullptr; // 8 u32 per 256-row tile
+    uint16_t *d_stream_code = nullptr; // one u16 per entry
     // K2c column-blocked copy (lazy)
     bool cb_built = false;
     uint32_t cb_forced_shift = 0;  // 0 automatic (2 MiB of x per block)

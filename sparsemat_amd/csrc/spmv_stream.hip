@@ -31,6 +31,7 @@
 namespace smh {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -43,9 +44,13 @@ __device__ __forceinline__ double st_add(double a, double b) { return __dadd_rn(
 
 // ---- inspector: up to 4 column intervals per tile -------------------------------------------------------
 // win[8*t + 2k], win[8*t + 2k + 1] = [lo, hi) of interval k (sorted, disjoint; hi == lo: unused).  All zero:
-// the tile has no window (gathers go to L2).
+// the tile has no window (gathers go to L2).  Limits: a tile qualifies when it holds at most max_entries entries,
+// every interval is at most max_width columns wide and the intervals hold at most max_total columns together
+// (K1s-w: what fits the LDS stage; 16-bit column codes: 16384 per interval, nothing else; there a tile WITHOUT
+// entries counts as described).
 __global__ void __launch_bounds__(kBlock)
 k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, uint64_t n_rows, uint64_t n_tiles,
+                 uint64_t max_entries, uint64_t max_width, uint64_t max_total, bool count_empty,
                  uint32_t *__restrict__ win, uint32_t *__restrict__ n_windowed) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
@@ -54,7 +59,7 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
         const uint64_t r0 = t * kStreamRows, r1 = r0 + kStreamRows < n_rows ? r0 + kStreamRows : n_rows;
         const uint64_t k0 = off[r0], k1 = off[r1];
         uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-        bool ok = k1 > k0 && k1 - k0 <= (uint64_t)kStreamCap;
+        bool ok = k1 > k0 && k1 - k0 <= max_entries;
         if (ok) {
             uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;
             for (uint64_t k = k0 + lane; k < k1; k += kWave) {
@@ -68,7 +73,7 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
                 cmax = max(cmax, (uint32_t)__shfl_xor(cmax, o, kWave));
             }
             const uint64_t span = (uint64_t)cmax - cmin + 1;
-            if (span <= (uint64_t)kStreamXWin) {
+            if (span <= max_width && span <= max_total) {
                 lo[0] = cmin; hi[0] = cmax + 1;
             } else {
                 // occupancy of 64 equal buckets over [cmin, cmax]; the 3 widest empty runs split the columns
@@ -112,7 +117,7 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
                     for (int sgm = 0; sgm < 4; ++sgm)
                         if (sgm < nseg && b >= seg_b[sgm] && b < seg_e[sgm]) { smin[sgm] = min(smin[sgm], c); smax[sgm] = max(smax[sgm], c); }
                 }
-                uint64_t total = 0;
+                uint64_t total = 0, widest = 0;
 #pragma unroll
                 for (int sgm = 0; sgm < 4; ++sgm) {
 #pragma unroll
@@ -120,16 +125,21 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
                         smin[sgm] = min(smin[sgm], (uint32_t)__shfl_xor(smin[sgm], o, kWave));
                         smax[sgm] = max(smax[sgm], (uint32_t)__shfl_xor(smax[sgm], o, kWave));
                     }
-                    if (sgm < nseg && smin[sgm] <= smax[sgm]) { lo[sgm] = smin[sgm]; hi[sgm] = smax[sgm] + 1; total += hi[sgm] - lo[sgm]; }
+                    if (sgm < nseg && smin[sgm] <= smax[sgm]) {
+                        lo[sgm] = smin[sgm]; hi[sgm] = smax[sgm] + 1;
+                        const uint64_t wd = (uint64_t)hi[sgm] - lo[sgm];
+                        total += wd;
+                        widest = wd > widest ? wd : widest;
+                    }
                 }
-                ok = total <= (uint64_t)kStreamXWin;
+                ok = total <= max_total && widest <= max_width;
             }
         }
         if (lane < 8) {
             const int k = lane >> 1;
             win[8 * t + lane] = ok ? ((lane & 1) ? hi[k] : lo[k]) : 0u;
         }
-        if (lane == 0 && ok) atomicAdd(n_windowed, 1u);  // integer count: exact
+        if (lane == 0 && (ok || (count_empty && k1 == k0))) atomicAdd(n_windowed, 1u);  // integer count: exact
     }
 }
 
@@ -147,10 +157,10 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // XCD (tiles at one in-plane position of all planes back to back, so that the three uses of an x entry coincide):
 // 1.95 ms vs 1.82 ms -- the concurrently active tiles then stream from 64 distant regions per array.  rocprofv3
 // (profiles/r01_pmc_lap512_stream.json): L2 fetches 9.9 GB for 8.6 GB algorithmic reads, 87 % of wave cycles waiting.
-// (c) 16-bit column codes (interval << 14 | offset, four column intervals per tile from the inspector, decoded with
-// three selects and an add): 25 % less HBM traffic, yet 1.88-1.93 ms against 1.63-1.69 ms with the u32 columns on one
-// box (profiles/r01_ab_stream_col16_codes_dropped.log) -- this kernel is bound by latency and instruction issue, not
-// by bytes (unlike K1r, where the same idea pays: the ring slot needs no decode at all).
+// 16-bit column codes (C16 below) DO pay -- 1.57 ms against 1.70-1.86 ms on one box (profiles/r01_ab_stream_col16_codes.log)
+// -- but only with the decode deferred to the gather phase: the first attempt decoded right after each chunk load,
+// which put a wait between the chunk loads, and lost (1.88-1.93 ms against 1.63-1.69 ms,
+// profiles/r01_ab_stream_col16_codes_dropped.log).
 #ifndef SMH_STREAM_MIN_WAVES
 #define SMH_STREAM_MIN_WAVES 0
 #endif
@@ -162,11 +172,22 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // CAP: entries of the LDS product stage (a pass).  (A CAP = 2048 body for sparse tiles -- 44 instead of 68 VGPRs, 8
 // waves per SIMD, half the LDS -- was measured on the 512^3 Laplacian: 1.84 / 1.79 ms against 1.82 / 1.66 ms: occupancy
 // is not what limits this kernel either.)
-template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap>
+// C16 (only when EVERY tile with entries has a code-table description): the kernel streams 16-bit column codes
+// (`code`: interval << 14 | offset; intervals in `cwin`, 8 u32 per 256-row tile) instead of the u32 columns -- 2 of
+// 8 bytes per f32 entry less from HBM.  The raw code words stay in registers through the load phase (decoding right
+// after each load would put a wait between the chunk loads) and are turned into columns in the gather phase.
+__device__ __forceinline__ uint32_t decode_col(uint32_t cd, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+    const uint32_t q = cd >> 14;
+    return (q == 0u ? b0 : q == 1u ? b1 : q == 2u ? b2 : b3) + (cd & 16383u);
+}
+
+template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false>
 __global__ void SMH_STREAM_BOUNDS
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
-              uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials) {
+              uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials,
+              const uint16_t *__restrict__ code, const uint32_t *__restrict__ cwin) {
+    static_assert(!C16 || (RPT == 1 && !XWIN), "the code table describes 256-row tiles");
     __shared__ T s_prod[CAP + CAP / 32 + 8];
     __shared__ T s_x[XWIN ? kStreamXWin : 1];
     // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of tiles
@@ -217,6 +238,11 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     // together), then all gathers.  A row that straddles passes keeps its accumulator: the order of the adds is
     // the storage order whatever the number of passes.
     constexpr int NIT = CAP / (4 * kBlock) + 1;
+    uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;  // C16: starts of the tile's column intervals (tile-uniform)
+    if constexpr (C16) {
+        const uint32_t *w = cwin + 8 * tile;  // scalar loads
+        cb0 = w[0]; cb1 = w[2]; cb2 = w[4]; cb3 = w[6];
+    }
     uint32_t ps = k0;
     do {
         const uint32_t pe = MULTI && k1 - ps > (uint32_t)CAP ? ps + (uint32_t)CAP : k1;
@@ -234,8 +260,13 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
             if (j < hi) {
                 if (j + 4 <= rd) {
-                    const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(colp + j));
-                    c[it][0] = cc.x; c[it][1] = cc.y; c[it][2] = cc.z; c[it][3] = cc.w;
+                    if constexpr (C16) {  // two packed words, untouched until the gather phase
+                        const u32x2 cw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(code + pa + j));
+                        c[it][0] = cw.x; c[it][1] = cw.y;
+                    } else {
+                        const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(colp + j));
+                        c[it][0] = cc.x; c[it][1] = cc.y; c[it][2] = cc.z; c[it][3] = cc.w;
+                    }
                     if constexpr (sizeof(T) == 4) {
                         const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(valp + j));
                         v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
@@ -248,7 +279,12 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const bool in = j + e < nn;
-                        c[it][e] = in ? colp[j + e] : 0u;
+                        if constexpr (C16) {
+                            const uint32_t cd = in ? (uint32_t)code[pa + j + e] : 0u;
+                            c[it][e >> 1] = (e & 1) ? (c[it][e >> 1] | (cd << 16)) : cd;
+                        } else {
+                            c[it][e] = in ? colp[j + e] : 0u;
+                        }
                         v[it][e] = in ? valp[j + e] : T(0);
                     }
                 }
@@ -267,6 +303,9 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
                         const uint32_t cc = c[it][e];
                         const uint32_t sh = cc >= lo3 ? sh3 : (cc >= lo2 ? sh2 : (cc >= lo1 ? sh1 : sh0));
                         xv[it][e] = s_x[cc - sh];
+                    } else if constexpr (C16) {
+                        const uint32_t cd = (e & 1) ? (c[it][e >> 1] >> 16) : (c[it][e >> 1] & 0xFFFFu);
+                        xv[it][e] = x[decode_col(cd, cb0, cb1, cb2, cb3)];
                     } else {
                         xv[it][e] = x[c[it][e]];
                     }
@@ -332,24 +371,25 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
 template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
                            size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
-                           hipStream_t s) {
+                           const uint16_t *code, const uint32_t *cwin, hipStream_t s) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
-#define SMH_ST_LAUNCH(XW, R, D, M)                                                                                       \
-    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
-                       (uint64_t)nnz, readable, n_tiles, win, dot_partials)
-#define SMH_ST_PICK(XW, R)                                                        \
+#define SMH_ST_LAUNCH(XW, R, D, M, C)                                                                                    \
+    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M, kStreamCap, C>), grid, block, 0, s, off, col, val, x, y,    \
+                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin)
+#define SMH_ST_PICK(XW, R, C)                                                     \
     do {                                                                          \
         if (single_pass) {                                                        \
-            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, false); else SMH_ST_LAUNCH(XW, R, false, false); \
+            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, false, C); else SMH_ST_LAUNCH(XW, R, false, false, C); \
         } else {                                                                  \
-            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, true); else SMH_ST_LAUNCH(XW, R, false, true);   \
+            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, true, C); else SMH_ST_LAUNCH(XW, R, false, true, C);   \
         }                                                                         \
     } while (0)
-    if (win) SMH_ST_PICK(true, 1);  // the window table describes 256-row tiles
-    else if (rpt == 2) SMH_ST_PICK(false, 2);
-    else SMH_ST_PICK(false, 1);
+    if (win) SMH_ST_PICK(true, 1, false);  // the window table describes 256-row tiles
+    else if (rpt == 2) SMH_ST_PICK(false, 2, false);
+    else if (code && cwin) SMH_ST_PICK(false, 1, true);  // 16-bit column codes (every tile described)
+    else SMH_ST_PICK(false, 1, false);
 #undef SMH_ST_PICK
 #undef SMH_ST_LAUNCH
     SMH_HIP(hipGetLastError());
@@ -367,8 +407,9 @@ static int launch_stream_block_t(const uint32_t *off, const uint32_t *col, const
     const dim3 grid((unsigned)n_tiles), block(kBlock);
 #define SMH_SB_LAUNCH(R, A, M)                                                                                          \
     hipLaunchKernelGGL((k_spmv_stream<T, false, R, false, A, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
-                       (uint64_t)nnz_total, readable, n_tiles, (const uint32_t *)nullptr, (T *)nullptr)
-#define SMH_SB_PICK(R)                                                                       \
+                       (uint64_t)nnz_total, readable, n_tiles, (const uint32_t *)nullptr, (T *)nullptr,         \
+                       (const uint16_t *)nullptr, (const uint32_t *)nullptr)
+#define SMH_SB_PICK(R)                                                                      \
     do {                                                                                     \
         if (single_pass) { if (acc) SMH_SB_LAUNCH(R, true, false); else SMH_SB_LAUNCH(R, false, false); } \
         else             { if (acc) SMH_SB_LAUNCH(R, true, true);  else SMH_SB_LAUNCH(R, false, true);  } \
@@ -404,24 +445,58 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
-                       void *dot_partials, hipStream_t s) {
+                       void *dot_partials, const uint16_t *code, const uint32_t *cwin, hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
     if (dtype == SMH_F64)
         return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
-                                       rpt, single_pass, (double *)dot_partials, s);
+                                       rpt, single_pass, (double *)dot_partials, code, cwin, s);
     return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
-                                  single_pass, (float *)dot_partials, s);
+                                  single_pass, (float *)dot_partials, code, cwin, s);
 }
 
-int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count,
-                          hipStream_t s) {
+// for_codes: intervals for the 16-bit column codes (any tile size, <= 16384 columns per interval; tiles without
+// entries count as described) instead of the K1s-w LDS windows (single-pass tiles, <= kStreamXWin columns in total)
+int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, bool for_codes, uint32_t *win,
+                          uint32_t *d_count, hipStream_t s) {
     const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
     SMH_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
     if (n_tiles == 0) return SMH_OK;
     uint64_t blocks = (n_tiles * kWave + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles, win,
-                       d_count);
+    const uint64_t max_entries = for_codes ? ~uint64_t(0) : (uint64_t)kStreamCap;
+    const uint64_t max_width = for_codes ? (uint64_t)kStreamCodeWidth : (uint64_t)kStreamXWin;
+    const uint64_t max_total = for_codes ? ~uint64_t(0) : (uint64_t)kStreamXWin;
+    hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles,
+                       max_entries, max_width, max_total, for_codes, win, d_count);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+// 16-bit column codes: code = interval << 14 | (column - interval start), intervals from the tile's table entry
+__global__ void __launch_bounds__(kBlock)
+k_stream_codes(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint32_t *__restrict__ win,
+               uint64_t n_rows, uint64_t n_tiles, uint16_t *__restrict__ code) {
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t *w = win + 8 * t;
+        const uint32_t a0 = w[0], a1 = w[2], e1 = w[3], a2 = w[4], e2 = w[5], a3 = w[6], e3 = w[7];
+        const uint64_t r0 = t * kStreamRows, r1 = r0 + kStreamRows < n_rows ? r0 + kStreamRows : n_rows;
+        const uint64_t k0 = off[r0], k1 = off[r1];
+        for (uint64_t k = k0 + threadIdx.x; k < k1; k += kBlock) {
+            const uint32_t c = col[k];
+            // the used intervals are a prefix of the table, sorted, disjoint, and contain every column of the tile
+            const uint32_t q = (uint32_t)(e1 > a1 && c >= a1) + (uint32_t)(e2 > a2 && c >= a2) + (uint32_t)(e3 > a3 && c >= a3);
+            const uint32_t base = q == 3u ? a3 : q == 2u ? a2 : q == 1u ? a1 : a0;
+            code[k] = (uint16_t)((q << 14) | (c - base));
+        }
+    }
+}
+
+int launch_stream_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint16_t *code,
+                        hipStream_t s) {
+    const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
+    if (n_tiles == 0) return SMH_OK;
+    const uint64_t blocks = n_tiles < 16384 ? n_tiles : 16384;
+    hipLaunchKernelGGL(k_stream_codes, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, win, (uint64_t)n_rows, n_tiles, code);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }

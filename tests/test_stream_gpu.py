@@ -143,3 +143,64 @@ def test_stream_edge_shapes(gpu):
         x = rng.uniform(-1, 1, 100).astype(f)
         m = sm.SparseMatCRS.from_raw_parts(n_rows, 100, off, col, val)
         assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
+
+
+def _with_codes(flag, fn):
+    import os
+    try:
+        os.environ["SMH_STREAM_C16"] = flag
+        return fn()
+    finally:
+        os.environ.pop("SMH_STREAM_C16", None)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_stream_16bit_column_codes_bit_exact(gpu, dtype):
+    """When every tile's columns fall into <= 4 intervals of <= 16384 the kernel streams 16-bit codes (interval << 14
+    | offset) instead of the u32 columns; the rebuilt column is the same number, so the product stays bit-exact --
+    stencils (3 intervals per tile, columns far beyond 65535), bands with empty rows and dense multi-pass tiles, a
+    matrix where some tiles do not qualify (u32 columns stay in use), borrowed arrays ending inside a chunk."""
+    rng = np.random.default_rng(77)
+    cases = []
+    g = (70, 66, 40)  # 184 800 rows: the +-plane neighbours are 4 620 columns away
+    off, col, val = oracle.laplace3d(*g, dtype)
+    cases.append(("laplace3d", g[0] * g[1] * g[2], g[0] * g[1] * g[2], off, col, val))
+    n = 120_000   # band of +-3000 around the diagonal, unsorted with duplicates, empty rows, a dense stretch
+    lens = rng.integers(0, 30, n)
+    lens[5000:5600] = 0
+    lens[70_000:70_300] = 90
+    off = np.zeros(n + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    centers = np.repeat(np.arange(n), lens)
+    col = np.clip(centers + rng.integers(-3000, 3000, len(centers)), 0, n - 1).astype(np.uint32)
+    cases.append(("band", n, n, off, col, rng.uniform(-1, 1, len(col)).astype(dtype)))
+    n_rows, n_cols = 30_000, 5_000_000   # only some tiles qualify
+    lens = rng.integers(0, 12, n_rows)
+    off = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = np.empty(int(off[-1]), np.uint32)
+    for i in range(n_rows):
+        a, b = off[i], off[i + 1]
+        if (i // 256) % 5 == 4:
+            col[a:b] = rng.integers(0, n_cols, b - a)
+        else:
+            col[a:b] = 150 * i + rng.choice([0, 70_000, 2_000_000], b - a) + rng.integers(0, 3000, b - a)
+    col = np.minimum(col, n_cols - 1).astype(np.uint32)
+    cases.append(("mixed", n_rows, n_cols, off, col, rng.uniform(-1, 1, len(col)).astype(dtype)))
+    for name, n_rows, n_cols, off, col, val in cases:
+        x = rng.uniform(-1, 1, n_cols).astype(dtype)
+        y_ref = oracle.spmv(off, col, val, x)
+        m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+        y16 = _with_codes("1", lambda: m.mvp(x, variant="stream"))
+        y32 = _with_codes("0", lambda: m.mvp(x, variant="stream"))
+        assert np.array_equal(bits(y16), bits(y_ref)), name
+        assert np.array_equal(bits(y32), bits(y_ref)), name
+        m.sort_rows()  # reorders the columns: the codes must follow
+        s_col, s_val = oracle.crs_sort_rows(off, col, val)
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, s_col, s_val, x))), name
+    # device-born Laplacian block whose arrays are borrowed and end inside a chunk
+    row_end = next(re for re in range(300, 310) if synth.laplace3d_nnz(11, 7, 5, 13, re) % 4 != 0)
+    m = synth.crs_laplace3d(11, 7, 5, np.float32, 13, row_end)
+    off, col, val = m.raw_parts()
+    x = oracle.gen_x(synth.SEED_X, 11 * 7 * 5, np.float32)
+    assert np.array_equal(bits(_with_codes("1", lambda: m.mvp(x, variant="stream"))), bits(oracle.spmv(off, col, val, x)))
