@@ -59,6 +59,7 @@ typedef enum {
                          /* reference loop sparsematrix.rs:146-158 (checker, not fast)      */
     SMH_SPMV_STREAM = 4, /* K1s: short rows; dense entry stream, rounded products in LDS,   */
                          /* one thread folds a row in storage order: fast AND bit-exact     */
+                         /* (stencil-like matrices stream 16-bit column codes, built once)  */
     SMH_SPMV_COLBLOCK = 5 /* K2c: columns without locality and x larger than an L2: the      */
                          /* device copy is split into blocks of 2^19 columns, y += A_b x    */
 } smh_spmv_variant;
