@@ -147,7 +147,6 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
                                              const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
                                              uint32_t nnz_lim, uint32_t lane) {
     constexpr int RPS = kWave / LANES;
-    constexpr uint32_t MASK = kRingEntries - 1;
     const uint32_t j = lane % LANES;
     T out = T(0);
 #pragma unroll
