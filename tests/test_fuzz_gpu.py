@@ -70,3 +70,9 @@ def test_fuzz_all_kernels(gpu, dtype):
                                       "%s %s vector lanes %d ring %d" % (what, tag, lanes, ring))
             m.set_vector_lanes(0)
             m.set_ring(-1)
+            # column-blocked K2c with a random block width (1 .. ~30 blocks)
+            shift = int(rng.integers(max(1, int(np.log2(max(n_cols, 2))) - 4), int(np.log2(max(n_cols, 2))) + 2))
+            m.set_colblock_shift(shift)
+            if (n_cols + (1 << shift) - 1) >> shift <= 128:
+                assert_spmv_close(m.mvp(x, variant="colblock"), off, col, val, x, "%s %s colblock 2^%d" % (what, tag, shift))
+            m.set_colblock_shift(0)
