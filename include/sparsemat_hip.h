@@ -138,7 +138,7 @@ int smh_crs_stream_windows(smh_crs *m, double *fraction_out, uint32_t *table_out
  * covers 4*lanes*chunks entry slots of its row per pass */
 int smh_crs_set_vector_chunks(smh_crs *m, int chunks);
 /* K1r, the pipelined VECTOR kernel with an LDS-resident sliding window of x: mode -1 =
- * automatic (whenever lanes <= 8; rows whose column span exceeds the ring gather from L2),
+ * automatic (always; rows whose column span exceeds the ring gather from L2),
  * 0 = plain K1, 1 = same as -1.  The ring holds 16384 columns (64 KiB of f32 with two 512-thread
  * blocks per CU, 128 KiB of f64 with one 1024-thread block per CU).  When at least a quarter of
  * the rows run in ring phases the handle also keeps a u16 array with the low halves of the

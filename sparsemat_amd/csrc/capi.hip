@@ -96,6 +96,25 @@ static int auto_lanes(const smh_crs *m) {
     const double need = mean < 16.0 ? mean + 3.0 : mean;
     int lanes = 1;
     while (lanes < 64 && 4.0 * lanes < need) lanes <<= 1;
+    // Long rows in the pipelined body (contiguous-band matrices, 320 M entries, same box): rows of 128 / 256 entries
+    // run in 0.313 / 0.301 ms with 16 lanes (2 / 4 passes of 64 slots) against 0.359 / 0.348 ms with one pass of 32 / 64
+    // lanes; rows of 100 entries prefer one pass of 32 lanes (0.398 vs 0.500 ms).
+    if (m->use_ring != 0) {
+        if (mean >= 128.0) lanes = 16;
+        else if (lanes > 32) lanes = 32;
+        // ... and when their columns do not fit the ring (global gathers, one cache line each) 8 lanes lose least
+        // (banded +-32768, rows of 256: 1.28-1.33 ms with 4-8 lanes, 1.51 ms with 16, 1.62-1.80 ms with 64)
+        if (mean > 32.0 && m->ring_planned && m->ring_fraction < 0.5) lanes = 8;
+    }
+    return lanes;
+}
+
+// lanes sized to the mean row alone (the skew test of AUTO)
+static int mean_lanes(const smh_crs *m) {
+    const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
+    const double need = mean < 16.0 ? mean + 3.0 : mean;
+    int lanes = 1;
+    while (lanes < 64 && 4.0 * lanes < need) lanes <<= 1;
     return lanes;
 }
 
@@ -140,12 +159,16 @@ static bool wants_colblock(const smh_crs *m) {
 static int resolve_variant(const smh_crs *m, int variant) {
     if (variant != SMH_SPMV_AUTO) return variant;
     if (wants_colblock(m)) return SMH_SPMV_COLBLOCK;
-    const int lanes = auto_lanes(m);
+    const int lanes = mean_lanes(m);
     // short rows (stencils, FEM): the dense CSR-stream kernel (a tile denser than its LDS stage takes several passes)
     const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
     if (mean <= 12.0 && m->max_row_len <= 64) return SMH_SPMV_STREAM;
     // skew test: the longest row needs >= 8 passes of a group sized for the mean row
     if ((uint64_t)m->max_row_len >= 8ull * 4ull * (uint64_t)lanes && m->max_row_len > 64) return SMH_SPMV_MERGE;
+    // long rows whose columns do not fit the LDS ring (plan taken at create time): every kernel is then bound by one
+    // cache line per gather; the dense stream kernel loses least up to ~128 entries per row (banded +-8192..32768,
+    // 320 M entries: rows of 64 / 128: K1s 0.91 / 1.18 ms, lane-group kernels 1.24-1.42 / 1.34-1.69 ms)
+    if (mean > 32.0 && mean <= 128.0 && m->ring_planned && m->ring_fraction < 0.5) return SMH_SPMV_STREAM;
     return SMH_SPMV_VECTOR;
 }
 
@@ -324,7 +347,7 @@ static void drop_stream_codes(smh_crs *m) {
 // does the VECTOR family run as K1r (LDS x-ring) for this matrix?
 static int vector_uses_ring(smh_crs *m, bool *out) {
     *out = false;
-    if (m->use_ring == 0 || auto_lanes(m) > 8 || m->n_rows == 0) return SMH_OK;
+    if (m->use_ring == 0 || m->n_rows == 0) return SMH_OK;
     SMH_TRY(ensure_ring_plan(m));
     // the pipelined body also wins without the ring (its global-gather phases), so it is the default
     // whenever its lane widths apply; mode 0 keeps the plain K1 kernel selectable
@@ -464,7 +487,9 @@ static int finish_create(smh_crs *m, int validate) {
             return fail(SMH_ERR_INDEX_RANGE, "column index %u >= n_cols %zu", h_st.max_col, m->n_cols);
         // x larger than the L2s: take the locality statistic AUTO needs (one pass over columns[]; it is the K1r
         // inspector, so its plan is ready too)
-        if (m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes) SMH_TRY(ensure_ring_plan(m));
+        // ... and rows long enough for the lane-group kernels: AUTO wants to know whether their columns fit the ring
+        if (m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes || (m->n_rows && m->nnz > 32 * m->n_rows))
+            SMH_TRY(ensure_ring_plan(m));
     }
     return SMH_OK;
 }

@@ -352,6 +352,9 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
             case 2 * 16 + 2: SMH_R2_LAUNCH(2, 2); break;
             case 4 * 16 + 1: SMH_R2_LAUNCH(4, 1); break;
             case 8 * 16 + 1: SMH_R2_LAUNCH(8, 1); break;
+            case 16 * 16 + 1: SMH_R2_LAUNCH(16, 1); break;
+            case 32 * 16 + 1: SMH_R2_LAUNCH(32, 1); break;
+            case 64 * 16 + 1: SMH_R2_LAUNCH(64, 1); break;
             default:
                 return fail(SMH_ERR_INVALID, "ring kernel: unsupported (lanes per row, chunks per lane) = (%d, %d)", lanes, chunks);
         }

@@ -43,6 +43,7 @@ def report(tag, B, med, mn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--k", type=int, default=32, help="entries per row of the fixed-length cases")
     ap.add_argument("--cases", default="banded,diag,uniform,powerlaw")
     ap.add_argument("--lanes", default="4,8,16")
     ap.add_argument("--cb-shifts", default="", help="K2c column-block widths to time (log2 columns), e.g. 18,19,20")
@@ -61,7 +62,7 @@ def main():
             dtype = np.float64 if case.endswith("64") else np.float32
             pat = {"banded": synth.PATTERN_BANDED, "uniform": synth.PATTERN_UNIFORM, "diag": synth.PATTERN_DIAG}[
                 case.replace("64", "")]
-            m = synth.crs_fixed(synth.SEED_MATRIX, pat, n, 32, dtype)
+            m = synth.crs_fixed(synth.SEED_MATRIX, pat, n, args.k, dtype)
         nr = m.n_rows()
         xbuf, xptr = synth.gen_x(synth.SEED_X, nr, dtype)
         ybuf = synth.DeviceBuffer(nr * np.dtype(dtype).itemsize)
@@ -75,8 +76,6 @@ def main():
             m.set_vector_lanes(lanes)
             m.set_vector_chunks(chunks)
             for ring in ((0, 1) if chunks == 0 else (1,)):
-                if ring and lanes > 8:
-                    continue
                 m.set_ring(ring)
                 med, mn = time_variant(m, xptr, nr, ybuf.ptr, "vector")
                 report("vector lanes=%s %s" % (spec, "K1r" if ring else "K1"), B, med, mn)
