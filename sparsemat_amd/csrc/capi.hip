@@ -1209,7 +1209,8 @@ int smh_synth_fixed(smh_dtype dtype, uint64_t seed, int pattern, size_t n, uint3
                     size_t row_end, uint32_t *offset_rows_dev, uint32_t *columns_dev, void *values_dev, void *stream) {
     SMH_TRY(require_device());
     if (k == 0 || n < k || row_end < row_begin || row_end > n) return fail(SMH_ERR_INVALID, "bad generator arguments");
-    if ((uint64_t)(row_end - row_begin) * k >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "block nnz exceeds u32");
+    if ((uint64_t)(row_end - row_begin) * k >= 0xFFFFFFFFull)
+        return fail(SMH_ERR_CAPACITY, "Maximum number of %u entries reached", 0xFFFFFFFFu);  // sparsemat_crs.rs:82-84
     return synth_fixed(dtype, seed, pattern, n, k, row_begin, row_end, offset_rows_dev, columns_dev, values_dev,
                        (hipStream_t)stream);
 }

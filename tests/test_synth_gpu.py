@@ -99,6 +99,62 @@ def _run(m, xptr, n_x, variant, dtype):
     return ybuf.download(dtype, m.n_rows())
 
 
+def test_more_than_2_to_the_31_entries_in_one_matrix(gpu):
+    """Maximum sizes: 70 M rows x 32 = 2.24e9 entries in ONE handle (> 2^31, below the reference's limit of u32::MAX,
+    sparsemat_crs.rs:82-84) -- the entry count of BASELINE C5 on a single GPU.  Every 32-bit index in the kernels
+    must be unsigned: sampled row blocks (incl. the rows whose entries straddle 2^31) against the oracle, bit-exact
+    for K1s and SEQ, tolerance for K1r and merge-path; the kernels agree on every row."""
+    n, k = 70_000_000, 32
+    m = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32)
+    assert m.n_non_zero_entries() == n * k > 2 ** 31
+    xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
+    x = xbuf.download(np.float32, n)
+    y_ring = _run(m, xptr, n, "auto", np.float32)
+    y_st = _run(m, xptr, n, "stream", np.float32)
+    y_mg = _run(m, xptr, n, "merge", np.float32)
+    y_seq = _run(m, xptr, n, "seq", np.float32)
+    r31 = (2 ** 31) // k  # the row holding entry 2^31
+    for rb in (0, r31 - 1500, n - 3000):
+        re = min(n, rb + 3000)
+        off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32, rb, re)
+        y_ref = oracle.spmv(off, col, val, x)
+        assert np.array_equal(y_st[rb:re].view(np.uint32), y_ref.view(np.uint32))
+        assert np.array_equal(y_seq[rb:re].view(np.uint32), y_ref.view(np.uint32))
+        assert_spmv_close(y_ring[rb:re], off, col, val, x, "K1r rows %d.." % rb)
+        assert_spmv_close(y_mg[rb:re], off, col, val, x, "merge rows %d.." % rb)
+    assert np.array_equal(y_st.view(np.uint32), y_seq.view(np.uint32))
+    assert np.abs(y_ring.astype(np.float64) - y_st).max() < 5e-5
+    assert np.abs(y_mg.astype(np.float64) - y_st).max() < 5e-5
+
+
+def test_entry_count_just_below_u32_max(gpu):
+    """The largest matrix the reference can hold (sparsemat_crs.rs:82-84: fewer than u32::MAX entries): 134 217 000
+    rows x 32 = 4 294 944 000 entries (43 GB of arrays) in one handle; the last rows' offsets sit 23 295 below 2^32.
+    Sampled row blocks at both ends against the oracle, all kernels agree on every row; one more row of 32 entries
+    would still fit, 729 more rows are refused with the reference's panic text."""
+    n, k = 134_217_000, 32
+    m = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32)
+    assert m.n_non_zero_entries() == n * k and 2 ** 32 - 1 - n * k == 23_295
+    xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
+    x = xbuf.download(np.float32, n)
+    y_ring = _run(m, xptr, n, "auto", np.float32)
+    y_st = _run(m, xptr, n, "stream", np.float32)
+    y_mg = _run(m, xptr, n, "merge", np.float32)
+    for rb in (0, n // 2, n - 2500):
+        re = min(n, rb + 2500)
+        off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32, rb, re)
+        y_ref = oracle.spmv(off, col, val, x)
+        assert np.array_equal(y_st[rb:re].view(np.uint32), y_ref.view(np.uint32))
+        assert_spmv_close(y_ring[rb:re], off, col, val, x, "K1r rows %d.." % rb)
+        assert_spmv_close(y_mg[rb:re], off, col, val, x, "merge rows %d.." % rb)
+    assert np.abs(y_ring.astype(np.float64) - y_st).max() < 5e-5
+    assert np.abs(y_mg.astype(np.float64) - y_st).max() < 5e-5
+    del m
+    with pytest.raises(sm.SparseMatPanic) as e:
+        synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n + 729, k, np.float32)
+    assert "Maximum number of 4294967295 entries reached" in str(e.value)
+
+
 def test_full_size_c2_uniform_colblock_properties(gpu):
     """C2 stress variant (10M rows x 32 uniform columns, f32) at full size: AUTO = column-blocked K2c; sampled row
     blocks against the oracle (rows regenerated independently), the bit-exact K1s/SEQ pair agrees with it on the
