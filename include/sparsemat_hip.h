@@ -148,6 +148,9 @@ int smh_crs_set_ring(smh_crs *m, int mode);
 /* the K1r phase plan (integer structure, invariants checked in tests): phase_ptr_out needs
  * n_blocks+1 entries, phases_out 5 u32 per phase {row_begin,row_end,load_lo,load_hi,use_ring};
  * call first with NULL arrays to get the sizes.                                           */
+/* columns the ring of this matrix's plan holds: 16384, or 32768 for f32 matrices whose rows need the
+ * wider window (128 KiB of LDS, one 1024-thread block per CU) */
+int smh_crs_ring_entries(smh_crs *m, uint32_t *out);
 int smh_crs_ring_plan(smh_crs *m, uint32_t *n_blocks_out, size_t *n_phases_out,
                       double *ring_fraction_out, int *active_out, uint32_t *phase_ptr_out,
                       uint32_t *phases_out);

@@ -236,6 +236,24 @@ static int ensure_ring_plan(smh_crs *m) {
     if (const char *e = getenv("SMH_GATHER_NT")) noring_mode = atoi(e) ? 2u : 0u;
     build_ring_plan(m->n_rows, kRingEntries, cmin.data(), cmax.data(), blocks, noring_mode, phase_ptr, phases,
                     &m->ring_fraction);
+    m->ring_entries = kRingEntries;
+    // f32 rows that do not fit 16384 columns but fit 32768: the wide ring (128 KiB of LDS, one 1024-thread block per CU
+    // like f64, so half as many blocks).  Rows of 64 entries in a +-8192 band: 0.90 ms (K1s) -> see DESIGN.md.
+    const char *wide_env = getenv("SMH_RING_WIDE");  // tuning knob: 0 = never
+    if (m->dtype == SMH_F32 && m->ring_fraction < 0.5 && !(wide_env && atoi(wide_env) == 0)) {
+        std::vector<uint32_t> phase_ptr_w;
+        std::vector<RingPhase> phases_w;
+        double frac_w = 0.0;
+        const unsigned blocks_w = ((blocks / 2) + 7u) & ~7u;
+        build_ring_plan(m->n_rows, kRingEntriesWide, cmin.data(), cmax.data(), blocks_w, noring_mode, phase_ptr_w, phases_w, &frac_w);
+        if (frac_w >= 0.5) {
+            phase_ptr.swap(phase_ptr_w);
+            phases.swap(phases_w);
+            m->ring_fraction = frac_w;
+            m->ring_entries = kRingEntriesWide;
+            blocks = blocks_w;
+        }
+    }
     SMH_HIP(hipMalloc((void **)&m->d_phase_ptr, phase_ptr.size() * sizeof(uint32_t)));
     SMH_HIP(hipMalloc((void **)&m->d_phases, (phases.size() + 1) * sizeof(RingPhase)));
     SMH_HIP(hipMemcpy(m->d_phase_ptr, phase_ptr.data(), phase_ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -401,7 +419,8 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
             if (ring)
                 // owned arrays are padded to a multiple of 4 entries; borrowed ones may end inside a 16-B chunk
                 return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_col16, m->d_val, x, y, m->n_rows,
-                                         m->nnz, m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases, s);
+                                         m->nnz, m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases,
+                                         m->ring_entries, s);
             return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, s);
         }
         case SMH_SPMV_SEQ:
@@ -821,6 +840,13 @@ int smh_crs_ring_plan(smh_crs *m, uint32_t *n_blocks_out, size_t *n_phases_out, 
         SMH_HIP(hipMemcpy(phase_ptr_out, m->d_phase_ptr, (m->ring_blocks + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (phases_out && m->ring_n_phases)
         SMH_HIP(hipMemcpy(phases_out, m->d_phases, m->ring_n_phases * sizeof(RingPhase), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+int smh_crs_ring_entries(smh_crs *m, uint32_t *out) {
+    if (!m || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    SMH_TRY(ensure_ring_plan(m));
+    *out = m->ring_entries;
     return SMH_OK;
 }
 

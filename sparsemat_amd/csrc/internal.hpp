@@ -39,6 +39,7 @@ constexpr int kMergeItemsPerThread = 8;
 constexpr int kMergeTile = kBlock * kMergeItemsPerThread;  // merge items (rows + nnz) per tile
 constexpr int kReducePartials = 1024;  // blocks of a stage-1 reduction
 constexpr int kRingEntries = 16384;    // K1r: columns of x the LDS ring holds (64 KiB f32 / 128 KiB f64)
+constexpr int kRingEntriesWide = 32768;  // ... f32 only, for rows that need it: 128 KiB, one 1024-thread block per CU
 constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
 constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
 constexpr int kStreamXWin = 3072;      // K1s-w: x entries of a tile's column intervals staged in LDS
@@ -94,7 +95,7 @@ int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 // phases then stream 2 instead of 4 bytes per column
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
-                      const uint32_t *phase_ptr, const RingPhase *phases, hipStream_t s);
+                      const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, hipStream_t s);
 int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size_t n_out, hipStream_t s);
 // structure statistics / validation
 struct CrsStats {
@@ -161,6 +162,7 @@ struct smh_crs {
     bool ring_planned = false;
     unsigned ring_blocks = 0;
     double ring_fraction = 0.0;  // share of rows whose gathers are served from the LDS ring
+    unsigned ring_entries = smh::kRingEntries;  // ring size the plan was built for
     size_t ring_n_phases = 0;
     uint32_t *d_phase_ptr = nullptr;
     smh::RingPhase *d_phases = nullptr;

@@ -30,7 +30,9 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 //   f32: 64 KiB  -> 512-thread blocks, two resident per CU;
 //   f64: 128 KiB -> 1024-thread blocks, one resident per CU (same 16 waves per CU, <= 128 VGPRs).
 // LDS is dynamic (above the 64 KiB static limit for f64).
-template <typename T> struct Ring2Cfg { static constexpr int kThreads = sizeof(T) == 8 ? 1024 : 512; };
+// RING = columns the ring holds: 16384 by default; f32 matrices whose rows do not fit that but fit 32768 take the
+// 128 KiB / 1024-thread configuration too (chosen by the plan builder's caller).
+template <typename T, int RING> struct Ring2Cfg { static constexpr int kThreads = (size_t)RING * sizeof(T) > 65536 ? 1024 : 512; };
 #ifndef SMH_RING2_SB
 #define SMH_RING2_SB 2
 #endif
@@ -84,9 +86,9 @@ __device__ __forceinline__ void load_chunk_nb(const void *__restrict__ colp, con
 }
 
 // ring slot of entry q of a chunk: column mod kRingEntries, from the u32 columns or from the packed 16-bit pairs
-template <bool C16>
+template <bool C16, int RING>
 __device__ __forceinline__ uint32_t ring_slot(const uint32_t (&c)[4], int q) {
-    constexpr uint32_t MASK = kRingEntries - 1;
+    constexpr uint32_t MASK = RING - 1;
     if constexpr (C16) return (q & 1) ? ((c[q >> 1] >> 16) & MASK) : (c[q >> 1] & MASK);
     else return c[q] & MASK;
 }
@@ -141,7 +143,7 @@ __device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const void *__re
     }
 }
 
-template <typename T, int LANES, int CH, int SB, int GM, bool C16>
+template <typename T, int LANES, int CH, int SB, int GM, bool C16, int RING>
 __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t base, uint64_t row_end,
                                              const void *__restrict__ colp, const T *__restrict__ valp,
                                              const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
@@ -166,7 +168,7 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
                 const uint32_t rel = 4u * (ch * LANES + j) + q;
                 const bool in = rel >= lo && rel < len;
                 T xv;
-                if constexpr (GM == 1) xv = ring[ring_slot<C16>(u.c[t * CH + ch], q)];
+                if constexpr (GM == 1) xv = ring[ring_slot<C16, RING>(u.c[t * CH + ch], q)];
                 else if constexpr (GM == 2) xv = __builtin_nontemporal_load(&x[in ? u.c[t * CH + ch][q] : 0u]);
                 else xv = x[in ? u.c[t * CH + ch][q] : 0u];
                 const T f = r2_fma(u.v[t * CH + ch][q], xv, sum);
@@ -182,7 +184,7 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
             for (int q = 0; q < 4; ++q) {
                 const bool in = rel + q < len;
                 T xv;
-                if constexpr (GM == 1) xv = ring[ring_slot<C16>(cc, q)];
+                if constexpr (GM == 1) xv = ring[ring_slot<C16, RING>(cc, q)];
                 else if constexpr (GM == 2) xv = __builtin_nontemporal_load(&x[in ? cc[q] : 0u]);
                 else xv = x[in ? cc[q] : 0u];
                 const T f = r2_fma(vv[q], xv, sum);
@@ -204,7 +206,7 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
 }
 
 // col: the 32-bit column array, or (C16) the 16-bit one
-template <typename T, int LANES, int CH, int GM, bool C16>
+template <typename T, int LANES, int CH, int GM, bool C16, int RING>
 __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, const void *__restrict__ col,
                                            const T *__restrict__ val, const T *__restrict__ x, const T *ring,
                                            T *__restrict__ y, uint64_t rb, uint64_t re, uint32_t nnz_lim,
@@ -213,7 +215,7 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
     constexpr int SBMAX = sizeof(T) == 8 ? 1 : kRing2SB;  // f64 chunks take 12 VGPRs: one step per unit
     constexpr int SB = STEPS < SBMAX ? STEPS : SBMAX;
     constexpr int RU = SB * (kWave / LANES);                 // rows per unit
-    constexpr uint64_t STRIDE = (uint64_t)(Ring2Cfg<T>::kThreads / kWave) * RU;  // rows between two units of a wave
+    constexpr uint64_t STRIDE = (uint64_t)(Ring2Cfg<T, RING>::kThreads / kWave) * RU;  // rows between two units of a wave
     uint64_t base = rb + (uint64_t)wave * RU;
     if (base >= re) return;
     // 32-bit addressing inside the phase: everything is relative to the phase's first (aligned) entry
@@ -228,22 +230,22 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
     issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
     for (;;) {
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM, C16>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM, C16, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         // program order = age order: offsets(+2) older than chunks(+1); both stay in flight under consume
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB, C16>(B, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM, C16>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        consume_unit<T, LANES, CH, SB, GM, C16, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         A.o0 = N.o0; A.o1 = N.o1;
         base += STRIDE;
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM, C16>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM, C16, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
             break;
         }
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM, C16>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        consume_unit<T, LANES, CH, SB, GM, C16, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
         B.o0 = N.o0; B.o1 = N.o1;
         base += STRIDE;
     }
@@ -251,15 +253,15 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
 
 // C16: ring phases stream the 16-bit column array `col16` (6 instead of 8 bytes per f32 entry); phases with global
 // gathers need whole columns and keep reading `col`
-template <typename T, int LANES, int CH, bool C16>
-__global__ void __launch_bounds__(Ring2Cfg<T>::kThreads, 4)  // 4 waves per SIMD: 16 waves per CU for either dtype
+template <typename T, int LANES, int CH, bool C16, int RING>
+__global__ void __launch_bounds__((Ring2Cfg<T, RING>::kThreads), 4)  // 4 waves per SIMD: 16 waves per CU either way
 k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint16_t *__restrict__ col16,
              const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
              const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];  // kRingEntries * sizeof(T), dynamic
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];  // RING * sizeof(T), dynamic
     T *ring = reinterpret_cast<T *>(ring_raw);
-    constexpr uint32_t MASK = kRingEntries - 1;
-    constexpr int kRing2Threads = Ring2Cfg<T>::kThreads;
+    constexpr uint32_t MASK = RING - 1;
+    constexpr int kRing2Threads = Ring2Cfg<T, RING>::kThreads;
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);  // XCD-aware: neighbours share an L2
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -276,12 +278,14 @@ k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
         // gather mode of the phase: 1 = LDS ring, 0 = L1/L2-cached global gathers, 2 = L1-bypassing (nt) global
         // gathers for phases whose columns have no locality to keep in the 32 KiB L1
         if (ph.use_ring == 1)
-            phase_rows<T, LANES, CH, 1, C16>(off, C16 ? (const void *)col16 : (const void *)col, val, x, ring, y, ph.row_begin,
-                                             ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 1, C16, RING>(off, C16 ? (const void *)col16 : (const void *)col, val, x, ring, y, ph.row_begin,
+                                                   ph.row_end, nnz_lim, last_chunk, wave, lane);
         else if (ph.use_ring == 2)
-            phase_rows<T, LANES, CH, 2, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 2, false, RING>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave,
+                                                     lane);
         else
-            phase_rows<T, LANES, CH, 0, false>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 0, false, RING>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave,
+                                                     lane);
     }
 }
 
@@ -315,7 +319,7 @@ int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size
     return SMH_OK;
 }
 
-template <typename T>
+template <typename T, int RING>
 static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16, const T *val,
                           const T *x, T *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
                           const uint32_t *phase_ptr, const RingPhase *phases, hipStream_t s) {
@@ -326,18 +330,18 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
         SMH_HIP(hipMemsetAsync(y, 0, n_rows * sizeof(T), s));
     } else {
         const uint64_t last_chunk = (nnz_lim - 1) & ~uint64_t(3);
-        dim3 grid(n_blocks), block(Ring2Cfg<T>::kThreads);
-        constexpr size_t lds_bytes = (size_t)kRingEntries * sizeof(T);
+        dim3 grid(n_blocks), block(Ring2Cfg<T, RING>::kThreads);
+        constexpr size_t lds_bytes = (size_t)RING * sizeof(T);
         // dynamic LDS above 64 KiB must be allowed per kernel (idempotent, cheap)
 #define SMH_R2_LAUNCH1(L, C, N)                                                                                          \
     do {                                                                                                                 \
         static bool attr_set = false; /* once per instantiation (and never inside a stream capture) */                  \
         if (!attr_set) {                                                                                                 \
-            SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C, N>),                        \
+            SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C, N, RING>),                  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                    \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N>), grid, block, lds_bytes, s, off, col, col16, val, x, y,            \
+        hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N, RING>), grid, block, lds_bytes, s, off, col, col16, val, x, y,      \
                            (uint32_t)nnz_lim, last_chunk, phase_ptr, phases);                                            \
     } while (0)
 #define SMH_R2_LAUNCH(L, C)                                            \
@@ -369,15 +373,22 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
     return SMH_OK;
 }
 
+// ring_entries: what the phase plan was built for (kRingEntries; kRingEntriesWide for f32 matrices that need it)
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
-                      const uint32_t *phase_ptr, const RingPhase *phases, hipStream_t s) {
+                      const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
-    if (dtype == SMH_F64)
-        return launch_ring2_t<double>(lanes, chunks, off, col, col16, (const double *)val, (const double *)x, (double *)y, n_rows,
-                                      nnz, padded, n_blocks, phase_ptr, phases, s);
-    return launch_ring2_t<float>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x, (float *)y, n_rows, nnz,
-                                 padded, n_blocks, phase_ptr, phases, s);
+    if (dtype == SMH_F64) {
+        if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "f64 ring kernel: ring of %u columns", ring_entries);
+        return launch_ring2_t<double, kRingEntries>(lanes, chunks, off, col, col16, (const double *)val, (const double *)x,
+                                                    (double *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, s);
+    }
+    if (ring_entries == (unsigned)kRingEntriesWide)
+        return launch_ring2_t<float, kRingEntriesWide>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x,
+                                                       (float *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, s);
+    if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "ring kernel: ring of %u columns", ring_entries);
+    return launch_ring2_t<float, kRingEntries>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x, (float *)y,
+                                               n_rows, nnz, padded, n_blocks, phase_ptr, phases, s);
 }
 
 }  // namespace smh

@@ -185,6 +185,12 @@ class SparseMatCRS:
         """K1r (LDS x-ring) for the vector family: -1 automatic, 0 off, 1 on."""
         check(lib().smh_crs_set_ring(self._h, mode))
 
+    def ring_entries(self):
+        """Columns the LDS ring of this matrix's K1r plan holds (16384, or 32768 for f32 matrices that need it)."""
+        out = C.c_uint32()
+        check(lib().smh_crs_ring_entries(self._h, C.byref(out)))
+        return out.value
+
     def ring_plan(self):
         """(n_blocks, ring_fraction, active, phase_ptr, phases[n,5]) of the K1r plan."""
         nb, nph, frac, act = C.c_uint32(), C.c_size_t(), C.c_double(), C.c_int()

@@ -15,7 +15,8 @@ def check_plan(m, off, col):
     """Every row is covered exactly once, in order, by its block's phases; a ring phase's window
     (what the ring holds after its load) contains every column its rows reference."""
     n_rows = len(off) - 1
-    ring = RING_ENTRIES  # same for f32 (64 KiB) and f64 (128 KiB of LDS)
+    ring = m.ring_entries()  # 16384 (64 KiB of f32, 128 KiB of f64) or, for f32 rows that need it, 32768
+    assert ring in (RING_ENTRIES, 2 * RING_ENTRIES) and (ring == RING_ENTRIES or m.dtype == np.float32)
     nb, frac, active, ptr, ph = m.ring_plan()
     assert nb % 8 == 0 and len(ptr) == nb + 1 and ptr[0] == 0 and ptr[-1] == len(ph)
     assert np.all(np.diff(ptr.astype(np.int64)) >= 0)
@@ -109,6 +110,33 @@ def test_ring_mixed_phases_random(gpu, dtype):
     m.sort_rows()
     s_col, s_val = oracle.crs_sort_rows(off, col, val)
     assert_spmv_close(m.mvp(x, variant="vector"), off, s_col, s_val, x, "after sort_rows")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_wide_ring_for_f32_bands_beyond_16384_columns(gpu, dtype):
+    """Rows whose columns span +-10000 around the diagonal do not fit the 16384-column ring: an f32 matrix takes the
+    32768-column ring (128 KiB of LDS), an f64 matrix keeps the narrow plan (global gathers) -- parity either way,
+    and the plan invariants hold for the ring size the plan reports."""
+    rng = np.random.default_rng(123)
+    n = 150_000
+    lens = rng.integers(20, 45, n)
+    off = np.zeros(n + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    centers = np.repeat(np.arange(n), lens)
+    col = np.clip(centers + rng.integers(-10_000, 10_000, len(centers)), 0, n - 1).astype(np.uint32)
+    val = rng.uniform(-1, 1, len(col)).astype(dtype)
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    frac, _ = check_plan(m, off, col)
+    if dtype == np.float32:
+        assert m.ring_entries() == 2 * RING_ENTRIES and frac > 0.9
+    else:
+        assert m.ring_entries() == RING_ENTRIES and frac < 0.1
+    for lanes in (4, 8, 16):
+        m.set_vector_lanes(lanes)
+        y = m.mvp(x, variant="vector")
+        assert_spmv_close(y, off, col, val, x, "wide ring lanes %d" % lanes)
+        assert np.array_equal(y, m.mvp(x, variant="vector"))
 
 
 def test_ring_small_and_edge_shapes(gpu):
