@@ -25,6 +25,8 @@ of where the local product runs; ``local`` is any object with ``n_rows``, ``col_
 ``mvp_into(x, y)``.  ``HipBlock`` (the product) wraps a device-resident ``SparseMatCRS``; the
 CPU/gloo tests plug in their own checker block.
 """
+import os
+
 import numpy as np
 
 
@@ -118,6 +120,9 @@ class SparseMatPar:
         self._gather_buf = None
         self._y_local = None
         self._plan = None  # (mode, send, recv, send_sizes, recv_sizes)
+        # halo exchange as grouped point-to-point operations on slices of the vector itself (no staging); False: one
+        # all_to_all_single through packed send / receive buffers (SMH_HALO_A2A=1 selects it)
+        self.halo_p2p = os.environ.get("SMH_HALO_A2A", "0") != "1"
 
     @classmethod
     def with_sub_matrices(cls, n_blocks, max_n_rows, n_cols, rank, local, group=None):
@@ -202,6 +207,21 @@ class SparseMatPar:
             return v
         if mode == "allgather":
             return self.allgather(v)
+        if self.halo_p2p:
+            # Zero-copy: every piece is a contiguous slice of v itself -- sends read this rank's slice, receives land in
+            # the neighbours' slices (disjoint from it) -- so the exchange is ONE grouped launch of point-to-point
+            # operations (ncclGroupStart/End under RCCL) with no staging buffer, no pack and no unpack kernel.
+            ops = []
+            for q, (a, b) in enumerate(recv):
+                if a < b:
+                    ops.append(dist.P2POp(dist.irecv, v[a:b], self._global_rank(q), group=self.group))
+            for q, (a, b) in enumerate(send):
+                if a < b:
+                    ops.append(dist.P2POp(dist.isend, v[a:b], self._global_rank(q), group=self.group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            return v
         pieces = [v[a:b] for (a, b) in send if a < b]
         sendbuf = torch.cat(pieces) if pieces else v.new_empty(0)
         recvbuf = v.new_empty(sum(recv_sizes))
@@ -213,6 +233,10 @@ class SparseMatPar:
                 v[a:b] = recvbuf[pos:pos + (b - a)]
                 pos += b - a
         return v
+
+    def _global_rank(self, q):
+        import torch.distributed as dist
+        return q if self.group is None else dist.get_global_rank(self.group, q)
 
     def mvp_window(self, x, out=None):
         """Local SpMV into this rank's slice of ``out`` + exchange of the referenced entries: afterwards
