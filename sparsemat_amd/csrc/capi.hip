@@ -162,7 +162,10 @@ static int resolve_variant(const smh_crs *m, int variant) {
     const int lanes = mean_lanes(m);
     // short rows (stencils, FEM): the dense CSR-stream kernel (a tile denser than its LDS stage takes several passes)
     const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
-    if (mean <= 12.0 && m->max_row_len <= 64) return SMH_SPMV_STREAM;
+    // ... except rows of 9-12 entries whose columns fit the LDS ring (plan taken at create time): there the ring kernel
+    // with 4 lanes wins (banded, 320 M entries, rows of 12: 0.445 vs 0.637 ms; rows of 8: 0.572 vs 0.586 ms, a tie)
+    const bool short_ring_rows = mean > 8.0 && m->ring_planned && m->ring_fraction >= 0.5 && m->use_ring != 0;
+    if (mean <= 12.0 && m->max_row_len <= 64 && !short_ring_rows) return SMH_SPMV_STREAM;
     // skew test: the longest row needs >= 8 passes of a group sized for the mean row
     if ((uint64_t)m->max_row_len >= 8ull * 4ull * (uint64_t)lanes && m->max_row_len > 64) return SMH_SPMV_MERGE;
     // long rows whose columns do not fit the LDS ring (plan taken at create time): every kernel is then bound by one
@@ -507,7 +510,7 @@ static int finish_create(smh_crs *m, int validate) {
         // x larger than the L2s: take the locality statistic AUTO needs (one pass over columns[]; it is the K1r
         // inspector, so its plan is ready too)
         // ... and rows long enough for the lane-group kernels: AUTO wants to know whether their columns fit the ring
-        if (m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes || (m->n_rows && m->nnz > 32 * m->n_rows))
+        if (m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes || (m->n_rows && m->nnz > 8 * m->n_rows))
             SMH_TRY(ensure_ring_plan(m));
     }
     return SMH_OK;
