@@ -146,11 +146,17 @@ int smh_crs_set_vector_chunks(smh_crs *m, int chunks);
  * stream that array instead of the u32 columns (same arithmetic, bitwise identical results). */
 int smh_crs_set_ring(smh_crs *m, int mode);
 /* the K1r phase plan (integer structure, invariants checked in tests): phase_ptr_out needs
- * n_blocks+1 entries, phases_out 5 u32 per phase {row_begin,row_end,load_lo,load_hi,use_ring};
+ * n_blocks+1 entries, phases_out 11 u32 per phase {row_begin,row_end,load_lo,load_hi,use_ring,
+ * lo1,lo2,lo3,hi1,hi2,hi3} (load ranges of band 0 and, in banded plans, of bands 1..3);
  * call first with NULL arrays to get the sizes.                                           */
 /* columns the ring of this matrix's plan holds: 16384, or 32768 for f32 matrices whose rows need the
  * wider window (128 KiB of LDS, one 1024-thread block per CU) */
 int smh_crs_ring_entries(smh_crs *m, uint32_t *out);
+/* 1: one sliding window (slot = column mod ring size).  4: banded ring for rows that reference a few narrow
+ * column intervals far apart (stencils): band k holds the k-th interval of the tiles, slot = k * S +
+ * column mod S, S = ring size / 4.  intervals_out (optional, banded plans only): 8 u32 per 64-row tile,
+ * {lo0,hi0,..,lo3,hi3} sorted and disjoint; all zero = tile without entries, [1,0) = not describable. */
+int smh_crs_ring_bands(smh_crs *m, uint32_t *bands_out, uint32_t *intervals_out);
 int smh_crs_ring_plan(smh_crs *m, uint32_t *n_blocks_out, size_t *n_phases_out,
                       double *ring_fraction_out, int *active_out, uint32_t *phase_ptr_out,
                       uint32_t *phases_out);

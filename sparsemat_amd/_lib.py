@@ -53,6 +53,7 @@ SIGNATURES = {
     "smh_crs_set_vector_chunks": (_int, [_vp, _int]),
     "smh_crs_set_ring": (_int, [_vp, _int]),
     "smh_crs_ring_entries": (_int, [_vp, _u32p]),
+    "smh_crs_ring_bands": (_int, [_vp, _u32p, _vp]),
     "smh_crs_ring_plan": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(C.c_double), C.POINTER(_int), _vp, _vp]),
     "smh_crs_set_colblock_shift": (_int, [_vp, C.c_uint32]),
     "smh_crs_colblock": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(_int), C.POINTER(C.c_double), _vp, _vp, _vp]),

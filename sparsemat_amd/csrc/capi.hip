@@ -71,6 +71,8 @@ int synth_laplace3d(int dtype, size_t nx, size_t ny, size_t nz, size_t row_begin
 void build_ring_plan(size_t n_rows, size_t ring_entries, const uint32_t *cmin, const uint32_t *cmax, size_t n_blocks,
                      uint32_t noring_mode, std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases,
                      double *ring_row_fraction);
+void build_ring_plan_banded(size_t n_rows, size_t ring_entries, const uint32_t *win, size_t n_blocks, uint32_t noring_mode,
+                            std::vector<uint32_t> &phase_ptr, std::vector<RingPhase> &phases, double *ring_row_fraction);
 void synth_powerlaw_cdf(uint32_t kmax, double alpha, uint32_t *cdf);
 void synth_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, uint32_t kmax, const uint32_t *cdf,
                             uint32_t *lengths);
@@ -257,6 +259,48 @@ static int ensure_ring_plan(smh_crs *m) {
             blocks = blocks_w;
         }
     }
+    // Still mostly outside the ring: rows that reference a few narrow column intervals far apart (stencils on
+    // structured grids) get the BANDED ring -- four bands of a quarter of the ring, one per interval of the tile.
+    m->ring_bands = 1;
+    const char *band_env = getenv("SMH_RING_BANDS");  // tuning knob: 0 = never
+    if (m->ring_fraction < 0.5 && n_tiles && m->nnz && !(band_env && atoi(band_env) == 0)) {
+        const unsigned sizes[2] = {(unsigned)kRingEntries, (unsigned)kRingEntriesWide};
+        const int n_sizes = m->dtype == SMH_F32 && !(wide_env && atoi(wide_env) == 0) ? 2 : 1;
+        std::vector<uint32_t> h_win(n_tiles * 8);
+        uint32_t *d_win = nullptr, *d_count = nullptr;
+        SMH_HIP(hipMalloc((void **)&d_win, n_tiles * 8 * sizeof(uint32_t)));
+        hipError_t e = hipMalloc((void **)&d_count, sizeof(uint32_t));
+        int rc = e == hipSuccess ? SMH_OK : hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+        bool adopted = false;
+        for (int si = 0; si < n_sizes && rc == SMH_OK && !adopted; ++si) {
+            const unsigned ring = sizes[si];
+            rc = launch_tile_intervals(m->d_off, m->d_col, m->n_rows, 64, ring / 4, d_win, d_count, m->stream);
+            if (rc == SMH_OK) {
+                e = hipMemcpyAsync(h_win.data(), d_win, n_tiles * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+                if (e != hipSuccess) rc = hip_fail(e, "tile interval readback", __FILE__, __LINE__);
+            }
+            if (rc != SMH_OK) break;
+            std::vector<uint32_t> phase_ptr_b;
+            std::vector<RingPhase> phases_b;
+            double frac_b = 0.0;
+            const unsigned blocks_b = ring == (unsigned)kRingEntries || m->dtype == SMH_F64 ? blocks : ((blocks / 2) + 7u) & ~7u;
+            build_ring_plan_banded(m->n_rows, ring, h_win.data(), blocks_b, noring_mode, phase_ptr_b, phases_b, &frac_b);
+            if (frac_b >= 0.5 && frac_b > m->ring_fraction) {
+                phase_ptr.swap(phase_ptr_b);
+                phases.swap(phases_b);
+                m->ring_fraction = frac_b;
+                m->ring_entries = ring;
+                m->ring_bands = 4;
+                blocks = blocks_b;
+                adopted = true;
+            }
+        }
+        (void)hipFree(d_count);
+        if (adopted) m->d_ring_win = d_win;  // kept: the 16-bit ring slots are built from it on first use
+        else (void)hipFree(d_win);
+        SMH_TRY(rc);
+    }
     SMH_HIP(hipMalloc((void **)&m->d_phase_ptr, phase_ptr.size() * sizeof(uint32_t)));
     SMH_HIP(hipMalloc((void **)&m->d_phases, (phases.size() + 1) * sizeof(RingPhase)));
     SMH_HIP(hipMemcpy(m->d_phase_ptr, phase_ptr.data(), phase_ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -377,11 +421,17 @@ static int vector_uses_ring(smh_crs *m, bool *out) {
     // ring phase reads -- 6 instead of 8 bytes per f32 entry from HBM.  One extra 2-byte-per-entry array, built once.
     int want = m->use_col16;
     if (const char *e = getenv("SMH_RING_COL16")) want = atoi(e) ? 1 : 0;  // tuning knob
-    const bool use16 = want == 1 || (want < 0 && m->ring_fraction >= 0.25);
+    // (the banded plan cannot do without: its gathers take the ring slot from that array)
+    const bool use16 = m->ring_bands == 4 || want == 1 || (want < 0 && m->ring_fraction >= 0.25);
     if (use16 && !m->d_col16 && m->nnz) {
         const size_t n_out = ((m->nnz + 3) & ~size_t(3)) + 4;
         SMH_HIP(hipMalloc((void **)&m->d_col16, n_out * sizeof(uint16_t)));
-        SMH_TRY(launch_narrow_columns(m->d_col, m->nnz, m->d_col16, n_out, m->stream));
+        if (m->ring_bands == 4) {
+            SMH_HIP(hipMemsetAsync(m->d_col16, 0, n_out * sizeof(uint16_t), m->stream));
+            SMH_TRY(launch_ring_band_codes(m->d_off, m->d_col, m->d_ring_win, m->n_rows, m->ring_entries / 4, m->d_col16, m->stream));
+        } else {
+            SMH_TRY(launch_narrow_columns(m->d_col, m->nnz, m->d_col16, n_out, m->stream));
+        }
         SMH_HIP(hipStreamSynchronize(m->stream));
     } else if (!use16 && m->d_col16) {
         (void)hipFree(m->d_col16);
@@ -423,7 +473,7 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
                 // owned arrays are padded to a multiple of 4 entries; borrowed ones may end inside a 16-B chunk
                 return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_col16, m->d_val, x, y, m->n_rows,
                                          m->nnz, m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases,
-                                         m->ring_entries, s);
+                                         m->ring_entries, m->ring_bands, s);
             return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, s);
         }
         case SMH_SPMV_SEQ:
@@ -717,7 +767,7 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
-    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16);
+    (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16); (void)hipFree(m->d_ring_win);
     (void)hipFree(m->d_stream_win); (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
@@ -850,6 +900,15 @@ int smh_crs_ring_entries(smh_crs *m, uint32_t *out) {
     if (!m || !out) return fail(SMH_ERR_INVALID, "NULL argument");
     SMH_TRY(ensure_ring_plan(m));
     *out = m->ring_entries;
+    return SMH_OK;
+}
+
+int smh_crs_ring_bands(smh_crs *m, uint32_t *bands_out, uint32_t *intervals_out) {
+    if (!m || !bands_out) return fail(SMH_ERR_INVALID, "NULL argument");
+    SMH_TRY(ensure_ring_plan(m));
+    *bands_out = m->ring_bands;
+    if (intervals_out && m->ring_bands == 4 && m->d_ring_win)
+        SMH_HIP(hipMemcpy(intervals_out, m->d_ring_win, ((m->n_rows + 63) / 64) * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SMH_OK;
 }
 

@@ -86,16 +86,24 @@ int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n
 // K1r (LDS x-ring): inspector, host plan, kernel
 struct RingPhase {
     uint32_t row_begin, row_end;  // rows of this phase (row_begin is a multiple of 64)
-    uint32_t load_lo, load_hi;    // columns of x to add to the LDS ring before the phase (may be empty)
+    uint32_t load_lo, load_hi;    // columns of x to add to the LDS ring before the phase (may be empty); band 0
     uint32_t use_ring;            // 0: the phase's column span exceeds the ring -> global gathers
+    uint32_t band_lo[3], band_hi[3];  // banded ring (4 bands of a quarter of the ring each): loads of bands 1..3
 };
+constexpr int kRingPhaseWords = 11;
 int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t n_tiles, uint32_t *cmin,
                      uint32_t *cmax, hipStream_t s);
 // col16 (optional): the low halves of the columns, padded with zeros to a multiple of 4 entries plus one chunk; ring
 // phases then stream 2 instead of 4 bytes per column
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
-                      const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, hipStream_t s);
+                      const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, unsigned bands,
+                      hipStream_t s);
+// banded ring (4 bands): per-tile column intervals (the K1s inspector over 64-row tiles) and the 16-bit ring slots
+int launch_tile_intervals(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t tile_rows, size_t max_width,
+                          uint32_t *win, uint32_t *d_count, hipStream_t s);
+int launch_ring_band_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint32_t S,
+                           uint16_t *code, hipStream_t s);
 int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size_t n_out, hipStream_t s);
 // structure statistics / validation
 struct CrsStats {
@@ -163,6 +171,8 @@ struct smh_crs {
     unsigned ring_blocks = 0;
     double ring_fraction = 0.0;  // share of rows whose gathers are served from the LDS ring
     unsigned ring_entries = smh::kRingEntries;  // ring size the plan was built for
+    unsigned ring_bands = 1;                    // 1: one sliding window; 4: banded ring (needs d_col16 = ring slots)
+    uint32_t *d_ring_win = nullptr;             // banded plan: the tiles' column intervals (8 u32 per 64-row tile)
     size_t ring_n_phases = 0;
     uint32_t *d_phase_ptr = nullptr;
     smh::RingPhase *d_phases = nullptr;

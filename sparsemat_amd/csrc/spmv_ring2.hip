@@ -257,10 +257,12 @@ template <typename T, int LANES, int CH, bool C16, int RING>
 __global__ void __launch_bounds__((Ring2Cfg<T, RING>::kThreads), 4)  // 4 waves per SIMD: 16 waves per CU either way
 k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint16_t *__restrict__ col16,
              const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
-             const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases) {
+             const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases, uint32_t bands) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];  // RING * sizeof(T), dynamic
     T *ring = reinterpret_cast<T *>(ring_raw);
-    constexpr uint32_t MASK = RING - 1;
+    // bands == 1: one window, slot = column mod RING.  bands == 4 (banded plan, C16 only): band k owns slots
+    // [k * S, (k + 1) * S), S = RING / 4, slot = k * S + column mod S -- which is what col16 then holds
+    const uint32_t MASK = (bands == 4u ? (uint32_t)RING / 4u : (uint32_t)RING) - 1u;
     constexpr int kRing2Threads = Ring2Cfg<T, RING>::kThreads;
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);  // XCD-aware: neighbours share an L2
@@ -269,10 +271,17 @@ k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
     const uint32_t p0 = phase_ptr[lb], p1 = phase_ptr[lb + 1];
     for (uint32_t p = p0; p < p1; ++p) {
         const RingPhase ph = phases[p];
-        if (ph.load_hi > ph.load_lo) {
+        const bool more = bands == 4u && (ph.band_hi[0] > ph.band_lo[0] || ph.band_hi[1] > ph.band_lo[1] || ph.band_hi[2] > ph.band_lo[2]);
+        if (ph.load_hi > ph.load_lo || more) {
             __syncthreads();  // the previous phase's gathers are done before its slots are overwritten
             for (uint64_t cidx = (uint64_t)ph.load_lo + threadIdx.x; cidx < ph.load_hi; cidx += kRing2Threads)
                 ring[cidx & MASK] = x[cidx];
+            if (more) {
+#pragma unroll
+                for (uint32_t k = 0; k < 3; ++k)
+                    for (uint64_t cidx = (uint64_t)ph.band_lo[k] + threadIdx.x; cidx < ph.band_hi[k]; cidx += kRing2Threads)
+                        ring[(k + 1u) * (MASK + 1u) + (cidx & MASK)] = x[cidx];
+            }
             __syncthreads();
         }
         // gather mode of the phase: 1 = LDS ring, 0 = L1/L2-cached global gathers, 2 = L1-bypassing (nt) global
@@ -322,7 +331,8 @@ int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size
 template <typename T, int RING>
 static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16, const T *val,
                           const T *x, T *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
-                          const uint32_t *phase_ptr, const RingPhase *phases, hipStream_t s) {
+                          const uint32_t *phase_ptr, const RingPhase *phases, uint32_t bands, hipStream_t s) {
+    if (bands == 4u && !col16) return fail(SMH_ERR_INVALID, "banded ring plan without the 16-bit slot array");
     // entries the streaming kernel may touch: everything when the arrays are padded to a multiple of 4,
     // else only whole chunks (the rest goes to k_ring2_tail)
     const uint64_t nnz_lim = padded ? nnz : (nnz & ~uint64_t(3));
@@ -342,7 +352,7 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
             attr_set = true;                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N, RING>), grid, block, lds_bytes, s, off, col, col16, val, x, y,      \
-                           (uint32_t)nnz_lim, last_chunk, phase_ptr, phases);                                            \
+                           (uint32_t)nnz_lim, last_chunk, phase_ptr, phases, bands);                                     \
     } while (0)
 #define SMH_R2_LAUNCH(L, C)                                            \
     do {                                                               \
@@ -376,19 +386,21 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
 // ring_entries: what the phase plan was built for (kRingEntries; kRingEntriesWide for f32 matrices that need it)
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
-                      const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, hipStream_t s) {
+                      const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, unsigned bands,
+                      hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
+    if (bands != 1u && bands != 4u) return fail(SMH_ERR_INVALID, "ring kernel: %u bands", bands);
     if (dtype == SMH_F64) {
         if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "f64 ring kernel: ring of %u columns", ring_entries);
         return launch_ring2_t<double, kRingEntries>(lanes, chunks, off, col, col16, (const double *)val, (const double *)x,
-                                                    (double *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, s);
+                                                    (double *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, s);
     }
     if (ring_entries == (unsigned)kRingEntriesWide)
         return launch_ring2_t<float, kRingEntriesWide>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x,
-                                                       (float *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, s);
+                                                       (float *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, s);
     if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "ring kernel: ring of %u columns", ring_entries);
     return launch_ring2_t<float, kRingEntries>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x, (float *)y,
-                                               n_rows, nnz, padded, n_blocks, phase_ptr, phases, s);
+                                               n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, s);
 }
 
 }  // namespace smh

@@ -50,13 +50,13 @@ __device__ __forceinline__ double st_add(double a, double b) { return __dadd_rn(
 // entries counts as described).
 __global__ void __launch_bounds__(kBlock)
 k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, uint64_t n_rows, uint64_t n_tiles,
-                 uint64_t max_entries, uint64_t max_width, uint64_t max_total, bool count_empty,
+                 uint64_t tile_rows, uint64_t max_entries, uint64_t max_width, uint64_t max_total, bool count_empty,
                  uint32_t *__restrict__ win, uint32_t *__restrict__ n_windowed) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     for (uint64_t t = wave; t < n_tiles; t += n_waves) {
-        const uint64_t r0 = t * kStreamRows, r1 = r0 + kStreamRows < n_rows ? r0 + kStreamRows : n_rows;
+        const uint64_t r0 = t * tile_rows, r1 = r0 + tile_rows < n_rows ? r0 + tile_rows : n_rows;
         const uint64_t k0 = off[r0], k1 = off[r1];
         uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
         bool ok = k1 > k0 && k1 - k0 <= max_entries;
@@ -137,7 +137,9 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
         }
         if (lane < 8) {
             const int k = lane >> 1;
-            win[8 * t + lane] = ok ? ((lane & 1) ? hi[k] : lo[k]) : 0u;
+            // count_empty mode distinguishes "no entries" (all zero) from "not describable" (interval 0 = [1, 0))
+            const uint32_t none = (count_empty && k1 > k0 && lane == 0) ? 1u : 0u;
+            win[8 * t + lane] = ok ? ((lane & 1) ? hi[k] : lo[k]) : none;
         }
         if (lane == 0 && (ok || (count_empty && k1 == k0))) atomicAdd(n_windowed, 1u);  // integer count: exact
     }
@@ -467,7 +469,22 @@ int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_row
     const uint64_t max_width = for_codes ? (uint64_t)kStreamCodeWidth : (uint64_t)kStreamXWin;
     const uint64_t max_total = for_codes ? ~uint64_t(0) : (uint64_t)kStreamXWin;
     hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles,
-                       max_entries, max_width, max_total, for_codes, win, d_count);
+                       (uint64_t)kStreamRows, max_entries, max_width, max_total, for_codes, win, d_count);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+// the same inspector over tiles of `tile_rows` rows with intervals of at most max_width columns each (K1r's banded
+// ring: 64-row tiles, a quarter of the ring per interval); tiles without entries count as described
+int launch_tile_intervals(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t tile_rows, size_t max_width,
+                          uint32_t *win, uint32_t *d_count, hipStream_t s) {
+    const uint64_t n_tiles = (n_rows + tile_rows - 1) / tile_rows;
+    SMH_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+    if (n_tiles == 0) return SMH_OK;
+    uint64_t blocks = (n_tiles * kWave + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles,
+                       (uint64_t)tile_rows, ~uint64_t(0), (uint64_t)max_width, ~uint64_t(0), true, win, d_count);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }

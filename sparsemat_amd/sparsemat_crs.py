@@ -191,12 +191,26 @@ class SparseMatCRS:
         check(lib().smh_crs_ring_entries(self._h, C.byref(out)))
         return out.value
 
+    def ring_bands(self, intervals=False):
+        """1 (one sliding window) or 4 (banded ring); with ``intervals`` also the per-tile column intervals
+        [n_tiles64, 4, 2] of a banded plan (None otherwise)."""
+        bands = C.c_uint32()
+        check(lib().smh_crs_ring_bands(self._h, C.byref(bands), None))
+        if not intervals:
+            return bands.value
+        if bands.value != 4:
+            return bands.value, None
+        table = np.zeros(((self.n_rows() + 63) // 64, 4, 2), dtype=np.uint32)
+        check(lib().smh_crs_ring_bands(self._h, C.byref(bands), table.ctypes.data))
+        return bands.value, table
+
     def ring_plan(self):
-        """(n_blocks, ring_fraction, active, phase_ptr, phases[n,5]) of the K1r plan."""
+        """(n_blocks, ring_fraction, active, phase_ptr, phases[n,11]) of the K1r plan; a phase row is
+        (row_begin, row_end, load_lo, load_hi, use_ring, lo1, lo2, lo3, hi1, hi2, hi3)."""
         nb, nph, frac, act = C.c_uint32(), C.c_size_t(), C.c_double(), C.c_int()
         check(lib().smh_crs_ring_plan(self._h, C.byref(nb), C.byref(nph), C.byref(frac), C.byref(act), None, None))
         ptr = np.zeros(nb.value + 1, dtype=np.uint32)
-        ph = np.zeros((nph.value, 5), dtype=np.uint32)
+        ph = np.zeros((nph.value, 11), dtype=np.uint32)
         check(lib().smh_crs_ring_plan(self._h, None, None, None, None, ptr.ctypes.data,
                                       ph.ctypes.data if nph.value else None))
         return nb.value, frac.value, bool(act.value), ptr, ph

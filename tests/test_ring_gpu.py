@@ -17,30 +17,51 @@ def check_plan(m, off, col):
     n_rows = len(off) - 1
     ring = m.ring_entries()  # 16384 (64 KiB of f32, 128 KiB of f64) or, for f32 rows that need it, 32768
     assert ring in (RING_ENTRIES, 2 * RING_ENTRIES) and (ring == RING_ENTRIES or m.dtype == np.float32)
+    bands, intervals = m.ring_bands(intervals=True)
+    assert bands in (1, 4)
+    S = ring // bands  # columns per band
     nb, frac, active, ptr, ph = m.ring_plan()
     assert nb % 8 == 0 and len(ptr) == nb + 1 and ptr[0] == 0 and ptr[-1] == len(ph)
     assert np.all(np.diff(ptr.astype(np.int64)) >= 0)
     next_row = 0
     ring_rows = 0
     for b in range(nb):
-        lo = hi = 0
+        win = [[0, 0] for _ in range(4)]  # band k holds columns [lo, hi): what its slots contain after the loads so far
         for p in range(ptr[b], ptr[b + 1]):
-            rb, re, llo, lhi, use = (int(v) for v in ph[p])
+            row = [int(v) for v in ph[p]]
+            rb, re, use = row[0], row[1], row[4]
+            loads = [(row[2], row[3])] + [(row[5 + k], row[8 + k]) for k in range(3)]
             assert rb == next_row and re > rb and rb % 64 == 0
             next_row = re
-            if llo < lhi:
-                assert lhi - llo <= ring
-                if llo == hi and hi > lo:  # continuation of the window
-                    hi = lhi
-                    lo = max(lo, hi - ring)
+            for k, (llo, lhi) in enumerate(loads):
+                if llo >= lhi:
+                    continue
+                assert k == 0 or bands == 4
+                assert lhi - llo <= S
+                lo, hi = win[k]
+                if llo == hi and hi > lo:  # continuation of the band's window: older slots get overwritten
+                    win[k] = [max(lo, lhi - S), lhi]
                 else:  # restart
-                    lo, hi = llo, lhi
+                    win[k] = [llo, lhi]
             if use:
                 ring_rows += re - rb
-                cols = col[off[rb]:off[re]]
-                if len(cols):
-                    assert cols.min() >= lo and cols.max() < hi, (b, p, cols.min(), cols.max(), lo, hi)
-                    assert hi - lo <= ring
+                for t in range(rb // 64, (re + 63) // 64):
+                    r0, r1 = t * 64, min(n_rows, t * 64 + 64)
+                    cols = col[off[r0]:off[r1]]
+                    if not len(cols):
+                        continue
+                    if bands == 1:
+                        assert cols.min() >= win[0][0] and cols.max() < win[0][1], (b, p, t)
+                    else:  # every column of the tile lies in one of its intervals, interval k inside band k's window
+                        iv = [(int(a), int(e)) for a, e in intervals[t] if e > a]
+                        assert iv and all(iv[i][1] <= iv[i + 1][0] for i in range(len(iv) - 1))
+                        inside = np.zeros(len(cols), bool)
+                        for k, (a, e) in enumerate(iv):
+                            assert e - a <= S and a >= win[k][0] and e <= win[k][1], (b, p, t, k, (a, e), win[k])
+                            inside |= (cols >= a) & (cols < e)
+                        assert inside.all(), (b, p, t)
+                for k in range(4):
+                    assert win[k][1] - win[k][0] <= S
     assert next_row == n_rows
     assert abs(frac - ring_rows / max(n_rows, 1)) < 1e-12
     return frac, active
@@ -137,6 +158,47 @@ def test_wide_ring_for_f32_bands_beyond_16384_columns(gpu, dtype):
         y = m.mvp(x, variant="vector")
         assert_spmv_close(y, off, col, val, x, "wide ring lanes %d" % lanes)
         assert np.array_equal(y, m.mvp(x, variant="vector"))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_banded_ring_for_stencils(gpu, dtype):
+    """Rows that reference a few narrow column intervals far apart (7-point stencil on a 200 x 200 x 30 grid: the
+    planes are 40 000 columns apart, more than any single window) take the BANDED ring: 4 bands of a quarter of the
+    ring, band k sliding over the tiles' k-th interval.  Plan invariants against the actual columns (incl. the
+    boundary planes, where tiles have 2 instead of 3 intervals) and value parity for every lane width; the same
+    for a 27-point stencil assembled from an element stream (unsorted rows) and after sort_rows."""
+    g = (200, 200, 30)
+    n = g[0] * g[1] * g[2]
+    off, col, val = oracle.laplace3d(*g, dtype)
+    rng = np.random.default_rng(5)
+    val = (val * rng.uniform(0.5, 1.5, len(val))).astype(dtype)  # no special structure in the values
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    frac, _ = check_plan(m, off, col)
+    assert m.ring_bands() == 4 and frac > 0.95
+    for lanes in (2, 4, 8):
+        m.set_vector_lanes(lanes)
+        y = m.mvp(x, variant="vector")
+        assert_spmv_close(y, off, col, val, x, "banded ring lanes %d" % lanes)
+        assert np.array_equal(y, m.mvp(x, variant="vector"))
+    # 27-point stencil from a hexahedral element stream: rows in first-appearance order
+    ge = 60
+    nodes = np.arange((ge + 1) ** 3, dtype=np.uint32).reshape(ge + 1, ge + 1, ge + 1)
+    corners = np.stack([nodes[dx:ge + dx, dy:ge + dy, dz:ge + dz].ravel()
+                        for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)], axis=1)
+    t_rows = np.repeat(corners, 8, axis=1).ravel()
+    t_cols = np.tile(corners, (1, 8)).ravel()
+    t_vals = rng.uniform(-1, 1, len(t_rows)).astype(dtype)
+    m27 = sm.SparseMatCRS.from_triplets(t_rows, t_cols, t_vals)
+    off, col, val = m27.raw_parts()
+    n27 = m27.n_rows()
+    x = rng.uniform(-1, 1, n27).astype(dtype)
+    assert m27.resolved_variant()[0] == "vector"
+    check_plan(m27, off, col)
+    assert_spmv_close(m27.mvp(x), off, col, val, x, "27-point")
+    m27.sort_rows()
+    off, col, val = m27.raw_parts()
+    assert_spmv_close(m27.mvp(x), off, col, val, x, "27-point, rows sorted")
 
 
 def test_ring_small_and_edge_shapes(gpu):
