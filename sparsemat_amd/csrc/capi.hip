@@ -192,8 +192,18 @@ static int ensure_merge_ws(smh_crs *m) {
 }
 
 // K1r: inspector pass + host plan, once per matrix
-static int ensure_ring_plan(smh_crs *m) {
-    if (m->ring_planned) return SMH_OK;
+// with_bands = false: the single-window plans only (what AUTO needs at create time from a matrix with rows too short
+// for the lane-group kernels anyway); the banded attempt -- an inspector pass, a table readback, a host pass over the
+// tiles: ~50 ms at 134 M rows -- then waits until the VECTOR family is actually used.
+static int ensure_ring_plan(smh_crs *m, bool with_bands = true) {
+    if (m->ring_planned && (!with_bands || m->ring_bands_tried)) return SMH_OK;
+    if (m->ring_planned) {  // planned without the banded attempt: plan again, completely
+        (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases);
+        m->d_phase_ptr = nullptr;
+        m->d_phases = nullptr;
+        m->ring_planned = false;
+    }
+    m->ring_bands_tried = with_bands;
     const size_t n_tiles = (m->n_rows + 63) / 64;
     int cus = 256;
     hipDeviceProp_t prop;
@@ -263,7 +273,7 @@ static int ensure_ring_plan(smh_crs *m) {
     // structured grids) get the BANDED ring -- four bands of a quarter of the ring, one per interval of the tile.
     m->ring_bands = 1;
     const char *band_env = getenv("SMH_RING_BANDS");  // tuning knob: 0 = never
-    if (m->ring_fraction < 0.5 && n_tiles && m->nnz && !(band_env && atoi(band_env) == 0)) {
+    if (with_bands && m->ring_fraction < 0.5 && n_tiles && m->nnz && !(band_env && atoi(band_env) == 0)) {
         const unsigned sizes[2] = {(unsigned)kRingEntries, (unsigned)kRingEntriesWide};
         const int n_sizes = m->dtype == SMH_F32 && !(wide_env && atoi(wide_env) == 0) ? 2 : 1;
         std::vector<uint32_t> h_win(n_tiles * 8);
@@ -560,8 +570,9 @@ static int finish_create(smh_crs *m, int validate) {
         // x larger than the L2s: take the locality statistic AUTO needs (one pass over columns[]; it is the K1r
         // inspector, so its plan is ready too)
         // ... and rows long enough for the lane-group kernels: AUTO wants to know whether their columns fit the ring
-        if (m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes || (m->n_rows && m->nnz > 8 * m->n_rows))
-            SMH_TRY(ensure_ring_plan(m));
+        const bool lane_group_rows = m->n_rows && m->nnz > 8 * m->n_rows;  // (mean row > 8)
+        if (m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes || lane_group_rows)
+            SMH_TRY(ensure_ring_plan(m, lane_group_rows));
     }
     return SMH_OK;
 }
@@ -828,7 +839,7 @@ int smh_crs_set_colblock_shift(smh_crs *m, uint32_t shift) {
 int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int *rows_per_thread_out,
                      double *span_fraction_out, uint32_t *offsets_out, uint32_t *columns_out, void *values_out) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
-    SMH_TRY(ensure_ring_plan(m));  // the locality statistic
+    SMH_TRY(ensure_ring_plan(m, false));  // the locality statistic
     SMH_TRY(ensure_colblock(m));
     if (shift_out) *shift_out = m->cb_shift;
     if (n_blocks_out) *n_blocks_out = m->cb_blocks;

@@ -172,6 +172,7 @@ struct smh_crs {
     double ring_fraction = 0.0;  // share of rows whose gathers are served from the LDS ring
     unsigned ring_entries = smh::kRingEntries;  // ring size the plan was built for
     unsigned ring_bands = 1;                    // 1: one sliding window; 4: banded ring (needs d_col16 = ring slots)
+    bool ring_bands_tried = false;              // the plan in place was built with the banded attempt allowed
     uint32_t *d_ring_win = nullptr;             // banded plan: the tiles' column intervals (8 u32 per 64-row tile)
     size_t ring_n_phases = 0;
     uint32_t *d_phase_ptr = nullptr;
