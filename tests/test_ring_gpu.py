@@ -201,6 +201,42 @@ def test_banded_ring_for_stencils(gpu, dtype):
     assert_spmv_close(m27.mvp(x), off, col, val, x, "27-point, rows sorted")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_banded_ring_random_clusters(gpu, dtype):
+    """Adversarial input for the banded plan: every 64-row tile draws 1-6 column clusters (more than 4: not
+    describable -> global-gather phase), cluster positions jump forwards and backwards from tile to tile, some
+    tiles are empty, some clusters are wider than a band.  The simulated ring contents must cover every ring
+    phase's columns and the product must match the oracle."""
+    rng = np.random.default_rng(2024)
+    n_rows, n_cols = 64 * 700 + 13, 3_000_000
+    lens = rng.integers(0, 25, n_rows)
+    for t in range(5, (n_rows + 63) // 64, 37):
+        lens[t * 64:t * 64 + 64] = 0  # tiles without entries
+    off = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = np.empty(int(off[-1]), np.uint32)
+    base = 0
+    for t in range((n_rows + 63) // 64):
+        r0, r1 = t * 64, min(n_rows, t * 64 + 64)
+        a, b = off[r0], off[r1]
+        n_clusters = int(rng.integers(1, 7))
+        base = (base + int(rng.integers(-40_000, 90_000))) % (n_cols - 600_000)  # wanders both ways
+        centres = base + np.sort(rng.choice(500_000, n_clusters, replace=False))
+        width = 6000 if t % 53 == 7 else int(rng.integers(50, 900))  # now and then wider than a 4096-column band
+        pick = rng.integers(0, n_clusters, b - a)
+        col[a:b] = centres[pick] + rng.integers(0, width, b - a)
+    val = rng.uniform(-1, 1, len(col)).astype(dtype)
+    x = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    frac, _ = check_plan(m, off, col)
+    assert m.ring_bands() == 4 and 0.5 <= frac < 1.0  # the > 4-cluster and the wide tiles stay outside the ring
+    for lanes in (4, 8):
+        m.set_vector_lanes(lanes)
+        y = m.mvp(x, variant="vector")
+        assert_spmv_close(y, off, col, val, x, "random clusters lanes %d" % lanes)
+        assert np.array_equal(y, m.mvp(x, variant="vector"))
+
+
 def test_ring_small_and_edge_shapes(gpu):
     f = np.float32
     rng = np.random.default_rng(4)
