@@ -206,7 +206,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
-        o0[rr] = off[r < r1 ? r : r1];
+        o0[rr] = off[r < r1 ? r : r1];  // (non-temporal loads here: no measurable difference)
         o1[rr] = off[r + 1 < r1 ? r + 1 : r1];
     }
     const uint32_t k0 = off[r0], k1 = off[r1];  // tile-uniform: scalar loads
