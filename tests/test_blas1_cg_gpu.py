@@ -116,6 +116,27 @@ def test_cg_laplace3d_matches_oracle(gpu, dtype, tol):
             np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=50 * tol)
 
 
+def test_cg_64_cubed_f64_convergence_parity(gpu):
+    """the 64^3 f64 convergence-parity case with the reference stop rule (sqrt(r.r) < tol, absolute,
+    tested before the beta update): same iteration count as the oracle (+-2: the reductions are regrouped) and the
+    same solution, for the bit-exact SpMV kernel and for AUTO; b = A.1, x0 = 0."""
+    g, dtype, tol = 64, np.float64, 1e-9
+    n = g ** 3
+    off, col, val = oracle.laplace3d(g, g, g, dtype)
+    b = oracle.spmv(off, col, val, np.ones(n, dtype))
+    x_ref, it_ref, rr_ref = oracle.cg(n, n, off, col, val, b, np.zeros(n, dtype), tol=tol, iter_max=2000)
+    assert 50 < it_ref < 2000 and np.sqrt(rr_ref) < tol
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    for variant in ("stream", "auto"):
+        xd, bd = sm.DenseVec.from_vec(np.zeros(n, dtype)), sm.DenseVec.from_vec(b)
+        cg = sm.ConjugateGradient(tol, 2000, variant=variant)
+        cg.solve(m, bd, xd)
+        assert abs(cg.iterations - it_ref) <= 2, (variant, cg.iterations, it_ref)
+        assert np.sqrt(cg.r_norm_squared) < tol
+        np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=100 * tol)
+        np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=100 * tol)
+
+
 def test_cg_iter_max_and_exact_iteration_semantics(gpu):
     """iter_max bodies are entered at most; with SEQ SpMV and equal scalars the first iteration is
     bit-identical to the oracle's (element-wise updates round like the reference)."""
