@@ -228,6 +228,9 @@ def main():
             "exchange": exchange_mode,
         },
         "gflops": 2.0 * nnz * world / (elapsed / args.steps) / 1e9,
+        # per step: the local SpMV kernel (HIP events, this rank) and what the rest of the step costs (the exchange and
+        # launch gaps; max over ranks is in ms_per_step)
+        "spmv_kernel_ms": kernel_ms, "step_minus_kernel_ms": ms_per_step - kernel_ms,
         "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBPS * world),
         "algorithmic_bytes_per_gpu_step": bytes_rank,
         "roofline": {
