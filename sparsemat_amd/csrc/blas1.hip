@@ -65,7 +65,10 @@ k_ew(T *__restrict__ x, const T *__restrict__ y, uint64_t n, T a, const T *__res
 
 static inline unsigned stream_grid(uint64_t work_items) {
     uint64_t blocks = (work_items + kBlock - 1) / kBlock;
-    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    // 256 CUs x 3 blocks, grid-stride the rest: measured on 2^27-element vectors, 768 blocks stream at 5.4-5.5 TB/s where
+    // 2048 reach 4.8-5.1 and 256 fall far behind (profiles/r01_blas1_bench.log); whole multiples of the CU count only
+    static const uint64_t cap = getenv("SMH_EW_BLOCKS") ? (uint64_t)atoll(getenv("SMH_EW_BLOCKS")) : 768;  // tuning knob
+    if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     return (unsigned)blocks;
 }

@@ -224,7 +224,11 @@ template <typename T>
 static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T *partials, const T *dot_partials,
                           uint32_t dot_count, hipStream_t s) {
     CgScalars<T> *sc = (CgScalars<T> *)scv;
-    const unsigned rb = reduce_blocks(n);
+    // 2 blocks per CU for the two vector sweeps of the tail: 2.51-2.57 ms per C4 iteration against 2.66-2.69 with 1024 / 2048
+    // blocks in the same call (profiles/r01_cg_grid_sweep.log)
+    static const unsigned grid_cap = getenv("SMH_CG_BLOCKS") ? (unsigned)atoi(getenv("SMH_CG_BLOCKS")) : 512u;  // tuning knob
+    unsigned rb = reduce_blocks(n);
+    if (rb > grid_cap) rb = grid_cap;
     const bool vec = cg_aligned16(x) && cg_aligned16(r) && cg_aligned16(p) && cg_aligned16(ap);
     // p . Ap: either the SpMV epilogue already left per-tile partials (fused), or a separate two-stage dot
     if (dot_partials && dot_count > (uint32_t)kReducePartials) {
@@ -248,7 +252,8 @@ static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T 
     hipLaunchKernelGGL(k_cg_beta<T>, dim3(1), dim3(kBlock), 0, s, sc, partials, rb);
     SMH_HIP(hipGetLastError());
     uint64_t pb = (n / CgVec<T>::N + kBlock) / kBlock;
-    if (pb > 2048) pb = 2048;
+    static const uint64_t p_cap = getenv("SMH_CG_P_BLOCKS") ? (uint64_t)atoll(getenv("SMH_CG_P_BLOCKS")) : 512;  // tuning knob
+    if (pb > p_cap) pb = p_cap;
     if (vec)
         hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, (uint64_t)n);
     else
