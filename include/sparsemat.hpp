@@ -149,6 +149,23 @@ class SparseMatCRS {
 
     // Sortable::sort_row (sparsemat_crs.rs:163-172) for every row: ascending columns, stable
     void sort_rows() { detail::check(smh_crs_sort_rows(h_)); }
+    // SparseMatrix::transpose (sparsematrix.rs:174-184): `ret.set(j, i, val)` over the entries in storage order, into a
+    // fresh SparseMatCRS -- same arrays as the reference's container ends up with (rows reversed, first-push quirk)
+    SparseMatCRS transpose() const {
+        SparseMatCRS t;
+        detail::check(smh_crs_transpose(h_, &t.h_));
+        return t;
+    }
+    // ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as arrays: rows[k] = row of entry k; iter_col(j)
+    // (:193-204) walks entries[col_ptr[j] .. col_ptr[j+1]) and yields (rows[e], values[e])
+    void column_info(std::vector<uint32_t> &rows, std::vector<uint32_t> &col_ptr, std::vector<uint32_t> &entries) const {
+        rows.assign(n_non_zero_entries() ? n_non_zero_entries() : 1, 0u);
+        entries.assign(rows.size(), 0u);
+        col_ptr.assign(n_cols() + 1, 0u);
+        detail::check(smh_crs_column_info(h_, rows.data(), col_ptr.data(), entries.data()));
+        rows.resize(n_non_zero_entries());
+        entries.resize(n_non_zero_entries());
+    }
     // the CRS arrays as stored (offset_rows, columns, values)
     void raw_parts(std::vector<uint32_t> &offset_rows, std::vector<uint32_t> &columns, std::vector<T> &values) const {
         offset_rows.assign(n_rows() + 1, 0u);

@@ -105,6 +105,34 @@ int smh_crs_assemble(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const 
 int smh_crs_assemble_dev(smh_dtype dtype, size_t n_ops, const uint32_t *rows_dev,
                          const uint32_t *cols_dev, const void *values_dev, const uint8_t *ops_dev,
                          smh_crs **out);
+/* smh_crs_replay: the same stream applied to a SparseMatCRS itself -- get_mut sparsemat_crs.rs:143-149
+ * over find_index :54-67 / push :71-92 -- which is the container SparseMatrix::transpose and ::prod
+ * fill through `set` (sparsematrix.rs:174-210).  Same entries and values as smh_crs_assemble, but
+ * a row stores them in REVERSE order of first appearance (push inserts at the row's start, :85-87),
+ * and the container's first-push quirk is honoured (:75-81: the first push leaves n_rows == 0):
+ * if the second operation's row is smaller than the first one's, the first entry is orphaned
+ * (Vec::resize truncates offset_rows) -- no row reaches it, so it is not part of the result
+ * arrays although the reference's n_non_zero_entries() still counts it and n_cols covers it; if
+ * the second operation names the same (row, column), the first keeps an entry of its own at the
+ * end of the row; a single operation gives a matrix without rows.  Bit-exact. */
+int smh_crs_replay(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols,
+                   const void *values, const uint8_t *ops, smh_crs **out);
+int smh_crs_replay_dev(smh_dtype dtype, size_t n_ops, const uint32_t *rows_dev,
+                       const uint32_t *cols_dev, const void *values_dev, const uint8_t *ops_dev,
+                       smh_crs **out);
+/* SparseMatrix::transpose (sparsematrix.rs:174-184) of a SparseMatCRS: `ret.set(j, i, val)` for
+ * every entry in row-major storage order, replayed as above (so row j of the result lists the
+ * source rows in DESCENDING order of visit, duplicates of (i, j) keep the last value, and the
+ * quirk drops the very first entry when the second stored entry has a smaller column). */
+int smh_crs_transpose(const smh_crs *a, smh_crs **out);
+/* ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as flat arrays: rows[k] = row of
+ * entry k (the reference's `rows` vector), and its per-column IndexList (entry indices in storage
+ * order, indexlist.rs:62-83) as col_ptr[n_cols + 1] / entries[nnz]: iter_col(j) (:193-204, next
+ * :211-219) yields (rows[e], values[e]) for e in entries[col_ptr[j] .. col_ptr[j+1]).  A column
+ * index >= n_cols is SMH_ERR_INDEX_RANGE.  The _dev form writes device arrays. */
+int smh_crs_column_info(const smh_crs *m, uint32_t *rows, uint32_t *col_ptr, uint32_t *entries);
+int smh_crs_column_info_dev(const smh_crs *m, uint32_t *rows_dev, uint32_t *col_ptr_dev,
+                            uint32_t *entries_dev);
 /* Sortable::sort_row (sparsemat_crs.rs:163-172) for every row: ascending columns, stable
  * (duplicates of a column keep their storage order).  Sorts the handle's arrays in place. */
 int smh_crs_sort_rows(smh_crs *m);

@@ -99,6 +99,8 @@ def _declare(L):
         getattr(L, "orc_laplace3d_" + suf).restype = _sz
         getattr(L, "orc_assemble_" + suf).argtypes = [_sz, _u32p, _u32p, fp, C.POINTER(C.c_uint8), C.POINTER(_sz),
                                                        C.POINTER(_sz), C.POINTER(_sz), _u32p, _u32p, fp]
+        getattr(L, "orc_crs_replay_" + suf).argtypes = [_sz, _u32p, _u32p, fp, C.POINTER(C.c_uint8), C.POINTER(_sz),
+                                                         C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), _u32p, _u32p, fp]
         getattr(L, "orc_crs_sort_rows_" + suf).argtypes = [_sz, _u32p, _u32p, fp]
         getattr(L, "orc_crs_sort_rows_" + suf).restype = None
     L.orc_par_rows_per_block.argtypes = [_sz, _sz]
@@ -375,6 +377,55 @@ def assemble(rows, cols, vals, ops=None):
         None if ops_a is None else ops_a.ctypes.data_as(C.POINTER(C.c_uint8)),
         C.byref(nr), C.byref(nc), C.byref(nnz), _p(off, _u32p), _p(col, _u32p), _p(val, fp)))
     return nr.value, nc.value, off[:nr.value + 1].copy(), col[:nnz.value].copy(), val[:nnz.value].copy()
+
+
+def crs_replay(rows, cols, vals, ops=None):
+    """The same stream replayed on a SparseMatCRS (sparsemat_crs.rs:54-92,143-149), first-push quirk included.
+    Returns (n_rows, n_cols, offset_rows[n_rows+1], columns, values, stored): columns / values hold what iter_row
+    reaches (offset_rows[n_rows] entries); `stored` = columns.len() of the reference (an orphaned first entry counts)."""
+    vals = np.ascontiguousarray(vals)
+    suf, fp = _suf(vals.dtype)
+    rows, cols = _c(rows, np.uint32), _c(cols, np.uint32)
+    n = len(vals)
+    assert len(rows) == n and len(cols) == n
+    ops_a = None if ops is None else _c(ops, np.uint8)
+    off = np.zeros((int(rows.max()) + 2) if n else 1, np.uint32)
+    col = np.zeros(max(n, 1), np.uint32)
+    val = np.zeros(max(n, 1), vals.dtype)
+    nr, nc, nnz, stored = _sz(), _sz(), _sz(), _sz()
+    _check(getattr(lib(), "orc_crs_replay_" + suf)(
+        n, _p(rows, _u32p), _p(cols, _u32p), _p(vals, fp),
+        None if ops_a is None else ops_a.ctypes.data_as(C.POINTER(C.c_uint8)),
+        C.byref(nr), C.byref(nc), C.byref(nnz), C.byref(stored), _p(off, _u32p), _p(col, _u32p), _p(val, fp)))
+    return nr.value, nc.value, off[:nr.value + 1].copy(), col[:nnz.value].copy(), val[:nnz.value].copy(), stored.value
+
+
+def transpose(offset_rows, columns, values):
+    """SparseMatrix::transpose (sparsematrix.rs:174-184) of a SparseMatCRS: `ret.set(j, i, val)` for every entry in
+    row-major storage order, into a fresh SparseMatCRS.  Same return as crs_replay."""
+    off = _c(offset_rows, np.uint32)
+    n_rows = len(off) - 1
+    src_rows = np.repeat(np.arange(n_rows, dtype=np.uint32), np.diff(off.astype(np.int64)))
+    nnz = int(off[-1]) if n_rows else 0
+    return crs_replay(_c(columns, np.uint32)[:nnz], src_rows, np.ascontiguousarray(values)[:nnz], np.ones(nnz, np.uint8))
+
+
+def column_info(offset_rows, columns, n_cols):
+    """ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191): rows[k] = row of entry k, and per column the entry
+    indices in storage order (what IndexList::iter_row of indexlist_col yields, indexlist.rs:62-83), as a CSC-like
+    (col_ptr[n_cols+1], entries[nnz]) pair.  iter_col(j) = [(rows[e], values[e]) for e in entries[col_ptr[j]:col_ptr[j+1]]]."""
+    off = _c(offset_rows, np.uint32)
+    n_rows = len(off) - 1
+    rows = np.repeat(np.arange(n_rows, dtype=np.uint32), np.diff(off.astype(np.int64)))
+    nnz = len(rows)
+    cols = _c(columns, np.uint32)[:nnz]
+    lists = [[] for _ in range(n_cols)]
+    for k in range(nnz):  # indexlist_col.push(j) in storage order
+        lists[int(cols[k])].append(k)
+    col_ptr = np.zeros(n_cols + 1, np.uint32)
+    col_ptr[1:] = np.cumsum([len(l) for l in lists], dtype=np.uint64).astype(np.uint32)
+    entries = np.array([e for l in lists for e in l], np.uint32)
+    return rows, col_ptr, entries
 
 
 def crs_sort_rows(offset_rows, columns, values):

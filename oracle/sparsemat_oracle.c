@@ -471,3 +471,57 @@ DEF_ASSEMBLE(f64, double)
 
 DEF_SORT_ROWS(f32, float)
 DEF_SORT_ROWS(f64, double)
+
+/* The same operation stream replayed on a SparseMatCRS itself (the container Trait::transpose and prod fill
+ * through `set`, sparsematrix.rs:174-184,186-210): get_mut sparsemat_crs.rs:143-149 -> find_index :54-67 (first
+ * match in storage order, only rows < n_rows) / push :71-92, restated literally:
+ *   - push inserts at the START of the row (index = offset_rows[i]) and bumps every later offset;
+ *   - the very first push sizes offset_rows to i + 2 but leaves n_rows == 0 (:75-76), so the second operation never
+ *     finds anything and pushes again; Vec::resize(i + 2, last) then TRUNCATES offset_rows when its row is smaller
+ *     than the first one's -- the first entry stays in columns / values (n_non_zero_entries counts it, :132-134)
+ *     but no row addresses it any more;
+ *   - n_cols = largest pushed column + 1.
+ * Outputs: offset_rows[0..n_rows] (needs max(row) + 2 entries), columns / values [stored] in storage order (need n
+ * entries); *nnz_out = offset_rows[n_rows] (what iter_row reaches), *stored_out = columns.len().  O(n * nnz): small
+ * cases only. */
+#define DEF_CRS_REPLAY(SUF, T)                                                                      \
+    int orc_crs_replay_##SUF(size_t n, const uint32_t *rows, const uint32_t *cols, const T *vals,   \
+                             const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out,            \
+                             size_t *nnz_out, size_t *stored_out, uint32_t *offset_rows,            \
+                             uint32_t *columns, T *values) {                                        \
+        size_t n_rows = 0, n_cols = 0, len_off = 0, stored = 0;                                     \
+        for (size_t k = 0; k < n; ++k) {                                                            \
+            const size_t i = rows[k], j = cols[k];                                                  \
+            size_t index = ORC_UNSET;                                                               \
+            if (i < n_rows)                                                                         \
+                for (size_t q = offset_rows[i]; q < offset_rows[i + 1]; ++q)                        \
+                    if (columns[q] == j) { index = q; break; }                                      \
+            if (index == ORC_UNSET) { /* push(i, j, T::zero()) */                                   \
+                if (j >= n_cols) n_cols = j + 1;                                                    \
+                if (len_off == 0) {                                                                 \
+                    for (size_t q = 0; q < i + 2; ++q) offset_rows[q] = 0;                          \
+                    len_off = i + 2;                                                                \
+                } else if (i >= n_rows) {                                                           \
+                    const uint32_t last = offset_rows[len_off - 1];                                 \
+                    for (size_t q = len_off; q < i + 2; ++q) offset_rows[q] = last;                 \
+                    len_off = i + 2; /* shrinks when i + 2 < len: Vec::resize truncates */          \
+                    n_rows = i + 1;                                                                 \
+                }                                                                                   \
+                if (offset_rows[i] == ORC_UNSET) return ORC_ERR_CAPACITY;                           \
+                index = offset_rows[i];                                                             \
+                memmove(columns + index + 1, columns + index, (stored - index) * sizeof(uint32_t)); \
+                memmove(values + index + 1, values + index, (stored - index) * sizeof(T));          \
+                columns[index] = (uint32_t)j;                                                       \
+                values[index] = (T)0;                                                               \
+                ++stored;                                                                           \
+                for (size_t q = i + 1; q < len_off; ++q) offset_rows[q] += 1;                       \
+            }                                                                                       \
+            if (ops && ops[k]) values[index] = vals[k]; else values[index] = values[index] + vals[k]; \
+        }                                                                                           \
+        *n_rows_out = n_rows; *n_cols_out = n_cols; *stored_out = stored;                           \
+        *nnz_out = n_rows ? offset_rows[n_rows] : 0;                                                \
+        return ORC_OK;                                                                              \
+    }
+
+DEF_CRS_REPLAY(f32, float)
+DEF_CRS_REPLAY(f64, double)

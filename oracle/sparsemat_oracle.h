@@ -31,6 +31,7 @@ extern "C" {
 #define ORC_ERR_INDEX_OOB 1     /* densevec.rs:40-42  values[i] out of bounds      */
 #define ORC_ERR_NOT_SQUARE 2    /* linearsolver.rs:30-32 "Matrix is not symmetric" */
 #define ORC_ERR_SIZE_MISMATCH 3 /* linearsolver.rs:33-36 / densevec.rs:52-54,61-63 */
+#define ORC_ERR_CAPACITY 4      /* sparsemat_crs.rs:82-84 "Maximum number of {} entries reached" */
 
 /* ---- SpMV: sparsematrix.rs:146-158 over sparsemat_crs.rs:102-110 ------- */
 int orc_spmv_f32(size_t n_rows, const uint32_t *offset_rows, const uint32_t *columns,
@@ -134,6 +135,16 @@ int orc_assemble_f32(size_t n, const uint32_t *rows, const uint32_t *cols, const
 int orc_assemble_f64(size_t n, const uint32_t *rows, const uint32_t *cols, const double *vals,
                      const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
                      uint32_t *offset_rows, uint32_t *columns, double *values);
+/* The same stream replayed on a SparseMatCRS (the container Trait::transpose / prod fill through `set`,
+ * sparsematrix.rs:174-210): sparsemat_crs.rs:54-92,143-149 literally, incl. the first-push quirk.
+ * offset_rows needs max(row)+2 entries, columns / values n entries; *nnz_out = entries reachable through
+ * iter_row, *stored_out = columns.len() (an orphaned first entry stays at the tail).  O(n * nnz). */
+int orc_crs_replay_f32(size_t n, const uint32_t *rows, const uint32_t *cols, const float *vals,
+                       const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
+                       size_t *stored_out, uint32_t *offset_rows, uint32_t *columns, float *values);
+int orc_crs_replay_f64(size_t n, const uint32_t *rows, const uint32_t *cols, const double *vals,
+                       const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
+                       size_t *stored_out, uint32_t *offset_rows, uint32_t *columns, double *values);
 /* Sortable::sort_row (sparsemat_crs.rs:163-172) on every row: stable by column */
 void orc_crs_sort_rows_f32(size_t n_rows, const uint32_t *offset_rows, uint32_t *columns, float *values);
 void orc_crs_sort_rows_f64(size_t n_rows, const uint32_t *offset_rows, uint32_t *columns, double *values);

@@ -29,6 +29,11 @@ extern "C" {
     // add_to (ops[k] == 0 / ops null) or set (ops[k] == 1) stream -> the CRS `to_crs()` would return
     pub fn smh_crs_assemble(dtype: c_int, n_ops: usize, rows: *const u32, cols: *const u32, values: *const c_void,
                             ops: *const u8, out: *mut *mut smh_crs) -> c_int;
+    // the same stream applied to a SparseMatCRS itself (push prepends, first-push quirk): what transpose / prod fill
+    pub fn smh_crs_replay(dtype: c_int, n_ops: usize, rows: *const u32, cols: *const u32, values: *const c_void,
+                          ops: *const u8, out: *mut *mut smh_crs) -> c_int;
+    pub fn smh_crs_transpose(a: *const smh_crs, out: *mut *mut smh_crs) -> c_int;
+    pub fn smh_crs_column_info(m: *const smh_crs, rows: *mut u32, col_ptr: *mut u32, entries: *mut u32) -> c_int;
     pub fn smh_crs_sort_rows(m: *mut smh_crs) -> c_int;
     pub fn smh_crs_n_rows(m: *const smh_crs) -> usize;
     pub fn smh_crs_n_cols(m: *const smh_crs) -> usize;

@@ -77,6 +77,26 @@ impl DeviceCrs {
         out
     }
 
+    /// `SparseMatrix::transpose` (src/sparsematrix.rs:174-184) for `Self = SparseMatCRS`: the arrays the reference's
+    /// `ret.set(j, i, val)` loop leaves in a fresh SparseMatCRS (rows reversed, first-push quirk), built on the device.
+    pub fn transpose(&self) -> DeviceCrs {
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ffi::smh_crs_transpose(self.handle, &mut handle) });
+        DeviceCrs { handle, n_rows: unsafe { ffi::smh_crs_n_rows(handle) } }
+    }
+
+    /// `ColumnIter::assemble_column_info` (src/sparsemat_crs.rs:180-191) as arrays `(rows, col_ptr, entries)`:
+    /// `iter_col(j)` yields `(rows[e], values[e])` for `e in entries[col_ptr[j]..col_ptr[j+1]]`.
+    pub fn column_info(&self) -> (Vec<u32>, Vec<u32>, Vec<u32>) {
+        let nnz = unsafe { ffi::smh_crs_nnz(self.handle) };
+        let n_cols = unsafe { ffi::smh_crs_n_cols(self.handle) };
+        let (mut rows, mut col_ptr, mut entries) = (vec![0u32; nnz.max(1)], vec![0u32; n_cols + 1], vec![0u32; nnz.max(1)]);
+        check(unsafe { ffi::smh_crs_column_info(self.handle, rows.as_mut_ptr(), col_ptr.as_mut_ptr(), entries.as_mut_ptr()) });
+        rows.truncate(nnz);
+        entries.truncate(nnz);
+        (rows, col_ptr, entries)
+    }
+
     /// `sort_row(i)` for every row (src/sparsemat_crs.rs:163-172), on the device copy.
     pub fn sort_rows(&mut self) {
         check(unsafe { ffi::smh_crs_sort_rows(self.handle) });

@@ -35,6 +35,11 @@ SIGNATURES = {
     "smh_crs_create_dev": (_int, [_int, _sz, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
     "smh_crs_assemble": (_int, [_int, _sz, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "smh_crs_assemble_dev": (_int, [_int, _sz, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "smh_crs_replay": (_int, [_int, _sz, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "smh_crs_replay_dev": (_int, [_int, _sz, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "smh_crs_transpose": (_int, [_vp, C.POINTER(_vp)]),
+    "smh_crs_column_info": (_int, [_vp, _vp, _vp, _vp]),
+    "smh_crs_column_info_dev": (_int, [_vp, _vp, _vp, _vp]),
     "smh_crs_sort_rows": (_int, [_vp]),
     "smh_crs_destroy": (_int, [_vp]),
     "smh_crs_update_values": (_int, [_vp, _vp]),

@@ -122,8 +122,8 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_asm_fold(const uint32_t *__restrict__ row_s, const uint64_t *__restrict__ cp_s, const T *__restrict__ vals_s,
            const uint8_t *__restrict__ ops_s, const uint32_t *__restrict__ entry_id /* exclusive scan of heads */,
-           uint64_t n, uint32_t *__restrict__ first_pos, uint32_t *__restrict__ uidx, uint32_t *__restrict__ ucol,
-           T *__restrict__ uval) {
+           uint64_t n, bool reverse, uint32_t *__restrict__ first_pos, uint32_t *__restrict__ uidx,
+           uint32_t *__restrict__ ucol, T *__restrict__ uval) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         if (!run_head(row_s, cp_s, k)) continue;
         T acc = T(0);
@@ -136,7 +136,8 @@ k_asm_fold(const uint32_t *__restrict__ row_s, const uint64_t *__restrict__ cp_s
             ++j;
         } while (j < n && !run_head(row_s, cp_s, j));
         const uint32_t u = entry_id[k];
-        first_pos[u] = (uint32_t)cp_s[k];  // the run is in stream order: its head is the first appearance
+        // the run is in stream order: its head is the first appearance (reverse: latest first, as a SparseMatCRS stores)
+        first_pos[u] = reverse ? (uint32_t)(n - 1) - (uint32_t)cp_s[k] : (uint32_t)cp_s[k];
         uidx[u] = u;
         ucol[u] = (uint32_t)(cp_s[k] >> 32);
         uval[u] = acc;
@@ -223,7 +224,7 @@ k_asm_rowwise(const uint32_t *__restrict__ seg, const uint64_t *__restrict__ cp_
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_asm_row_emit(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ off, const uint32_t *__restrict__ lcol,
-               const T *__restrict__ lval, uint64_t n_rows, uint32_t *__restrict__ col, T *__restrict__ val) {
+               const T *__restrict__ lval, uint64_t n_rows, bool reverse, uint32_t *__restrict__ col, T *__restrict__ val) {
     // a block moves the lists of 256 consecutive rows: the output range is walked densely (coalesced stores), the
     // row of an output position found by bisection of the block's 257 offsets held in LDS
     __shared__ uint32_t s_off[kBlock + 1], s_seg[kBlock];
@@ -234,7 +235,7 @@ k_asm_row_emit(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ of
         __syncthreads();  // (the previous group's tables are no longer read)
         if (threadIdx.x < nr) s_seg[threadIdx.x] = seg[r0 + threadIdx.x];
         if (threadIdx.x <= nr) s_off[threadIdx.x] = off[r0 + threadIdx.x];
-        if (threadIdx.x == 0 && nr == (uint32_t)kBlock) s_off[kBlock] = off[r1];
+        if (threadIdx.x == 0 && nr == (uint32_t)kBlock) s_off[kBlock] = off[r1];  // (off has n_rows + 1 entries)
         __syncthreads();
         const uint32_t base = s_off[0], total = s_off[nr] - base;
         for (uint32_t p = threadIdx.x; p < total; p += kBlock) {
@@ -243,7 +244,8 @@ k_asm_row_emit(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ of
                 const uint32_t mid = (lo + hi) >> 1;
                 if (s_off[mid] - base <= p) lo = mid; else hi = mid;
             }
-            const uint64_t src = (uint64_t)s_seg[lo] + (p - (s_off[lo] - base));
+            const uint32_t idx = p - (s_off[lo] - base);  // reverse: a SparseMatCRS prepends (sparsemat_crs.rs:85-87)
+            const uint64_t src = (uint64_t)s_seg[lo] + (reverse ? s_off[lo + 1] - s_off[lo] - 1 - idx : idx);
             col[(uint64_t)base + p] = lcol[src];
             val[(uint64_t)base + p] = lval[src];
         }
@@ -283,7 +285,7 @@ struct Scratch {
 };
 
 template <typename T>
-static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, const T *vals, const uint8_t *ops,
+static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, const T *vals, const uint8_t *ops, bool reverse,
                       size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out, uint32_t **col_out,
                       T **val_out, hipStream_t s) {
     // SMH_ASSEMBLE_TIMING=1: wall time of every stage on stderr (development aid)
@@ -349,7 +351,7 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
             SMH_HIP(hipMemsetAsync(col + n_entries, 0, 4 * sizeof(uint32_t), s));
             SMH_HIP(hipMemsetAsync(val + n_entries, 0, 4 * sizeof(T), s));
             lap("offsets, result allocation");
-            hipLaunchKernelGGL((k_asm_row_emit<T>), dim3(grid_for(n_rows)), dim3(kBlock), 0, s, seg, off, lcol, lval, n_rows, col, val);
+            hipLaunchKernelGGL((k_asm_row_emit<T>), dim3(grid_for(n_rows)), dim3(kBlock), 0, s, seg, off, lcol, lval, n_rows, reverse, col, val);
             SMH_HIP(hipGetLastError());
             SMH_HIP(hipStreamSynchronize(s));
             lap("emit");
@@ -384,8 +386,8 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
     SMH_TRY(tmp_bufs.alloc(&uidx_s, n_entries));
     SMH_TRY(tmp_bufs.alloc(&ucol, n_entries));
     SMH_TRY(tmp_bufs.alloc(&uval, n_entries));
-    hipLaunchKernelGGL((k_asm_fold<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, runs, vals_s, ops_s, head, n, first_pos, uidx,
-                       ucol, uval);
+    hipLaunchKernelGGL((k_asm_fold<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, runs, vals_s, ops_s, head, n, reverse, first_pos,
+                       uidx, ucol, uval);
     SMH_HIP(hipGetLastError());
     // result arrays (owned by the caller; padded like smh_crs_create's)
     uint32_t *off = nullptr, *col = nullptr;
@@ -417,13 +419,15 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
 }
 
 // rows/cols/vals/ops: DEVICE arrays of n operations (ops may be null: all add_to).  n >= 1.
+// reverse_rows: every row in REVERSE order of first appearance -- the layout the same stream leaves in a SparseMatCRS, whose push
+// inserts at the start of the row (sparsemat_crs.rs:85-87); the first-push quirk is the caller's business (capi.hip).
 int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t *cols, const void *vals, const uint8_t *ops,
-                      size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out, uint32_t **col_out,
+                      bool reverse_rows, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out, uint32_t **col_out,
                       void **val_out, hipStream_t s) {
     if (dtype == SMH_F64)
-        return assemble_t<double>(n, rows, cols, (const double *)vals, ops, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
+        return assemble_t<double>(n, rows, cols, (const double *)vals, ops, reverse_rows, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
                                   (double **)val_out, s);
-    return assemble_t<float>(n, rows, cols, (const float *)vals, ops, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
+    return assemble_t<float>(n, rows, cols, (const float *)vals, ops, reverse_rows, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
                              (float **)val_out, s);
 }
 
@@ -465,6 +469,107 @@ int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n
     SMH_HIP(hipGetLastError());
     SMH_HIP(hipMemcpyAsync(col, col_s, nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     SMH_HIP(hipMemcpyAsync(val, val_s, nnz * vs, hipMemcpyDeviceToDevice, s));
+    SMH_HIP(hipStreamSynchronize(s));
+    return SMH_OK;
+}
+
+// ---- row of every entry, transpose, column tables ------------------------------------------------------------
+// rows[k] = row of entry k (what assemble_column_info pushes, sparsemat_crs.rs:186-189).  A block takes 256
+// consecutive rows and walks their entries densely (coalesced stores), bisecting its 257 offsets in LDS.
+__global__ void __launch_bounds__(kBlock)
+k_expand_rows(const uint32_t *__restrict__ off, uint64_t n_rows, uint32_t *__restrict__ rows) {
+    __shared__ uint32_t s_off[kBlock + 1];
+    const uint64_t n_groups = (n_rows + kBlock - 1) / kBlock;
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t r0 = g * kBlock, r1 = r0 + kBlock < n_rows ? r0 + kBlock : n_rows;
+        const uint32_t nr = (uint32_t)(r1 - r0);
+        __syncthreads();
+        if (threadIdx.x <= nr) s_off[threadIdx.x] = off[r0 + threadIdx.x];
+        if (threadIdx.x == 0 && nr == (uint32_t)kBlock) s_off[kBlock] = off[r1];
+        __syncthreads();
+        const uint32_t base = s_off[0], total = s_off[nr] - base;
+        for (uint32_t p = threadIdx.x; p < total; p += kBlock) {
+            uint32_t lo = 0, hi = nr;  // last row with s_off[row] - base <= p
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_off[mid] - base <= p) lo = mid; else hi = mid;
+            }
+            rows[(uint64_t)base + p] = (uint32_t)(r0 + lo);
+        }
+    }
+}
+
+int expand_rows(const uint32_t *off, size_t n_rows, uint32_t *rows_out, hipStream_t s) {
+    if (n_rows == 0) return SMH_OK;
+    hipLaunchKernelGGL(k_expand_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, off, (uint64_t)n_rows, rows_out);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bump_offsets(uint32_t *__restrict__ off, uint64_t first, uint64_t last) {  // off[first..last] += 1
+    for (uint64_t r = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= last; r += (uint64_t)gridDim.x * blockDim.x) off[r] += 1u;
+}
+
+// One more entry at the END of row `row` (new arrays, the old ones are freed): the place the first-push quirk of a
+// SparseMatCRS leaves the first operation's entry in when the second operation names the same (row, column)
+// (sparsemat_crs.rs:75-81; capi.hip::assemble_common).
+int append_to_row(int dtype, uint32_t *off, uint32_t **col, void **val, size_t n_rows, size_t *nnz, size_t row, uint32_t column,
+                  const void *value_host, hipStream_t s) {
+    const size_t vs = dtype_size(dtype), n = *nnz;
+    uint32_t p = 0;
+    SMH_HIP(hipMemcpyAsync(&p, off + row + 1, sizeof p, hipMemcpyDeviceToHost, s));
+    SMH_HIP(hipStreamSynchronize(s));
+    uint32_t *ncol = nullptr;
+    char *nval = nullptr;
+    SMH_HIP(hipMalloc((void **)&ncol, (n + 1 + 4) * sizeof(uint32_t)));
+    if (hipMalloc((void **)&nval, (n + 1 + 4) * vs) != hipSuccess) { (void)hipFree(ncol); return fail(SMH_ERR_OOM, "hipMalloc failed"); }
+    auto go = [&]() -> int {
+        SMH_HIP(hipMemsetAsync(ncol + n + 1, 0, 4 * sizeof(uint32_t), s));
+        SMH_HIP(hipMemsetAsync(nval + (n + 1) * vs, 0, 4 * vs, s));
+        if (p) {
+            SMH_HIP(hipMemcpyAsync(ncol, *col, (size_t)p * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            SMH_HIP(hipMemcpyAsync(nval, *val, (size_t)p * vs, hipMemcpyDeviceToDevice, s));
+        }
+        SMH_HIP(hipMemcpyAsync(ncol + p, &column, sizeof column, hipMemcpyHostToDevice, s));
+        SMH_HIP(hipMemcpyAsync(nval + (size_t)p * vs, value_host, vs, hipMemcpyHostToDevice, s));
+        if (n > p) {
+            SMH_HIP(hipMemcpyAsync(ncol + p + 1, *col + p, (n - p) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            SMH_HIP(hipMemcpyAsync(nval + ((size_t)p + 1) * vs, (const char *)*val + (size_t)p * vs, (n - p) * vs, hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL(k_bump_offsets, dim3(grid_for(n_rows - row)), dim3(kBlock), 0, s, off, (uint64_t)row + 1, (uint64_t)n_rows);
+        SMH_HIP(hipGetLastError());
+        SMH_HIP(hipStreamSynchronize(s));
+        return SMH_OK;
+    };
+    const int rc = go();
+    if (rc != SMH_OK) { (void)hipFree(ncol); (void)hipFree(nval); return rc; }
+    (void)hipFree(*col); (void)hipFree(*val);
+    *col = ncol; *val = nval; *nnz = n + 1;
+    return SMH_OK;
+}
+
+// ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as arrays: rows[k] = row of entry k; the per-column
+// lists the reference keeps as an IndexList (entry indices in storage order: indexlist.rs:62-83 appends at the
+// list's tail) = a STABLE sort of the entry indices by column, col_ptr[j]..col_ptr[j+1] delimiting column j.
+// All three outputs are device arrays: rows[nnz], col_ptr[n_cols + 1], entries[nnz].  Columns must be < n_cols.
+int column_info(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t n_cols, size_t nnz, uint32_t max_col, uint32_t *rows,
+                uint32_t *col_ptr, uint32_t *entries, hipStream_t s) {
+    if (nnz == 0) {
+        SMH_HIP(hipMemsetAsync(col_ptr, 0, (n_cols + 1) * sizeof(uint32_t), s));
+        SMH_HIP(hipStreamSynchronize(s));
+        return SMH_OK;
+    }
+    SMH_TRY(expand_rows(off, n_rows, rows, s));
+    Scratch tmp_bufs;
+    uint32_t *col_s = nullptr, *idx = nullptr;
+    SMH_TRY(tmp_bufs.alloc(&col_s, nnz));
+    SMH_TRY(tmp_bufs.alloc(&idx, nnz));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(nnz)), dim3(kBlock), 0, s, idx, (uint64_t)nnz);
+    SMH_HIP(hipGetLastError());
+    SMH_ROCPRIM(rocprim::radix_sort_pairs(tmp, bytes, col, col_s, idx, entries, nnz, 0u, bits_for(max_col), s));
+    hipLaunchKernelGGL(k_asm_segments, dim3(grid_for(nnz)), dim3(kBlock), 0, s, col_s, (uint64_t)nnz, (uint64_t)n_cols, col_ptr);
+    SMH_HIP(hipGetLastError());
     SMH_HIP(hipStreamSynchronize(s));
     return SMH_OK;
 }

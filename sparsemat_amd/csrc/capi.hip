@@ -705,8 +705,15 @@ int smh_crs_create_dev(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz
 }
 
 // add_to / set stream -> CRS (assemble.hip).  `on_device`: the arrays are device pointers.
+// into_crs: the stream is replayed on a SparseMatCRS instead of a SparseMatIndexList + to_crs(): rows come out in reverse order
+// of first appearance (push prepends, sparsemat_crs.rs:85-87) and the container's first-push quirk applies (:75-81: the first push
+// leaves n_rows == 0, so the second operation never finds an entry):
+//   * second row <  first row: Vec::resize truncates offset_rows and the first entry is orphaned -- it stays in columns / values
+//     (and in n_cols) but no row reaches it; the result is the replay of operations 1.. alone.  Orphans are not materialised here;
+//   * second (row, column) == first: the first operation keeps an entry of its own, the oldest of its row (= last in storage);
+//   * a single operation: no rows at all (n_rows stays 0), one orphan.
 static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols, const void *values,
-                           const uint8_t *ops, bool on_device, smh_crs **out) {
+                           const uint8_t *ops, bool on_device, bool into_crs, smh_crs **out) {
     if (!out) return fail(SMH_ERR_INVALID, "NULL out pointer");
     if (dtype != SMH_F32 && dtype != SMH_F64) return fail(SMH_ERR_INVALID, "unknown dtype %d", (int)dtype);
     if (n_ops && (!rows || !cols || !values)) return fail(SMH_ERR_INVALID, "NULL operation array");
@@ -718,13 +725,32 @@ static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, 
     m->device = current_device();
     const size_t vs = dtype_size(dtype);
     void *d_in[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto no_rows = [&](size_t n_cols) -> int {  // SparseMatCRS::new() (sparsemat_crs.rs:47-49): no rows at all
+        SMH_HIP(hipMalloc((void **)&m->d_off, sizeof(uint32_t)));
+        SMH_HIP(hipMemset(m->d_off, 0, sizeof(uint32_t)));
+        SMH_HIP(hipMalloc((void **)&m->d_col, 4 * sizeof(uint32_t)));
+        SMH_HIP(hipMalloc(&m->d_val, 4 * vs));
+        m->n_cols = n_cols;
+        return finish_create(m, 0);
+    };
     auto go = [&]() -> int {
-        if (n_ops == 0) {  // SparseMatCRS::new() (sparsemat_crs.rs:47-49): no rows at all
-            SMH_HIP(hipMalloc((void **)&m->d_off, sizeof(uint32_t)));
-            SMH_HIP(hipMemset(m->d_off, 0, sizeof(uint32_t)));
-            SMH_HIP(hipMalloc((void **)&m->d_col, 4 * sizeof(uint32_t)));
-            SMH_HIP(hipMalloc(&m->d_val, 4 * vs));
-            return finish_create(m, 0);
+        if (n_ops == 0) return no_rows(0);
+        // the first two operations decide the SparseMatCRS quirk
+        size_t skip = 0, min_cols = 0;
+        bool twin = false;
+        uint32_t r01[2] = {0, 0}, c01[2] = {0, 0};
+        double v0 = 0.0;  // (holds an f32 or an f64 bit pattern)
+        uint8_t op0 = 0;
+        if (into_crs) {
+            const size_t k = n_ops < 2 ? n_ops : 2;
+            const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+            SMH_HIP(hipMemcpy(r01, rows, k * sizeof(uint32_t), kind));
+            SMH_HIP(hipMemcpy(c01, cols, k * sizeof(uint32_t), kind));
+            SMH_HIP(hipMemcpy(&v0, values, vs, kind));
+            if (ops) SMH_HIP(hipMemcpy(&op0, ops, 1, kind));
+            if (n_ops == 1) return no_rows((size_t)c01[0] + 1);
+            if (r01[1] < r01[0]) { skip = 1; min_cols = (size_t)c01[0] + 1; }
+            else if (r01[1] == r01[0] && c01[1] == c01[0]) { skip = 1; twin = true; }
         }
         const uint32_t *d_rows = rows, *d_cols = cols;
         const void *d_vals = values;
@@ -742,8 +768,17 @@ static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, 
             }
             d_rows = (const uint32_t *)d_in[0]; d_cols = (const uint32_t *)d_in[1]; d_vals = d_in[2]; d_ops = (const uint8_t *)d_in[3];
         }
-        SMH_TRY(assemble_triplets(dtype, n_ops, d_rows, d_cols, d_vals, d_ops, &m->n_rows, &m->n_cols, &m->nnz, &m->d_off,
-                                  &m->d_col, &m->d_val, nullptr));
+        SMH_TRY(assemble_triplets(dtype, n_ops - skip, d_rows + skip, d_cols + skip, (const char *)d_vals + skip * vs,
+                                  d_ops ? d_ops + skip : nullptr, into_crs, &m->n_rows, &m->n_cols, &m->nnz, &m->d_off, &m->d_col,
+                                  &m->d_val, nullptr));
+        if (min_cols > m->n_cols) m->n_cols = min_cols;
+        if (twin) {  // the first operation's own entry: push(i, j, zero) then `=` or `+=` (sparsematrix.rs:226-233)
+            if (!op0) {
+                if (dtype == SMH_F64) { double v; memcpy(&v, &v0, 8); v = 0.0 + v; memcpy(&v0, &v, 8); }
+                else { float v; memcpy(&v, &v0, 4); v = 0.0f + v; memcpy(&v0, &v, 4); }
+            }
+            SMH_TRY(append_to_row(dtype, m->d_off, &m->d_col, &m->d_val, m->n_rows, &m->nnz, r01[0], c01[0], &v0, nullptr));
+        }
         return finish_create(m, 0);
     };
     const int rc = go();
@@ -755,12 +790,74 @@ static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, 
 
 int smh_crs_assemble(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols, const void *values,
                      const uint8_t *ops, smh_crs **out) {
-    return assemble_common(dtype, n_ops, rows, cols, values, ops, false, out);
+    return assemble_common(dtype, n_ops, rows, cols, values, ops, false, false, out);
 }
 
 int smh_crs_assemble_dev(smh_dtype dtype, size_t n_ops, const uint32_t *rows_dev, const uint32_t *cols_dev,
                          const void *values_dev, const uint8_t *ops_dev, smh_crs **out) {
-    return assemble_common(dtype, n_ops, rows_dev, cols_dev, values_dev, ops_dev, true, out);
+    return assemble_common(dtype, n_ops, rows_dev, cols_dev, values_dev, ops_dev, true, false, out);
+}
+
+int smh_crs_replay(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols, const void *values,
+                   const uint8_t *ops, smh_crs **out) {
+    return assemble_common(dtype, n_ops, rows, cols, values, ops, false, true, out);
+}
+
+int smh_crs_replay_dev(smh_dtype dtype, size_t n_ops, const uint32_t *rows_dev, const uint32_t *cols_dev,
+                       const void *values_dev, const uint8_t *ops_dev, smh_crs **out) {
+    return assemble_common(dtype, n_ops, rows_dev, cols_dev, values_dev, ops_dev, true, true, out);
+}
+
+// SparseMatrix::transpose (sparsematrix.rs:174-184) for Self = SparseMatCRS: `ret.set(j, i, val)` for every entry in row-major
+// storage order into a fresh SparseMatCRS -- the replay above with rows = the columns array (borrowed), columns = the row of
+// every entry, all operations `set`.
+int smh_crs_transpose(const smh_crs *a, smh_crs **out) {
+    if (!a || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    SMH_HIP(hipStreamSynchronize(a->stream));
+    if (a->nnz == 0) return assemble_common((smh_dtype)a->dtype, 0, nullptr, nullptr, nullptr, nullptr, true, true, out);
+    uint32_t *d_rowof = nullptr;
+    uint8_t *d_set = nullptr;
+    SMH_HIP(hipMalloc((void **)&d_rowof, a->nnz * sizeof(uint32_t)));
+    if (hipMalloc((void **)&d_set, a->nnz) != hipSuccess) { (void)hipFree(d_rowof); return fail(SMH_ERR_OOM, "hipMalloc failed"); }
+    auto go = [&]() -> int {
+        SMH_HIP(hipMemset(d_set, 1, a->nnz));
+        SMH_TRY(expand_rows(a->d_off, a->n_rows, d_rowof, nullptr));
+        SMH_HIP(hipStreamSynchronize(nullptr));
+        return assemble_common((smh_dtype)a->dtype, a->nnz, a->d_col, d_rowof, a->d_val, d_set, true, true, out);
+    };
+    const int rc = go();
+    (void)hipFree(d_rowof); (void)hipFree(d_set);
+    return rc;
+}
+
+static int column_info_common(const smh_crs *m, uint32_t *rows, uint32_t *col_ptr, uint32_t *entries, bool on_device) {
+    if (!m || !rows || !col_ptr || !entries) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (m->nnz && (size_t)m->max_col >= m->n_cols)
+        return fail(SMH_ERR_INDEX_RANGE, "column %u out of range for %zu columns", m->max_col, m->n_cols);
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    if (on_device) return column_info(m->d_off, m->d_col, m->n_rows, m->n_cols, m->nnz, m->max_col, rows, col_ptr, entries, m->stream);
+    uint32_t *d[3] = {nullptr, nullptr, nullptr};
+    auto go = [&]() -> int {
+        SMH_HIP(hipMalloc((void **)&d[0], (m->nnz ? m->nnz : 1) * sizeof(uint32_t)));
+        SMH_HIP(hipMalloc((void **)&d[1], (m->n_cols + 1) * sizeof(uint32_t)));
+        SMH_HIP(hipMalloc((void **)&d[2], (m->nnz ? m->nnz : 1) * sizeof(uint32_t)));
+        SMH_TRY(column_info(m->d_off, m->d_col, m->n_rows, m->n_cols, m->nnz, m->max_col, d[0], d[1], d[2], m->stream));
+        if (m->nnz) SMH_HIP(hipMemcpy(rows, d[0], m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        SMH_HIP(hipMemcpy(col_ptr, d[1], (m->n_cols + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (m->nnz) SMH_HIP(hipMemcpy(entries, d[2], m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return SMH_OK;
+    };
+    const int rc = go();
+    for (uint32_t *p : d) (void)hipFree(p);
+    return rc;
+}
+
+int smh_crs_column_info(const smh_crs *m, uint32_t *rows, uint32_t *col_ptr, uint32_t *entries) {
+    return column_info_common(m, rows, col_ptr, entries, false);
+}
+
+int smh_crs_column_info_dev(const smh_crs *m, uint32_t *rows_dev, uint32_t *col_ptr_dev, uint32_t *entries_dev) {
+    return column_info_common(m, rows_dev, col_ptr_dev, entries_dev, true);
 }
 
 int smh_crs_sort_rows(smh_crs *m) {

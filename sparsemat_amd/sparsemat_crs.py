@@ -54,11 +54,13 @@ class SparseMatCRS:
         return cls(h, dtype, keep)
 
     @classmethod
-    def from_triplets(cls, rows, cols, values, ops=None):
+    def from_triplets(cls, rows, cols, values, ops=None, into_crs=False):
         """The CRS the reference ends up with after the call stream ``mat.add_to(rows[k], cols[k], values[k])``
         (``ops[k] == 1``: ``mat.set(...)``) on a SparseMatIndexList and ``to_crs()``
         (sparsemat_indexlist.rs:61-63,158-164; sparsemat_crs.rs:24-50) -- built on the device, bit-exact:
-        entries of a row in order of first appearance, duplicates folded in stream order."""
+        entries of a row in order of first appearance, duplicates folded in stream order.
+        ``into_crs=True``: the stream is applied to a SparseMatCRS itself (sparsemat_crs.rs:54-92,143-149): rows in
+        reverse order of first appearance, first-push quirk included (see ``smh_crs_replay`` in the header)."""
         values = np.ascontiguousarray(values)
         if values.dtype not in (np.float32, np.float64):
             raise TypeError("the HIP path handles f32/f64 values only (got %s)" % values.dtype)
@@ -71,18 +73,46 @@ class SparseMatCRS:
         if ops_a is not None and len(ops_a) != n:
             raise _lib.SparseMatPanic(_lib.SMH_ERR_INVALID, "ops and values differ in length")
         h = C.c_void_p()
-        check(lib().smh_crs_assemble(_lib.dtype_code(values.dtype), n, rows.ctypes.data if n else None,
-                                     cols.ctypes.data if n else None, values.ctypes.data if n else None,
-                                     ops_a.ctypes.data if (ops_a is not None and n) else None, C.byref(h)))
+        fn = lib().smh_crs_replay if into_crs else lib().smh_crs_assemble
+        check(fn(_lib.dtype_code(values.dtype), n, rows.ctypes.data if n else None, cols.ctypes.data if n else None,
+                 values.ctypes.data if n else None, ops_a.ctypes.data if (ops_a is not None and n) else None, C.byref(h)))
         return cls(h, values.dtype)
 
     @classmethod
-    def from_device_triplets(cls, n_ops, rows_ptr, cols_ptr, vals_ptr, dtype, ops_ptr=None):
+    def from_device_triplets(cls, n_ops, rows_ptr, cols_ptr, vals_ptr, dtype, ops_ptr=None, into_crs=False):
         """``from_triplets`` over operation arrays that already live in HBM (raw device pointers)."""
         h = C.c_void_p()
-        check(lib().smh_crs_assemble_dev(_lib.dtype_code(dtype), n_ops, C.c_void_p(rows_ptr), C.c_void_p(cols_ptr),
-                                         C.c_void_p(vals_ptr), C.c_void_p(ops_ptr or 0), C.byref(h)))
+        fn = lib().smh_crs_replay_dev if into_crs else lib().smh_crs_assemble_dev
+        check(fn(_lib.dtype_code(dtype), n_ops, C.c_void_p(rows_ptr), C.c_void_p(cols_ptr), C.c_void_p(vals_ptr),
+                 C.c_void_p(ops_ptr or 0), C.byref(h)))
         return cls(h, dtype)
+
+    def transpose(self):
+        """SparseMatrix::transpose (sparsematrix.rs:174-184): ``ret.set(j, i, val)`` for every entry in row-major
+        storage order into a fresh SparseMatCRS -- on the device, bit-exact including the storage order the
+        reference's CRS container produces (rows reversed, first-push quirk)."""
+        h = C.c_void_p()
+        check(lib().smh_crs_transpose(self._h, C.byref(h)))
+        return type(self)(h, self.dtype)
+
+    def column_info(self):
+        """ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as arrays ``(rows, col_ptr, entries)``:
+        ``rows[k]`` = row of entry k; column j's entries in storage order are ``entries[col_ptr[j]:col_ptr[j+1]]``."""
+        nnz, n_cols = self.n_non_zero_entries(), self.n_cols()
+        rows = np.zeros(max(nnz, 1), np.uint32)
+        col_ptr = np.zeros(n_cols + 1, np.uint32)
+        entries = np.zeros(max(nnz, 1), np.uint32)
+        check(lib().smh_crs_column_info(self._h, rows.ctypes.data, col_ptr.ctypes.data, entries.ctypes.data))
+        return rows[:nnz], col_ptr, entries[:nnz]
+
+    def iter_col(self, col, info=None, values=None):
+        """ColumnIter::iter_col (sparsemat_crs.rs:193-204): the (row, value) pairs of a column in storage order.
+        ``info`` = a ``column_info()`` result and ``values`` the downloaded values, to avoid repeating both."""
+        rows, col_ptr, entries = info if info is not None else self.column_info()
+        if values is None:
+            values = self.raw_parts()[2]
+        e = entries[col_ptr[col]:col_ptr[col + 1]] if col < len(col_ptr) - 1 else entries[:0]
+        return list(zip(rows[e].tolist(), values[e].tolist()))
 
     def sort_rows(self):
         """Sortable::sort_row (sparsemat_crs.rs:163-172) on every row: ascending columns, stable."""

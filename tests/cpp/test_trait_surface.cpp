@@ -64,6 +64,23 @@ int main() {
         CHECK((col == std::vector<uint32_t>{0, 1, 2, 1, 2, 2}));
         CHECK((val == std::vector<float>{7.12f, 4.2f, 0.12f, 2.24f, 4.12f, 2.12f}));
     }
+    // SparseMatrix::transpose (sparsematrix.rs:174-184) + ColumnIter tables (sparsemat_crs.rs:180-204)
+    {
+        auto a = SparseMatCRS<float>::from_raw_parts(3, 4, {0, 2, 2, 5}, {1, 3, 0, 3, 1}, {1.0f, 2.0f, 3.0f, 4.0f, 5.0f});
+        auto t = a.transpose();
+        std::vector<uint32_t> off, col;
+        std::vector<float> val;
+        t.raw_parts(off, col, val);
+        CHECK(t.n_rows() == 4 && t.n_cols() == 3);
+        CHECK((off == std::vector<uint32_t>{0, 1, 3, 3, 5}));
+        CHECK((col == std::vector<uint32_t>{2, 2, 0, 2, 0}));     // a SparseMatCRS prepends: latest source row first
+        CHECK((val == std::vector<float>{3.0f, 5.0f, 1.0f, 4.0f, 2.0f}));
+        std::vector<uint32_t> rows, col_ptr, entries;
+        a.column_info(rows, col_ptr, entries);
+        CHECK((rows == std::vector<uint32_t>{0, 0, 2, 2, 2}));
+        CHECK((col_ptr == std::vector<uint32_t>{0, 1, 3, 3, 5}));
+        CHECK((entries == std::vector<uint32_t>{2, 0, 4, 1, 3}));
+    }
     // check_cg (src/lib.rs:36-52)
     {
         auto a = SparseMatCRS<double>::from_raw_parts(2, 2, {0, 2, 4}, {0, 1, 0, 1}, {4.0, 1.0, 1.0, 3.0});

@@ -101,6 +101,48 @@ def test_c_assembly_oracle_reproduces_reference_crs(case):
     assert val.tobytes() == _values(case).tobytes()
 
 
+def test_c_crs_replay_oracle_reproduces_reference_crs_and_container_restatement():
+    """orc_crs_replay (the stream applied to a SparseMatCRS itself: push prepends, first-push quirk) against the
+    arrays src/lib.rs:114-154 pins, and against the step-by-step Python container (CrsPushMatrix) on random streams,
+    orphaned first entries included; transpose / column_info restatements against a dense walk."""
+    case = [c for c in CASES if c["name"] == "check_sparsemat_crs"][0]
+    rows, cols, vals, ops = _ops_arrays(case, np.float32)
+    n_rows, n_cols, off, col, val, stored = oracle.crs_replay(rows, cols, vals, ops)
+    crs = case["crs"]
+    assert (n_rows, n_cols, stored) == (crs["n_rows"], crs["n_cols"], len(crs["columns"]))
+    assert list(off) == crs["offset_rows"] and list(col) == crs["columns"]
+    assert val.tobytes() == _values(case).tobytes()
+    rng = np.random.default_rng(6)
+    orphans = 0
+    for t in range(300):
+        dt = np.float32 if t % 2 else np.float64
+        n, n_r, n_c = int(rng.integers(0, 60)), int(rng.integers(1, 8)), int(rng.integers(1, 6))
+        rows, cols = rng.integers(0, n_r, n), rng.integers(0, n_c, n)
+        vals = rng.uniform(-1, 1, n).astype(dt)
+        vals[rng.random(n) < 0.1] = dt(-0.0)
+        ops = rng.integers(0, 2, n) if t % 3 else None
+        m = assembly.CrsPushMatrix(dt)
+        for k in range(n):
+            (m.set if ops is not None and ops[k] else m.add_to)(int(rows[k]), int(cols[k]), vals[k])
+        n_rows, n_cols, off, col, val, stored = oracle.crs_replay(rows, cols, vals, ops)
+        e_rows, e_cols, e_off, e_col, e_val = m.to_crs_arrays()
+        reach = int(e_off[-1]) if e_rows else 0
+        assert (n_rows, n_cols, stored) == (e_rows, e_cols, len(e_col))
+        assert np.array_equal(off[:n_rows + 1] if n_rows else off[:0], e_off[:n_rows + 1] if n_rows else e_off[:0])
+        assert np.array_equal(col, e_col[:reach]) and val.tobytes() == e_val[:reach].tobytes()
+        orphans += stored - reach
+    assert orphans > 0  # the quirk was exercised
+    # transpose = the set(j, i, val) replay; column_info = per-column entry lists in storage order
+    off = np.array([0, 2, 2, 5], np.uint32)
+    col = np.array([1, 3, 0, 3, 1], np.uint32)
+    val = np.array([1.0, 2.0, 3.0, 4.0, 5.0], np.float32)
+    t_rows, t_cols, t_off, t_col, t_val, t_stored = oracle.transpose(off, col, val)
+    assert (t_rows, t_cols, t_stored) == (4, 3, 5)
+    assert list(t_off) == [0, 1, 3, 3, 5] and list(t_col) == [2, 2, 0, 2, 0] and list(t_val) == [3.0, 5.0, 1.0, 4.0, 2.0]
+    rows, col_ptr, entries = oracle.column_info(off, col, 4)
+    assert list(rows) == [0, 0, 2, 2, 2] and list(col_ptr) == [0, 1, 3, 3, 5] and list(entries) == [2, 0, 4, 1, 3]
+
+
 def test_c_assembly_oracle_matches_container_restatement():
     """Random add_to/set streams: the C oracle equals the step-by-step Python container (IndexListMatrix),
     incl. gaps (empty rows), -0.0 values and the empty stream; sort_rows equals a stable numpy sort."""
