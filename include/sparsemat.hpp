@@ -156,6 +156,23 @@ class SparseMatCRS {
         detail::check(smh_crs_transpose(h_, &t.h_));
         return t;
     }
+    // SparseMatrix::prod (sparsematrix.rs:186-210): self * rhs as the reference's loops build it (same order of
+    // additions, zero sums dropped, rows in descending column order); Err("Dimension mismatch") becomes a Panic
+    SparseMatCRS prod(const SparseMatCRS &rhs) const {
+        SparseMatCRS c;
+        detail::check(smh_crs_prod(h_, rhs.h_, &c.h_));
+        return c;
+    }
+    bool is_symmetric() const {  // sparsematrix.rs:212-222
+        int out = 0;
+        detail::check(smh_crs_is_symmetric(h_, &out));
+        return out != 0;
+    }
+    bool is_sorted() const {  // sparsematrix.rs:263-271
+        int out = 0;
+        detail::check(smh_crs_is_sorted(h_, &out));
+        return out != 0;
+    }
     // ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as arrays: rows[k] = row of entry k; iter_col(j)
     // (:193-204) walks entries[col_ptr[j] .. col_ptr[j+1]) and yields (rows[e], values[e])
     void column_info(std::vector<uint32_t> &rows, std::vector<uint32_t> &col_ptr, std::vector<uint32_t> &entries) const {

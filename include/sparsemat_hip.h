@@ -133,6 +133,18 @@ int smh_crs_transpose(const smh_crs *a, smh_crs **out);
 int smh_crs_column_info(const smh_crs *m, uint32_t *rows, uint32_t *col_ptr, uint32_t *entries);
 int smh_crs_column_info_dev(const smh_crs *m, uint32_t *rows_dev, uint32_t *col_ptr_dev,
                             uint32_t *entries_dev);
+/* SparseMatrix::prod (sparsematrix.rs:186-210), self = a, rhs = b, both SparseMatCRS: the matrix the
+ * reference's loops leave in a fresh SparseMatCRS -- entry (i, j) = the sum over rhs' column j in
+ * storage order of val(i, row) * val_rhs with the same order of additions (bit-exact), sums that
+ * compare == 0 dropped (:203), rows in descending column order (ascending `set` calls into a CRS),
+ * n_rows / n_cols = largest kept row / column + 1; one kept sum leaves a matrix without rows (the
+ * first-push quirk).  The reference's Err("Dimension mismatch") (:188-190: a.n_rows != b.n_cols or
+ * a.n_cols != b.n_rows) is SMH_ERR_DIM_MISMATCH.  No column tables are needed on rhs. */
+int smh_crs_prod(const smh_crs *a, const smh_crs *b, smh_crs **out);
+/* is_symmetric (sparsematrix.rs:212-222: get(j, i) != val for some stored entry -> false; get takes
+ * the first match in storage order) and is_sorted (:251-271): *out = 1 / 0. */
+int smh_crs_is_symmetric(const smh_crs *m, int *out);
+int smh_crs_is_sorted(const smh_crs *m, int *out);
 /* Sortable::sort_row (sparsemat_crs.rs:163-172) for every row: ascending columns, stable
  * (duplicates of a column keep their storage order).  Sorts the handle's arrays in place. */
 int smh_crs_sort_rows(smh_crs *m);

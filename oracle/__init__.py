@@ -101,6 +101,8 @@ def _declare(L):
                                                        C.POINTER(_sz), C.POINTER(_sz), _u32p, _u32p, fp]
         getattr(L, "orc_crs_replay_" + suf).argtypes = [_sz, _u32p, _u32p, fp, C.POINTER(C.c_uint8), C.POINTER(_sz),
                                                          C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), _u32p, _u32p, fp]
+        getattr(L, "orc_crs_prod_ops_" + suf).argtypes = [_sz, _sz, _u32p, _u32p, fp, _sz, _sz, _u32p, _u32p, fp, _sz,
+                                                           C.POINTER(_sz), _u32p, _u32p, fp]
         getattr(L, "orc_crs_sort_rows_" + suf).argtypes = [_sz, _u32p, _u32p, fp]
         getattr(L, "orc_crs_sort_rows_" + suf).restype = None
     L.orc_par_rows_per_block.argtypes = [_sz, _sz]
@@ -408,6 +410,26 @@ def transpose(offset_rows, columns, values):
     src_rows = np.repeat(np.arange(n_rows, dtype=np.uint32), np.diff(off.astype(np.int64)))
     nnz = int(off[-1]) if n_rows else 0
     return crs_replay(_c(columns, np.uint32)[:nnz], src_rows, np.ascontiguousarray(values)[:nnz], np.ones(nnz, np.uint8))
+
+
+def prod(a, b, cap=None):
+    """SparseMatrix::prod (sparsematrix.rs:186-210) for SparseMatCRS operands a, b = (n_rows, n_cols, offset_rows,
+    columns, values): the reference's loops produce the call stream ret.set(i, j, sum); replayed on a SparseMatCRS.
+    Same return as crs_replay.  Raises OraclePanic(ORC_ERR_SIZE_MISMATCH) for the reference's Err("Dimension mismatch")."""
+    a_rows, a_cols, a_off, a_col, a_val = a
+    b_rows, b_cols, b_off, b_col, b_val = b
+    a_val = np.ascontiguousarray(a_val)
+    suf, fp = _suf(a_val.dtype)
+    b_val = _c(b_val, a_val.dtype)
+    a_off, a_col, b_off, b_col = (_c(v, np.uint32) for v in (a_off, a_col, b_off, b_col))
+    cap = int(cap if cap is not None else min(a_rows * max(b_cols, 1), 50_000_000))
+    o_rows, o_cols, o_vals = np.zeros(max(cap, 1), np.uint32), np.zeros(max(cap, 1), np.uint32), np.zeros(max(cap, 1), a_val.dtype)
+    n = _sz()
+    _check(getattr(lib(), "orc_crs_prod_ops_" + suf)(
+        a_rows, a_cols, _p(a_off, _u32p), _p(a_col, _u32p), _p(a_val, fp), b_rows, b_cols, _p(b_off, _u32p), _p(b_col, _u32p),
+        _p(b_val, fp), cap, C.byref(n), _p(o_rows, _u32p), _p(o_cols, _u32p), _p(o_vals, fp)))
+    k = n.value
+    return crs_replay(o_rows[:k], o_cols[:k], o_vals[:k], np.ones(k, np.uint8))
 
 
 def column_info(offset_rows, columns, n_cols):

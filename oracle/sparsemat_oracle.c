@@ -525,3 +525,64 @@ DEF_SORT_ROWS(f64, double)
 
 DEF_CRS_REPLAY(f32, float)
 DEF_CRS_REPLAY(f64, double)
+
+/* SparseMatrix::prod (sparsematrix.rs:186-210) for Self = SparseMatCRS, rhs = SparseMatCRS with its column tables
+ * (assemble_column_info sparsemat_crs.rs:180-191: per column the entries in storage order), restated literally up
+ * to the container: for every row i (its entries stably sorted by column, :194-195) and every column j of rhs in
+ * ascending order, sum = 0; for every (row, val_rhs) of rhs' column j in list order, for every (col, val) of the
+ * sorted row while col <= row: if col == row { sum += val * val_rhs } (multiply and add rounded separately); the
+ * sums that compare != 0 become the call stream ret.set(i, j, sum) -- written to ops_* here (capacity cap), to be
+ * replayed on a SparseMatCRS by orc_crs_replay.  Dimension rule of :188-190 -> ORC_ERR_SIZE_MISMATCH.
+ * O(n_rows * n_cols): small cases only. */
+#define DEF_PROD(SUF, T)                                                                            \
+    int orc_crs_prod_ops_##SUF(size_t a_rows, size_t a_cols, const uint32_t *a_off,                 \
+                               const uint32_t *a_col, const T *a_val, size_t b_rows, size_t b_cols, \
+                               const uint32_t *b_off, const uint32_t *b_col, const T *b_val,        \
+                               size_t cap, size_t *n_out, uint32_t *ops_rows, uint32_t *ops_cols,   \
+                               T *ops_vals) {                                                       \
+        if (a_rows != b_cols || a_cols != b_rows) return ORC_ERR_SIZE_MISMATCH;                     \
+        const size_t b_nnz = b_rows ? b_off[b_rows] : 0;                                            \
+        /* column tables of rhs: counting sort by column keeps the storage order inside a column */ \
+        uint32_t *ptr = (uint32_t *)calloc(b_cols + 2, sizeof(uint32_t));                           \
+        uint32_t *ent = (uint32_t *)malloc((b_nnz + 1) * sizeof(uint32_t));                         \
+        uint32_t *row_of = (uint32_t *)malloc((b_nnz + 1) * sizeof(uint32_t));                      \
+        for (size_t r = 0; r < b_rows; ++r)                                                         \
+            for (size_t q = b_off[r]; q < b_off[r + 1]; ++q) { row_of[q] = (uint32_t)r; ptr[b_col[q] + 2]++; } \
+        for (size_t j = 0; j < b_cols; ++j) ptr[j + 2] += ptr[j + 1];                               \
+        for (size_t q = 0; q < b_nnz; ++q) ent[ptr[b_col[q] + 1]++] = (uint32_t)q;                  \
+        size_t n = 0, max_len = 0;                                                                  \
+        for (size_t i = 0; i < a_rows; ++i)                                                         \
+            if ((size_t)(a_off[i + 1] - a_off[i]) > max_len) max_len = a_off[i + 1] - a_off[i];     \
+        uint32_t *sc = (uint32_t *)malloc((max_len + 1) * sizeof(uint32_t));                        \
+        T *sv = (T *)malloc((max_len + 1) * sizeof(T));                                             \
+        int rc = ORC_OK;                                                                            \
+        for (size_t i = 0; i < a_rows && rc == ORC_OK; ++i) {                                       \
+            const size_t len = a_off[i + 1] - a_off[i];                                             \
+            for (size_t q = 0; q < len; ++q) { /* stable insertion sort by column */                \
+                const uint32_t c = a_col[a_off[i] + q];                                             \
+                const T v = a_val[a_off[i] + q];                                                    \
+                size_t p = q;                                                                       \
+                while (p > 0 && sc[p - 1] > c) { sc[p] = sc[p - 1]; sv[p] = sv[p - 1]; --p; }       \
+                sc[p] = c; sv[p] = v;                                                               \
+            }                                                                                       \
+            for (size_t j = 0; j < b_cols; ++j) {                                                   \
+                T sum = (T)0;                                                                       \
+                for (size_t t = ptr[j]; t < ptr[j + 1]; ++t) {                                      \
+                    const uint32_t row = row_of[ent[t]];                                            \
+                    const T val_rhs = b_val[ent[t]];                                                \
+                    for (size_t q = 0; q < len && sc[q] <= row; ++q)                                \
+                        if (sc[q] == row) { const T prod = sv[q] * val_rhs; sum = sum + prod; }     \
+                }                                                                                   \
+                if (sum != (T)0) {                                                                  \
+                    if (n >= cap) { rc = ORC_ERR_CAPACITY; break; }                                 \
+                    ops_rows[n] = (uint32_t)i; ops_cols[n] = (uint32_t)j; ops_vals[n] = sum; ++n;   \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+        *n_out = n;                                                                                 \
+        free(ptr); free(ent); free(row_of); free(sc); free(sv);                                     \
+        return rc;                                                                                  \
+    }
+
+DEF_PROD(f32, float)
+DEF_PROD(f64, double)

@@ -145,6 +145,17 @@ int orc_crs_replay_f32(size_t n, const uint32_t *rows, const uint32_t *cols, con
 int orc_crs_replay_f64(size_t n, const uint32_t *rows, const uint32_t *cols, const double *vals,
                        const uint8_t *ops, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
                        size_t *stored_out, uint32_t *offset_rows, uint32_t *columns, double *values);
+/* SparseMatrix::prod (sparsematrix.rs:186-210), literally, up to the container: writes the call stream
+ * ret.set(i, j, sum) (sums != 0, i then j ascending) to ops_* (capacity cap; ORC_ERR_CAPACITY beyond), to be
+ * replayed with orc_crs_replay.  Dimension rule :188-190 -> ORC_ERR_SIZE_MISMATCH.  O(n_rows * n_cols). */
+int orc_crs_prod_ops_f32(size_t a_rows, size_t a_cols, const uint32_t *a_off, const uint32_t *a_col,
+                         const float *a_val, size_t b_rows, size_t b_cols, const uint32_t *b_off,
+                         const uint32_t *b_col, const float *b_val, size_t cap, size_t *n_out,
+                         uint32_t *ops_rows, uint32_t *ops_cols, float *ops_vals);
+int orc_crs_prod_ops_f64(size_t a_rows, size_t a_cols, const uint32_t *a_off, const uint32_t *a_col,
+                         const double *a_val, size_t b_rows, size_t b_cols, const uint32_t *b_off,
+                         const uint32_t *b_col, const double *b_val, size_t cap, size_t *n_out,
+                         uint32_t *ops_rows, uint32_t *ops_cols, double *ops_vals);
 /* Sortable::sort_row (sparsemat_crs.rs:163-172) on every row: stable by column */
 void orc_crs_sort_rows_f32(size_t n_rows, const uint32_t *offset_rows, uint32_t *columns, float *values);
 void orc_crs_sort_rows_f64(size_t n_rows, const uint32_t *offset_rows, uint32_t *columns, double *values);

@@ -6,6 +6,7 @@ use std::os::raw::{c_char, c_double, c_int, c_void};
 #[repr(C)] pub struct smh_vec { _private: [u8; 0] }
 
 pub const SMH_OK: c_int = 0;
+pub const SMH_ERR_DIM_MISMATCH: c_int = 1;
 pub const SMH_F32: c_int = 0;
 pub const SMH_F64: c_int = 1;
 pub const SMH_SPMV_AUTO: c_int = 0;
@@ -33,6 +34,9 @@ extern "C" {
     pub fn smh_crs_replay(dtype: c_int, n_ops: usize, rows: *const u32, cols: *const u32, values: *const c_void,
                           ops: *const u8, out: *mut *mut smh_crs) -> c_int;
     pub fn smh_crs_transpose(a: *const smh_crs, out: *mut *mut smh_crs) -> c_int;
+    pub fn smh_crs_prod(a: *const smh_crs, b: *const smh_crs, out: *mut *mut smh_crs) -> c_int;
+    pub fn smh_crs_is_symmetric(m: *const smh_crs, out: *mut c_int) -> c_int;
+    pub fn smh_crs_is_sorted(m: *const smh_crs, out: *mut c_int) -> c_int;
     pub fn smh_crs_column_info(m: *const smh_crs, rows: *mut u32, col_ptr: *mut u32, entries: *mut u32) -> c_int;
     pub fn smh_crs_sort_rows(m: *mut smh_crs) -> c_int;
     pub fn smh_crs_n_rows(m: *const smh_crs) -> usize;

@@ -85,6 +85,30 @@ impl DeviceCrs {
         DeviceCrs { handle, n_rows: unsafe { ffi::smh_crs_n_rows(handle) } }
     }
 
+    /// `SparseMatrix::prod` (src/sparsematrix.rs:186-210) with the reference's `Result`: `Err("Dimension mismatch")`
+    /// when `self.n_rows() != rhs.n_cols() || self.n_cols() != rhs.n_rows()`; no column tables needed on `rhs`.
+    pub fn prod(&self, rhs: &DeviceCrs) -> Result<DeviceCrs, String> {
+        let mut handle = std::ptr::null_mut();
+        let status = unsafe { ffi::smh_crs_prod(self.handle, rhs.handle, &mut handle) };
+        if status == ffi::SMH_ERR_DIM_MISMATCH {
+            return Err(unsafe { CStr::from_ptr(ffi::smh_last_error()) }.to_string_lossy().into_owned());
+        }
+        check(status);
+        Ok(DeviceCrs { handle, n_rows: unsafe { ffi::smh_crs_n_rows(handle) } })
+    }
+
+    /// `is_symmetric` (src/sparsematrix.rs:212-222) / `is_sorted` (:263-271) on the device copy.
+    pub fn is_symmetric(&self) -> bool {
+        let mut out: c_int = 0;
+        check(unsafe { ffi::smh_crs_is_symmetric(self.handle, &mut out) });
+        out != 0
+    }
+    pub fn is_sorted(&self) -> bool {
+        let mut out: c_int = 0;
+        check(unsafe { ffi::smh_crs_is_sorted(self.handle, &mut out) });
+        out != 0
+    }
+
     /// `ColumnIter::assemble_column_info` (src/sparsemat_crs.rs:180-191) as arrays `(rows, col_ptr, entries)`:
     /// `iter_col(j)` yields `(rows[e], values[e])` for `e in entries[col_ptr[j]..col_ptr[j+1]]`.
     pub fn column_info(&self) -> (Vec<u32>, Vec<u32>, Vec<u32>) {

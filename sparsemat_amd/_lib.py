@@ -40,6 +40,9 @@ SIGNATURES = {
     "smh_crs_transpose": (_int, [_vp, C.POINTER(_vp)]),
     "smh_crs_column_info": (_int, [_vp, _vp, _vp, _vp]),
     "smh_crs_column_info_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "smh_crs_prod": (_int, [_vp, _vp, C.POINTER(_vp)]),
+    "smh_crs_is_symmetric": (_int, [_vp, C.POINTER(_int)]),
+    "smh_crs_is_sorted": (_int, [_vp, C.POINTER(_int)]),
     "smh_crs_sort_rows": (_int, [_vp]),
     "smh_crs_destroy": (_int, [_vp]),
     "smh_crs_update_values": (_int, [_vp, _vp]),

@@ -860,6 +860,40 @@ int smh_crs_column_info_dev(const smh_crs *m, uint32_t *rows_dev, uint32_t *col_
     return column_info_common(m, rows_dev, col_ptr_dev, entries_dev, true);
 }
 
+// SparseMatrix::prod (sparsematrix.rs:186-210) for SparseMatCRS operands; Err("Dimension mismatch") of :188-190 as a status
+int smh_crs_prod(const smh_crs *a, const smh_crs *b, smh_crs **out) {
+    if (!a || !b || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (a->dtype != b->dtype) return fail(SMH_ERR_INVALID, "operands differ in value type");
+    if (a->n_rows != b->n_cols || a->n_cols != b->n_rows) return fail(SMH_ERR_DIM_MISMATCH, "Dimension mismatch");
+    if (a->nnz && (size_t)a->max_col >= a->n_cols)
+        return fail(SMH_ERR_INDEX_RANGE, "column %u out of range for %zu columns", a->max_col, a->n_cols);
+    SMH_HIP(hipStreamSynchronize(a->stream));
+    SMH_HIP(hipStreamSynchronize(b->stream));
+    smh_crs *m = new (std::nothrow) smh_crs();
+    if (!m) return fail(SMH_ERR_OOM, "host allocation failed");
+    m->dtype = a->dtype; m->owns = true;
+    m->device = current_device();
+    auto go = [&]() -> int {
+        SMH_TRY(prod_crs(a->dtype, a->d_off, a->d_col, a->d_val, a->n_rows, a->nnz, a->max_col, b->d_off, b->d_col, b->d_val, b->n_rows,
+                         &m->n_rows, &m->n_cols, &m->nnz, &m->d_off, &m->d_col, &m->d_val, nullptr));
+        return finish_create(m, 0);
+    };
+    const int rc = go();
+    if (rc != SMH_OK) { char keep[512]; strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0; smh_crs_destroy(m); strncpy(g_err, keep, sizeof g_err); return rc; }
+    *out = m;
+    return SMH_OK;
+}
+
+int smh_crs_is_symmetric(const smh_crs *m, int *out) {
+    if (!m || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    return crs_is_symmetric(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, out, m->stream);
+}
+
+int smh_crs_is_sorted(const smh_crs *m, int *out) {
+    if (!m || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    return crs_is_sorted(m->d_off, m->d_col, m->n_rows, out, m->stream);
+}
+
 int smh_crs_sort_rows(smh_crs *m) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(sort_rows(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, m->max_col, m->stream));

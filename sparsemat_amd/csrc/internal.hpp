@@ -88,6 +88,12 @@ int column_info(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t 
                 uint32_t *col_ptr, uint32_t *entries, hipStream_t s);
 int sort_rows(int dtype, const uint32_t *off, uint32_t *col, void *val, size_t n_rows, size_t nnz, uint32_t max_col,
               hipStream_t s);
+// structure predicates and SparseMatrix::prod (matops.hip).  Device pointers.
+int crs_is_sorted(const uint32_t *off, const uint32_t *col, size_t n_rows, int *out, hipStream_t s);
+int crs_is_symmetric(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, int *out, hipStream_t s);
+int prod_crs(int dtype, const uint32_t *a_off, const uint32_t *a_col, const void *a_val, size_t a_rows, size_t a_nnz, uint32_t a_max_col,
+             const uint32_t *b_off, const uint32_t *b_col, const void *b_val, size_t b_rows, size_t *n_rows_out, size_t *n_cols_out,
+             size_t *nnz_out, uint32_t **off_out, uint32_t **col_out, void **val_out, hipStream_t s);
 // K1r (LDS x-ring): inspector, host plan, kernel
 struct RingPhase {
     uint32_t row_begin, row_end;  // rows of this phase (row_begin is a multiple of 64)

@@ -114,6 +114,24 @@ class SparseMatCRS:
         e = entries[col_ptr[col]:col_ptr[col + 1]] if col < len(col_ptr) - 1 else entries[:0]
         return list(zip(rows[e].tolist(), values[e].tolist()))
 
+    def prod(self, rhs):
+        """SparseMatrix::prod (sparsematrix.rs:186-210): the SparseMatCRS the reference's loops build for
+        ``self.prod(&rhs)`` -- same sums (order of additions included), zero sums dropped, rows in descending column
+        order.  Err("Dimension mismatch") becomes a SparseMatPanic with that text."""
+        h = C.c_void_p()
+        check(lib().smh_crs_prod(self._h, rhs._h, C.byref(h)))
+        return type(self)(h, self.dtype)
+
+    def is_symmetric(self):  # sparsematrix.rs:212-222
+        out = C.c_int(0)
+        check(lib().smh_crs_is_symmetric(self._h, C.byref(out)))
+        return bool(out.value)
+
+    def is_sorted(self):  # sparsematrix.rs:263-271
+        out = C.c_int(0)
+        check(lib().smh_crs_is_sorted(self._h, C.byref(out)))
+        return bool(out.value)
+
     def sort_rows(self):
         """Sortable::sort_row (sparsemat_crs.rs:163-172) on every row: ascending columns, stable."""
         check(lib().smh_crs_sort_rows(self._h))

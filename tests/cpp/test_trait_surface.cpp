@@ -80,6 +80,20 @@ int main() {
         CHECK((rows == std::vector<uint32_t>{0, 0, 2, 2, 2}));
         CHECK((col_ptr == std::vector<uint32_t>{0, 1, 3, 3, 5}));
         CHECK((entries == std::vector<uint32_t>{2, 0, 4, 1, 3}));
+        CHECK(!a.is_sorted() && !a.is_symmetric());
+        // prod (sparsematrix.rs:186-210): needs a.n_rows == b.n_cols and a.n_cols == b.n_rows
+        auto b = SparseMatCRS<float>::from_raw_parts(4, 3, {0, 1, 2, 2, 4}, {0, 2, 1, 2}, {2.0f, 0.5f, 4.0f, -1.0f});
+        auto c = a.prod(b);
+        c.raw_parts(off, col, val);
+        // row 0 of a: (1, 1.0), (3, 2.0) -> b row 1: (2, .5), b row 3: (1, 4), (2, -1): c(0,1) = 8, c(0,2) = .5 + (-2)
+        // row 2 of a: (0, 3.0), (3, 4.0), (1, 5.0) -> c(2,0) = 6, c(2,1) = 16, c(2,2) = 2.5 + (-4); columns descending
+        CHECK(c.n_rows() == 3 && c.n_cols() == 3);
+        CHECK((off == std::vector<uint32_t>{0, 2, 2, 5}));
+        CHECK((col == std::vector<uint32_t>{2, 1, 2, 1, 0}));
+        CHECK((val == std::vector<float>{-1.5f, 8.0f, -1.5f, 16.0f, 6.0f}));
+        bool threw = false;
+        try { a.prod(a); } catch (const Panic &p) { threw = std::string(p.what()).find("Dimension mismatch") != std::string::npos; }
+        CHECK(threw);
     }
     // check_cg (src/lib.rs:36-52)
     {
