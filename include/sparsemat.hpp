@@ -238,6 +238,50 @@ class SparseMatIndexList {
     size_t n_rows_ = 0, n_cols_ = 0;
 };
 
+// SparseMatPar<SparseMatCRS<T,u32>> (sparsemat_par.rs:12-35, 86-140) driven by one process: block b = rows
+// [b R, (b+1) R), R = n_rows / n_blocks (the last block takes the remainder), on device devices[b] (empty: block b on
+// device b mod device count).  Filled from a global CRS; host vectors in, host vectors out.
+template <typename T>
+class SparseMatPar {
+  public:
+    static SparseMatPar with_sub_matrices(size_t n_blocks, size_t n_rows, size_t n_cols, const std::vector<uint32_t> &offset_rows,
+                                          const std::vector<uint32_t> &columns, const std::vector<T> &values,
+                                          const std::vector<int> &devices = {}) {
+        if (offset_rows.size() != n_rows + 1) throw Panic(SMH_ERR_INVALID, "offset_rows must have n_rows+1 entries");
+        if (columns.size() != values.size()) throw Panic(SMH_ERR_INVALID, "columns and values differ in length");
+        if (!devices.empty() && devices.size() != n_blocks) throw Panic(SMH_ERR_INVALID, "one device per block");
+        SparseMatPar m;
+        detail::check(smh_par_create(detail::dtype_of<T>::value, n_blocks, devices.empty() ? nullptr : devices.data(), n_rows, n_cols,
+                                     offset_rows.data(), columns.data(), values.data(), 1, &m.h_));
+        return m;
+    }
+    SparseMatPar(SparseMatPar &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    SparseMatPar &operator=(SparseMatPar &&o) noexcept { std::swap(h_, o.h_); return *this; }
+    SparseMatPar(const SparseMatPar &) = delete;
+    ~SparseMatPar() { smh_par_destroy(h_); }
+
+    size_t n_rows() const { return smh_par_n_rows(h_); }
+    size_t n_cols() const { return smh_par_n_cols(h_); }                       // sparsemat_par.rs:109-115
+    size_t n_non_zero_entries() const { return smh_par_nnz(h_); }              // :117-123
+    size_t n_blocks() const { return smh_par_n_blocks(h_); }
+    void scale(T a) { detail::check(smh_par_scale(h_, (double)a)); }           // :135-139
+    std::pair<size_t, size_t> get_block_and_row_id(size_t row) const {         // :31-35, clamped to the last block
+        size_t b = 0, r = 0;
+        detail::check(smh_par_get_block_and_row_id(h_, row, &b, &r));
+        return {b, r};
+    }
+    std::vector<T> mvp(const std::vector<T> &rhs, int variant = SMH_SPMV_AUTO) const {
+        std::vector<T> y(n_rows());
+        detail::check(smh_par_spmv(h_, rhs.data(), rhs.size(), y.data(), variant));
+        return y;
+    }
+    smh_par *handle() const { return h_; }
+
+  private:
+    SparseMatPar() = default;
+    smh_par *h_ = nullptr;
+};
+
 // linearsolver.rs:12-61.  The reference keeps tol / iter_max private with only Default (1e-12, 10000);
 // the two-argument constructor is the documented addition.
 class ConjugateGradient {
@@ -249,6 +293,12 @@ class ConjugateGradient {
     template <typename T>
     void solve(const SparseMatCRS<T> &mat, const DenseVec<T> &b, DenseVec<T> &x) {
         detail::check(smh_cg_solve_vec(mat.handle(), b.handle(), x.handle(), tol_, iter_max_, SMH_SPMV_AUTO, 0,
+                                       &iterations_, &r_norm_squared_));
+    }
+    // the same solve on a row-partitioned matrix (M = SparseMatPar): host vectors, x updated in place
+    template <typename T>
+    void solve(const SparseMatPar<T> &mat, const std::vector<T> &b, std::vector<T> &x) {
+        detail::check(smh_par_cg_solve(mat.handle(), b.data(), b.size(), x.data(), x.size(), tol_, iter_max_, SMH_SPMV_AUTO,
                                        &iterations_, &r_norm_squared_));
     }
     size_t iterations() const { return iterations_; }

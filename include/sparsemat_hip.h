@@ -290,6 +290,41 @@ int smh_cg_solve(smh_crs *m, const void *b_host, size_t b_len, void *x_host_inou
 int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_t iter_max,
                      int variant, size_t check_every, size_t *iters_out, double *rr_out);
 
+/* ---- SparseMatPar<SparseMatCRS<T,u32>> (sparsemat_par.rs:12-35, 86-140), one process ------
+ * n_blocks row blocks of R = n_rows / n_blocks rows (with_sub_matrices :20-28; integer
+ * division :21), block b = global rows [b R, (b+1) R) with local row ids and GLOBAL column ids,
+ * living on device device_ids[b] (NULL: block b on device b mod device count; several blocks
+ * may share a device).  The last block takes the remainder -- the reference clamps the block id
+ * to n_blocks (:32), one past the last block, and panics there.  R == 0 is SMH_ERR_INVALID (the
+ * reference divides by zero in :32).  The global CRS arrays are host arrays, borrowed for the
+ * call and split at the block boundaries.
+ * smh_par_spmv: y = A x (the trait-default mvp through iter_row :86-89) on host vectors; blocks
+ * run concurrently, each uploading only x[min column .. max column] of its rows.
+ * smh_par_cg_solve: ConjugateGradient::solve (linearsolver.rs:27-61) with x, r, p, Ap distributed
+ * by rows; per iteration blocks exchange only the entries of p their columns reference (device
+ * to device, hipMemcpyPeerAsync) and the two dot products are folded on the host in block order.
+ * Same statuses and outputs as smh_cg_solve.  The multi-process form (one rank per GPU, RCCL)
+ * is sparsemat_amd/sparsemat_par.py. */
+typedef struct smh_par smh_par;
+int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size_t n_rows,
+                   size_t n_cols, const uint32_t *offset_rows, const uint32_t *columns,
+                   const void *values, int validate, smh_par **out);
+int smh_par_destroy(smh_par *p);
+size_t smh_par_n_blocks(const smh_par *p);
+size_t smh_par_n_rows(const smh_par *p);
+size_t smh_par_n_cols(const smh_par *p);          /* :109-115 */
+size_t smh_par_nnz(const smh_par *p);             /* n_non_zero_entries :117-123 */
+size_t smh_par_rows_per_block(const smh_par *p);  /* n_rows_sub_matrix :13 */
+/* block b: its device matrix (owned by the par handle), global row range, device ordinal */
+int smh_par_block(const smh_par *p, size_t block, smh_crs **crs_out, size_t *row_begin,
+                  size_t *row_end, int *device);
+/* get_block_and_row_id (:31-35), clamped to the last block */
+int smh_par_get_block_and_row_id(const smh_par *p, size_t row, size_t *block_out, size_t *row_out);
+int smh_par_scale(smh_par *p, double a);          /* :135-139 */
+int smh_par_spmv(smh_par *p, const void *x_host, size_t x_len, void *y_host, int variant);
+int smh_par_cg_solve(smh_par *p, const void *b_host, size_t b_len, void *x_host_inout, size_t x_len,
+                     double tol, size_t iter_max, int variant, size_t *iters_out, double *rr_out);
+
 /* ---- synthetic workloads (bench / test support, DESIGN.md "Synthetic inputs") ------------
  * Counter-based generators writing straight into device memory so 10M..80M-row inputs never
  * cross PCIe.  pattern: 0 banded-stratified (ascending), 1 uniform (draw order),

@@ -4,6 +4,7 @@ use std::os::raw::{c_char, c_double, c_int, c_void};
 
 #[repr(C)] pub struct smh_crs { _private: [u8; 0] }
 #[repr(C)] pub struct smh_vec { _private: [u8; 0] }
+#[repr(C)] pub struct smh_par { _private: [u8; 0] }
 
 pub const SMH_OK: c_int = 0;
 pub const SMH_ERR_DIM_MISMATCH: c_int = 1;
@@ -39,6 +40,15 @@ extern "C" {
     pub fn smh_crs_is_sorted(m: *const smh_crs, out: *mut c_int) -> c_int;
     pub fn smh_crs_column_info(m: *const smh_crs, rows: *mut u32, col_ptr: *mut u32, entries: *mut u32) -> c_int;
     pub fn smh_crs_sort_rows(m: *mut smh_crs) -> c_int;
+    // SparseMatPar<SparseMatCRS<T,u32>>, one process: block b on device device_ids[b] (null: b mod device count)
+    pub fn smh_par_create(dtype: c_int, n_blocks: usize, device_ids: *const c_int, n_rows: usize, n_cols: usize,
+                          offset_rows: *const u32, columns: *const u32, values: *const c_void, validate: c_int,
+                          out: *mut *mut smh_par) -> c_int;
+    pub fn smh_par_destroy(p: *mut smh_par) -> c_int;
+    pub fn smh_par_spmv(p: *mut smh_par, x_host: *const c_void, x_len: usize, y_host: *mut c_void, variant: c_int) -> c_int;
+    pub fn smh_par_cg_solve(p: *mut smh_par, b_host: *const c_void, b_len: usize, x_host_inout: *mut c_void, x_len: usize,
+                            tol: c_double, iter_max: usize, variant: c_int, iters_out: *mut usize,
+                            rr_out: *mut c_double) -> c_int;
     pub fn smh_crs_n_rows(m: *const smh_crs) -> usize;
     pub fn smh_crs_n_cols(m: *const smh_crs) -> usize;
     pub fn smh_crs_nnz(m: *const smh_crs) -> usize;

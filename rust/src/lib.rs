@@ -171,3 +171,50 @@ impl Drop for DeviceCrs {
         unsafe { ffi::smh_crs_destroy(self.handle) };
     }
 }
+
+/// `SparseMatPar<SparseMatCRS<T, u32>>` (src/sparsemat_par.rs:12-35) on several devices of this process: block `b`
+/// = rows `[b R, (b+1) R)`, `R = n_rows / n_blocks` (src/sparsemat_par.rs:21), on device `devices[b]`.  Built from the
+/// global CRS arrays the sub-matrices concatenate to (local row ids, global column ids, as the reference stores them).
+pub struct DevicePar {
+    handle: *mut ffi::smh_par,
+    n_rows: usize,
+}
+
+impl DevicePar {
+    pub fn new<T: HipValue>(n_blocks: usize, devices: Option<&[i32]>, n_rows: usize, n_cols: usize, offset_rows: &[u32],
+                            columns: &[u32], values: &[T]) -> Self {
+        assert_eq!(offset_rows.len(), n_rows + 1);
+        if let Some(d) = devices { assert_eq!(d.len(), n_blocks); }
+        let mut handle = std::ptr::null_mut();
+        check(unsafe {
+            ffi::smh_par_create(T::DTYPE, n_blocks, devices.map_or(std::ptr::null(), |d| d.as_ptr()), n_rows, n_cols,
+                                offset_rows.as_ptr(), columns.as_ptr(), values.as_ptr() as *const c_void, 1, &mut handle)
+        });
+        DevicePar { handle, n_rows }
+    }
+
+    /// `SparseMatrix::mvp` through `iter_row` (src/sparsemat_par.rs:86-89): all blocks run concurrently.
+    pub fn mvp<T: HipValue + Default>(&self, x: &[T]) -> Vec<T> {
+        let mut y = vec![T::default(); self.n_rows];
+        check(unsafe {
+            ffi::smh_par_spmv(self.handle, x.as_ptr() as *const c_void, x.len(), y.as_mut_ptr() as *mut c_void, ffi::SMH_SPMV_AUTO)
+        });
+        y
+    }
+
+    /// `ConjugateGradient::solve` with `M = SparseMatPar<..>`: halos of `p` travel device to device.
+    pub fn cg_solve<T: HipValue>(&self, b: &[T], x: &mut [T], tol: f64, iter_max: usize) -> (usize, f64) {
+        let (mut iters, mut rr) = (0usize, 0f64);
+        check(unsafe {
+            ffi::smh_par_cg_solve(self.handle, b.as_ptr() as *const c_void, b.len(), x.as_mut_ptr() as *mut c_void, x.len(),
+                                  tol, iter_max, ffi::SMH_SPMV_AUTO, &mut iters, &mut rr)
+        });
+        (iters, rr)
+    }
+}
+
+impl Drop for DevicePar {
+    fn drop(&mut self) {
+        unsafe { ffi::smh_par_destroy(self.handle) };
+    }
+}

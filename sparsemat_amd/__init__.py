@@ -15,6 +15,7 @@ from .sparsemat_crs import SparseMatCRS  # noqa: F401
 from .linearsolver import ConjugateGradient  # noqa: F401
 from . import sparsemat_par, synth  # noqa: F401
 from .sparsemat_par import SparseMatPar  # noqa: F401
+from .sparsemat_par_local import SparseMatParLocal  # noqa: F401
 
-__all__ = ["SparseMatCRS", "DenseVec", "ConjugateGradient", "SparseMatPar", "SparseMatPanic", "synth",
+__all__ = ["SparseMatCRS", "DenseVec", "ConjugateGradient", "SparseMatPar", "SparseMatParLocal", "SparseMatPanic", "synth",
            "sparsemat_par", "lib", "LIB_PATH"]

@@ -100,6 +100,19 @@ SIGNATURES = {
                             C.POINTER(C.c_double)]),
     "smh_cg_solve_vec": (_int, [_vp, _vp, _vp, C.c_double, _sz, _int, _sz, C.POINTER(_sz),
                                 C.POINTER(C.c_double)]),
+    "smh_par_create": (_int, [_int, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
+    "smh_par_destroy": (_int, [_vp]),
+    "smh_par_n_blocks": (_sz, [_vp]),
+    "smh_par_n_rows": (_sz, [_vp]),
+    "smh_par_n_cols": (_sz, [_vp]),
+    "smh_par_nnz": (_sz, [_vp]),
+    "smh_par_rows_per_block": (_sz, [_vp]),
+    "smh_par_block": (_int, [_vp, _sz, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_int)]),
+    "smh_par_get_block_and_row_id": (_int, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "smh_par_scale": (_int, [_vp, C.c_double]),
+    "smh_par_spmv": (_int, [_vp, _vp, _sz, _vp, _int]),
+    "smh_par_cg_solve": (_int, [_vp, _vp, _sz, _vp, _sz, C.c_double, _sz, _int, C.POINTER(_sz),
+                                C.POINTER(C.c_double)]),
     "smh_synth_x": (_int, [_int, C.c_uint64, _sz, _sz, _vp, _vp]),
     "smh_synth_fixed": (_int, [_int, C.c_uint64, _int, _sz, C.c_uint32, _sz, _sz, _vp, _vp, _vp, _vp]),
     "smh_synth_powerlaw_cdf": (_int, [C.c_uint32, C.c_double, _vp]),

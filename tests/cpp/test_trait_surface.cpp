@@ -95,6 +95,24 @@ int main() {
         try { a.prod(a); } catch (const Panic &p) { threw = std::string(p.what()).find("Dimension mismatch") != std::string::npos; }
         CHECK(threw);
     }
+    // check_sparsemat_par (src/lib.rs:180-202): with_sub_matrices(4, 16) holding the matrix of the other container tests
+    {
+        std::vector<uint32_t> off = {0, 3, 5, 6};
+        off.resize(17, 6u);  // rows 3..15 empty
+        auto par = SparseMatPar<float>::with_sub_matrices(4, 16, 3, off, {1, 2, 0, 2, 1, 2},
+                                                          {4.2f, 0.12f, 7.12f, 4.12f, 2.24f, 2.12f}, {0, 0, 0, 0});
+        CHECK(par.n_blocks() == 4 && par.n_non_zero_entries() == 6 && par.n_cols() == 3);
+        auto y = par.mvp(std::vector<float>{2.0f, 4.8f, 1.2f}, SMH_SPMV_STREAM);
+        CHECK(y[0] == 34.544f);              // assert_eq!(mvp.get(0), 34.544)
+        CHECK((par.get_block_and_row_id(7) == std::pair<size_t, size_t>{1, 3}));
+        // ConjugateGradient::solve on a partitioned SPD matrix (two blocks on device 0)
+        auto spd = SparseMatPar<double>::with_sub_matrices(2, 2, 2, {0, 2, 4}, {0, 1, 0, 1}, {4.0, 1.0, 1.0, 3.0}, {0, 0});
+        std::vector<double> b = {1.0, 2.0}, x = {2.0, 1.0};
+        ConjugateGradient cg;
+        cg.solve(spd, b, x);
+        CHECK(std::floor(x[0] * 10000.0) / 10000.0 == 0.0909);   // src/lib.rs:49-51 through the partitioned path
+        CHECK(cg.iterations() == 2);
+    }
     // check_cg (src/lib.rs:36-52)
     {
         auto a = SparseMatCRS<double>::from_raw_parts(2, 2, {0, 2, 4}, {0, 1, 0, 1}, {4.0, 1.0, 1.0, 3.0});
