@@ -143,6 +143,53 @@ def test_c_crs_replay_oracle_reproduces_reference_crs_and_container_restatement(
     assert list(rows) == [0, 0, 2, 2, 2] and list(col_ptr) == [0, 1, 3, 3, 5] and list(entries) == [2, 0, 4, 1, 3]
 
 
+def test_c_prod_oracle_matches_the_loops_written_out():
+    """orc_crs_prod_ops + orc_crs_replay against SparseMatrix::prod (sparsematrix.rs:186-210) written out in plain
+    Python over the step-by-step CRS container: column lists of rhs in storage order, the row stably sorted,
+    take_while(col <= row), `sum += val * val_rhs` in the value type, `if sum != 0 { ret.set(i, j, sum) }`."""
+    rng = np.random.default_rng(8)
+    for t in range(25):
+        dt = np.float32 if t % 2 else np.float64
+        n, k = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+
+        def rand(n_rows, n_cols):
+            lens = rng.integers(0, 5, n_rows)
+            lens[-1] = max(lens[-1], 1)
+            off = np.zeros(n_rows + 1, np.uint32)
+            np.cumsum(lens, out=off[1:])
+            col = rng.integers(0, n_cols, int(off[-1])).astype(np.uint32)  # unsorted, duplicates
+            col[-1] = n_cols - 1
+            val = rng.integers(-2, 3, len(col)).astype(dt) if t % 3 == 0 else rng.uniform(-1, 1, len(col)).astype(dt)
+            return n_rows, n_cols, off, col, val
+        a, b = rand(n, k), rand(k, n)
+        # rhs.assemble_column_info(): per column the (row, value) pairs in storage order
+        b_cols = [[] for _ in range(b[1])]
+        for r in range(b[0]):
+            for q in range(b[2][r], b[2][r + 1]):
+                b_cols[b[3][q]].append((r, b[4][q]))
+        ret = assembly.CrsPushMatrix(dt)
+        for i in range(a[0]):
+            row = sorted(((int(a[3][q]), a[4][q]) for q in range(a[2][i], a[2][i + 1])), key=lambda cv: cv[0])  # stable
+            for j in range(b[1]):
+                s = dt(0)
+                for r, v_rhs in b_cols[j]:
+                    for c, v in row:
+                        if c > r:
+                            break
+                        if c == r:
+                            s = dt(s + dt(v * v_rhs))
+                if s != 0:
+                    ret.set(i, j, s)
+        e_rows, e_cols, e_off, e_col, e_val = ret.to_crs_arrays()
+        reach = int(e_off[-1]) if e_rows else 0
+        n_rows, n_cols, off, col, val, stored = oracle.prod(a, b)
+        assert (n_rows, n_cols, stored) == (e_rows, e_cols, len(e_col))
+        assert np.array_equal(off[:n_rows + 1] if n_rows else off[:0], e_off[:n_rows + 1] if n_rows else e_off[:0])
+        assert np.array_equal(col, e_col[:reach]) and val.tobytes() == e_val[:reach].tobytes()
+    with pytest.raises(oracle.OraclePanic):  # Err("Dimension mismatch"), :188-190
+        oracle.prod(a, (b[0], b[1] + 1, b[2], b[3], b[4]))
+
+
 def test_c_assembly_oracle_matches_container_restatement():
     """Random add_to/set streams: the C oracle equals the step-by-step Python container (IndexListMatrix),
     incl. gaps (empty rows), -0.0 values and the empty stream; sort_rows equals a stable numpy sort."""
