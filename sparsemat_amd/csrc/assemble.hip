@@ -122,7 +122,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_asm_fold(const uint32_t *__restrict__ row_s, const uint64_t *__restrict__ cp_s, const T *__restrict__ vals_s,
            const uint8_t *__restrict__ ops_s, const uint32_t *__restrict__ entry_id /* exclusive scan of heads */,
-           uint64_t n, bool reverse, uint32_t *__restrict__ first_pos, uint32_t *__restrict__ uidx,
+           uint64_t n, bool reverse, bool all_set, uint32_t *__restrict__ first_pos, uint32_t *__restrict__ uidx,
            uint32_t *__restrict__ ucol, T *__restrict__ uval) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         if (!run_head(row_s, cp_s, k)) continue;
@@ -130,7 +130,7 @@ k_asm_fold(const uint32_t *__restrict__ row_s, const uint64_t *__restrict__ cp_s
         uint64_t j = k;
         do {
             const T v = vals_s[j];
-            if (ops_s && ops_s[j]) acc = v;
+            if (all_set || (ops_s && ops_s[j])) acc = v;
             else if constexpr (sizeof(T) == 4) acc = __fadd_rn(acc, v);
             else acc = __dadd_rn(acc, v);
             ++j;
@@ -184,7 +184,8 @@ constexpr uint32_t kRowwiseMaxOps = 2048;
 template <typename T>
 __global__ void __launch_bounds__(kRowBlock)
 k_asm_rowwise(const uint32_t *__restrict__ seg, const uint64_t *__restrict__ cp_s, const T *__restrict__ vals,
-              const uint8_t *__restrict__ ops, uint64_t n_rows, uint32_t *lcol, T *lval, uint32_t *__restrict__ counts) {
+              const uint8_t *__restrict__ ops, bool all_set, uint64_t n_rows, uint32_t *lcol, T *lval,
+              uint32_t *__restrict__ counts) {
     __shared__ uint32_t s_col[kRowCap][kRowBlock];
     __shared__ T s_val[kRowCap][kRowBlock];
     const uint32_t t = threadIdx.x;
@@ -196,7 +197,7 @@ k_asm_rowwise(const uint32_t *__restrict__ seg, const uint64_t *__restrict__ cp_
         const uint64_t e = cp_s[j];
         const uint32_t c = (uint32_t)(e >> 32), i = (uint32_t)e;
         const T v = vals[i];
-        const bool set = ops && ops[i];
+        const bool set = all_set || (ops && ops[i]);
         uint32_t f = cnt;  // find_index (sparsemat_indexlist.rs:29-42): first match in list order
         const uint32_t lim = cnt < (uint32_t)kRowCap ? cnt : (uint32_t)kRowCap;
         for (uint32_t q = 0; q < lim; ++q)
@@ -252,6 +253,48 @@ k_asm_row_emit(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ of
     }
 }
 
+// ---- streams without repeated (row, column) pairs: nothing to fold, nothing to search --------------------------
+// The caller may guarantee that operations on the same (row, column) are ADJACENT in the row's list (transpose: all
+// entries of a source row are consecutive in the stream).  Then one pass over neighbours tells whether any pair
+// repeats at all; if none does, every operation is its own entry: offsets = the row segments, and the entries are the
+// sorted operations themselves (reversed per row for a SparseMatCRS target).
+__global__ void __launch_bounds__(kBlock)
+k_asm_adjacent_repeats(const uint32_t *__restrict__ row_s, const uint64_t *__restrict__ cp_s, uint64_t n, uint32_t *flag) {
+    for (uint64_t k = 1 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+        if (row_s[k] == row_s[k - 1] && (uint32_t)(cp_s[k] >> 32) == (uint32_t)(cp_s[k - 1] >> 32)) *flag = 1u;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_asm_direct_emit(const uint32_t *__restrict__ seg, const uint64_t *__restrict__ cp_s, const T *__restrict__ vals,
+                  const uint8_t *__restrict__ ops, bool all_set, uint64_t n_rows, bool reverse, uint32_t *__restrict__ col,
+                  T *__restrict__ val) {
+    __shared__ uint32_t s_off[kBlock + 1];
+    const uint64_t n_groups = (n_rows + kBlock - 1) / kBlock;
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t r0 = g * kBlock, r1 = r0 + kBlock < n_rows ? r0 + kBlock : n_rows;
+        const uint32_t nr = (uint32_t)(r1 - r0);
+        __syncthreads();
+        if (threadIdx.x <= nr) s_off[threadIdx.x] = seg[r0 + threadIdx.x];
+        if (threadIdx.x == 0 && nr == (uint32_t)kBlock) s_off[kBlock] = seg[r1];
+        __syncthreads();
+        const uint32_t base = s_off[0], total = s_off[nr] - base;
+        for (uint32_t p = threadIdx.x; p < total; p += kBlock) {
+            uint32_t lo = 0, hi = nr;  // last row with s_off[row] - base <= p
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_off[mid] - base <= p) lo = mid; else hi = mid;
+            }
+            const uint32_t idx = p - (s_off[lo] - base);
+            const uint64_t e = cp_s[reverse ? (uint64_t)s_off[lo + 1] - 1 - idx : (uint64_t)s_off[lo] + idx];
+            const uint32_t i = (uint32_t)e;
+            const T v = vals[i];
+            col[(uint64_t)base + p] = (uint32_t)(e >> 32);
+            val[(uint64_t)base + p] = (all_set || (ops && ops[i])) ? v : asm_add(T(0), v);  // push(.., zero) then `=` or `+=`
+        }
+    }
+}
+
 static unsigned bits_for(uint64_t v) {  // bits needed to hold v
     unsigned b = 1;
     while (b < 64 && (v >> b)) ++b;
@@ -286,6 +329,7 @@ struct Scratch {
 
 template <typename T>
 static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, const T *vals, const uint8_t *ops, bool reverse,
+                      bool all_set, bool repeats_adjacent,
                       size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out, uint32_t **col_out,
                       T **val_out, hipStream_t s) {
     // SMH_ASSEMBLE_TIMING=1: wall time of every stage on stderr (development aid)
@@ -298,6 +342,7 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
         fprintf(stderr, "[assemble] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    if (all_set) ops = nullptr;  // every operation is `set`: no array to consult
     Scratch tmp_bufs;
     uint32_t *dims = nullptr, *row_key = nullptr, *row_s = nullptr, *seg = nullptr, *head = nullptr;
     uint64_t *cp = nullptr, *cp_s = nullptr;
@@ -330,6 +375,42 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
     SMH_HIP(hipMemcpyAsync(&max_ops, dims, sizeof max_ops, hipMemcpyDeviceToHost, s));
     SMH_HIP(hipStreamSynchronize(s));
     static const bool allow_rowwise = !(getenv("SMH_ASSEMBLE_ROWWISE") && atoi(getenv("SMH_ASSEMBLE_ROWWISE")) == 0);
+    static const bool allow_direct = !(getenv("SMH_ASSEMBLE_DIRECT") && atoi(getenv("SMH_ASSEMBLE_DIRECT")) == 0);
+    if (repeats_adjacent && allow_direct) {
+        uint32_t repeats = 0;
+        SMH_HIP(hipMemsetAsync(dims, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_asm_adjacent_repeats, dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, cp_s, n, dims);
+        SMH_HIP(hipGetLastError());
+        SMH_HIP(hipMemcpyAsync(&repeats, dims, sizeof repeats, hipMemcpyDeviceToHost, s));
+        SMH_HIP(hipStreamSynchronize(s));
+        lap("segments, longest row, repeats");
+        if (!repeats) {  // every operation is an entry: offsets = segments, entries = the sorted operations
+            uint32_t *off = nullptr, *col = nullptr;
+            T *val = nullptr;
+            auto go = [&]() -> int {
+                SMH_HIP(hipMalloc((void **)&off, (n_rows + 1) * sizeof(uint32_t)));
+                SMH_HIP(hipMalloc((void **)&col, (n + 4) * sizeof(uint32_t)));
+                SMH_HIP(hipMalloc((void **)&val, (n + 4) * sizeof(T)));
+                SMH_HIP(hipMemcpyAsync(off, seg, (n_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                SMH_HIP(hipMemsetAsync(col + n, 0, 4 * sizeof(uint32_t), s));
+                SMH_HIP(hipMemsetAsync(val + n, 0, 4 * sizeof(T), s));
+                hipLaunchKernelGGL((k_asm_direct_emit<T>), dim3(grid_for(n_rows)), dim3(kBlock), 0, s, seg, cp_s, vals, ops, all_set, n_rows,
+                                   reverse, col, val);
+                SMH_HIP(hipGetLastError());
+                SMH_HIP(hipStreamSynchronize(s));
+                lap("direct emit");
+                return SMH_OK;
+            };
+            const int rc = go();
+            if (rc != SMH_OK) {
+                (void)hipFree(off); (void)hipFree(col); (void)hipFree(val);
+                return rc;
+            }
+            *n_rows_out = (size_t)n_rows; *n_cols_out = (size_t)n_cols; *nnz_out = (size_t)n;
+            *off_out = off; *col_out = col; *val_out = val;
+            return SMH_OK;
+        }
+    }
     if (allow_rowwise && max_ops <= kRowwiseMaxOps) {
         // short rows: one thread replays a row; lists land in `row_key` (columns) / a value scratch at seg[r]
         uint32_t *lcol = row_key;  // dead after the sort
@@ -342,7 +423,7 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
         auto go = [&]() -> int {
             SMH_HIP(hipMalloc((void **)&off, (n_rows + 1) * sizeof(uint32_t)));
             hipLaunchKernelGGL((k_asm_rowwise<T>), dim3((unsigned)((n_rows + kRowBlock - 1) / kRowBlock)), dim3(kRowBlock), 0, s, seg, cp_s,
-                               vals, ops, n_rows, lcol, lval, off);
+                               vals, ops, all_set, n_rows, lcol, lval, off);
             SMH_HIP(hipGetLastError());
             lap("row replay");
             SMH_TRY(device_exclusive_scan_u32(off, n_rows + 1, s, &n_entries));  // counts -> CRS offsets
@@ -386,7 +467,7 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
     SMH_TRY(tmp_bufs.alloc(&uidx_s, n_entries));
     SMH_TRY(tmp_bufs.alloc(&ucol, n_entries));
     SMH_TRY(tmp_bufs.alloc(&uval, n_entries));
-    hipLaunchKernelGGL((k_asm_fold<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, runs, vals_s, ops_s, head, n, reverse, first_pos,
+    hipLaunchKernelGGL((k_asm_fold<T>), dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, runs, vals_s, ops_s, head, n, reverse, all_set, first_pos,
                        uidx, ucol, uval);
     SMH_HIP(hipGetLastError());
     // result arrays (owned by the caller; padded like smh_crs_create's)
@@ -419,15 +500,18 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
 }
 
 // rows/cols/vals/ops: DEVICE arrays of n operations (ops may be null: all add_to).  n >= 1.
+// all_set: every operation is `set` (ops ignored).  repeats_adjacent: the caller guarantees that operations on the same (row,
+// column) are neighbours in the row's list (transpose) -- streams without any repeat then skip the replay.
 // reverse_rows: every row in REVERSE order of first appearance -- the layout the same stream leaves in a SparseMatCRS, whose push
 // inserts at the start of the row (sparsemat_crs.rs:85-87); the first-push quirk is the caller's business (capi.hip).
 int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t *cols, const void *vals, const uint8_t *ops,
-                      bool reverse_rows, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out, uint32_t **col_out,
+                      bool reverse_rows, bool all_set, bool repeats_adjacent, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
+                      uint32_t **off_out, uint32_t **col_out,
                       void **val_out, hipStream_t s) {
     if (dtype == SMH_F64)
-        return assemble_t<double>(n, rows, cols, (const double *)vals, ops, reverse_rows, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
+        return assemble_t<double>(n, rows, cols, (const double *)vals, ops, reverse_rows, all_set, repeats_adjacent, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
                                   (double **)val_out, s);
-    return assemble_t<float>(n, rows, cols, (const float *)vals, ops, reverse_rows, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
+    return assemble_t<float>(n, rows, cols, (const float *)vals, ops, reverse_rows, all_set, repeats_adjacent, n_rows_out, n_cols_out, nnz_out, off_out, col_out,
                              (float **)val_out, s);
 }
 

@@ -713,7 +713,8 @@ int smh_crs_create_dev(smh_dtype dtype, size_t n_rows, size_t n_cols, size_t nnz
 //   * second (row, column) == first: the first operation keeps an entry of its own, the oldest of its row (= last in storage);
 //   * a single operation: no rows at all (n_rows stays 0), one orphan.
 static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, const uint32_t *cols, const void *values,
-                           const uint8_t *ops, bool on_device, bool into_crs, smh_crs **out) {
+                           const uint8_t *ops, bool on_device, bool into_crs, smh_crs **out, bool transposing = false) {
+    // transposing: every operation is `set` (ops unused) and repeats of a (row, column) pair are neighbours in the row's list
     if (!out) return fail(SMH_ERR_INVALID, "NULL out pointer");
     if (dtype != SMH_F32 && dtype != SMH_F64) return fail(SMH_ERR_INVALID, "unknown dtype %d", (int)dtype);
     if (n_ops && (!rows || !cols || !values)) return fail(SMH_ERR_INVALID, "NULL operation array");
@@ -747,7 +748,8 @@ static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, 
             SMH_HIP(hipMemcpy(r01, rows, k * sizeof(uint32_t), kind));
             SMH_HIP(hipMemcpy(c01, cols, k * sizeof(uint32_t), kind));
             SMH_HIP(hipMemcpy(&v0, values, vs, kind));
-            if (ops) SMH_HIP(hipMemcpy(&op0, ops, 1, kind));
+            if (transposing) op0 = 1;
+            else if (ops) SMH_HIP(hipMemcpy(&op0, ops, 1, kind));
             if (n_ops == 1) return no_rows((size_t)c01[0] + 1);
             if (r01[1] < r01[0]) { skip = 1; min_cols = (size_t)c01[0] + 1; }
             else if (r01[1] == r01[0] && c01[1] == c01[0]) { skip = 1; twin = true; }
@@ -769,7 +771,7 @@ static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, 
             d_rows = (const uint32_t *)d_in[0]; d_cols = (const uint32_t *)d_in[1]; d_vals = d_in[2]; d_ops = (const uint8_t *)d_in[3];
         }
         SMH_TRY(assemble_triplets(dtype, n_ops - skip, d_rows + skip, d_cols + skip, (const char *)d_vals + skip * vs,
-                                  d_ops ? d_ops + skip : nullptr, into_crs, &m->n_rows, &m->n_cols, &m->nnz, &m->d_off, &m->d_col,
+                                  d_ops ? d_ops + skip : nullptr, into_crs, transposing, transposing, &m->n_rows, &m->n_cols, &m->nnz, &m->d_off, &m->d_col,
                                   &m->d_val, nullptr));
         if (min_cols > m->n_cols) m->n_cols = min_cols;
         if (twin) {  // the first operation's own entry: push(i, j, zero) then `=` or `+=` (sparsematrix.rs:226-233)
@@ -816,17 +818,14 @@ int smh_crs_transpose(const smh_crs *a, smh_crs **out) {
     SMH_HIP(hipStreamSynchronize(a->stream));
     if (a->nnz == 0) return assemble_common((smh_dtype)a->dtype, 0, nullptr, nullptr, nullptr, nullptr, true, true, out);
     uint32_t *d_rowof = nullptr;
-    uint8_t *d_set = nullptr;
     SMH_HIP(hipMalloc((void **)&d_rowof, a->nnz * sizeof(uint32_t)));
-    if (hipMalloc((void **)&d_set, a->nnz) != hipSuccess) { (void)hipFree(d_rowof); return fail(SMH_ERR_OOM, "hipMalloc failed"); }
     auto go = [&]() -> int {
-        SMH_HIP(hipMemset(d_set, 1, a->nnz));
         SMH_TRY(expand_rows(a->d_off, a->n_rows, d_rowof, nullptr));
         SMH_HIP(hipStreamSynchronize(nullptr));
-        return assemble_common((smh_dtype)a->dtype, a->nnz, a->d_col, d_rowof, a->d_val, d_set, true, true, out);
+        return assemble_common((smh_dtype)a->dtype, a->nnz, a->d_col, d_rowof, a->d_val, nullptr, true, true, out, true);
     };
     const int rc = go();
-    (void)hipFree(d_rowof); (void)hipFree(d_set);
+    (void)hipFree(d_rowof);
     return rc;
 }
 

@@ -79,8 +79,8 @@ int build_colblock(int dtype, const uint32_t *off, const uint32_t *col, const vo
                    hipStream_t s);
 // on-device assembly (assemble.hip): add_to/set stream -> CRS; sort_row for all rows.  Device pointers.
 int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t *cols, const void *vals, const uint8_t *ops,
-                      bool reverse_rows, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out, uint32_t **off_out,
-                      uint32_t **col_out, void **val_out, hipStream_t s);
+                      bool reverse_rows, bool all_set, bool repeats_adjacent, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
+                      uint32_t **off_out, uint32_t **col_out, void **val_out, hipStream_t s);
 int expand_rows(const uint32_t *off, size_t n_rows, uint32_t *rows_out, hipStream_t s);
 int append_to_row(int dtype, uint32_t *off, uint32_t **col, void **val, size_t n_rows, size_t *nnz, size_t row, uint32_t column,
                   const void *value_host, hipStream_t s);

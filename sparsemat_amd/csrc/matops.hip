@@ -310,7 +310,7 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
         size_t nr = 0, nc = 0, nnz_b = 0;
         uint32_t *off_b = nullptr, *col_b = nullptr;
         void *val_b = nullptr;
-        SMH_TRY(assemble_triplets(dtype, products, p_row, p_col, p_val, nullptr, false, &nr, &nc, &nnz_b, &off_b, &col_b, &val_b, s));
+        SMH_TRY(assemble_triplets(dtype, products, p_row, p_col, p_val, nullptr, false, false, false, &nr, &nc, &nnz_b, &off_b, &col_b, &val_b, s));
         bufs.p.push_back(off_b); bufs.p.push_back(col_b); bufs.p.push_back(val_b);
         SMH_TRY(sort_rows(dtype, off_b, col_b, val_b, nr, nnz_b, (uint32_t)(nc ? nc - 1 : 0), s));
         uint32_t *loc = nullptr;
