@@ -19,6 +19,9 @@
 //     push quirk :75-76), the quirk's other two forms cannot occur for ascending (i, j).
 #include "internal.hpp"
 
+#include <chrono>
+#include <memory>
+#include <new>
 #include <vector>
 
 namespace smh {
@@ -128,11 +131,11 @@ k_prod_counts(const uint32_t *__restrict__ a_col, uint64_t a_nnz, const uint32_t
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_prod_row_sums(const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ cnt, uint64_t n_rows, uint64_t *__restrict__ row_sum) {
+k_prod_row_sums(const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ cnt, uint64_t n_rows, uint32_t *__restrict__ row_sum) {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t sum = 0;
         for (uint64_t q = a_off[r]; q < a_off[r + 1]; ++q) sum += cnt[q];
-        row_sum[r] = sum;
+        row_sum[r] = sum < 0xFFFFFFFFull ? (uint32_t)sum : 0xFFFFFFFFu;  // (saturated: refused by the host, a row must stay below 2^31)
     }
 }
 
@@ -233,6 +236,16 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
                   size_t *nnz_out, uint32_t **off_out, uint32_t **col_out, T **val_out, hipStream_t s) {
     const int dtype = sizeof(T) == 8 ? SMH_F64 : SMH_F32;
     static const uint64_t budget = getenv("SMH_PROD_BATCH") ? (uint64_t)atoll(getenv("SMH_PROD_BATCH")) : (uint64_t)1 << 27;
+    // SMH_PROD_TIMING=1: wall time of every stage on stderr (development aid)
+    static const bool timing = getenv("SMH_PROD_TIMING") && atoi(getenv("SMH_PROD_TIMING")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[prod] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     DevBufs bufs;
     *n_rows_out = *n_cols_out = *nnz_out = 0;
     *off_out = *col_out = nullptr;
@@ -253,7 +266,7 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
         as_col = c; as_val = v;
     }
     uint32_t *row_of = nullptr, *cnt = nullptr, *kept = nullptr, *dims = nullptr;
-    uint64_t *row_sum = nullptr;
+    uint32_t *row_sum = nullptr;
     SMH_TRY(bufs.alloc(&row_of, a_nnz));
     SMH_TRY(bufs.alloc(&cnt, a_nnz));
     SMH_TRY(bufs.alloc(&row_sum, a_rows));
@@ -266,14 +279,16 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
     SMH_HIP(hipGetLastError());
     if (a_rows) hipLaunchKernelGGL(k_prod_row_sums, dim3(mat_grid(a_rows)), dim3(kBlock), 0, s, a_off, cnt, (uint64_t)a_rows, row_sum);
     SMH_HIP(hipGetLastError());
-    std::vector<uint32_t> h_off(a_rows + 1);
-    std::vector<uint64_t> h_sum(a_rows);
-    SMH_HIP(hipMemcpyAsync(h_off.data(), a_off, (a_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (a_rows) SMH_HIP(hipMemcpyAsync(h_sum.data(), row_sum, a_rows * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    // products per row on the host (4 bytes a row, no zero-filled staging); the entry offsets of the few batch borders are
+    // fetched one by one below
+    std::unique_ptr<uint32_t[]> h_sum(new (std::nothrow) uint32_t[a_rows ? a_rows : 1]);
+    if (!h_sum) return fail(SMH_ERR_OOM, "host allocation failed");
+    if (a_rows) SMH_HIP(hipMemcpyAsync(h_sum.get(), row_sum, a_rows * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     SMH_HIP(hipStreamSynchronize(s));
     bufs.release(row_sum);
+    lap("sorted check, counts, row sums");
     // batches of whole rows with at most `budget` products (a longer single row goes alone)
-    struct Batch { size_t r0, r1; uint64_t products; };
+    struct Batch { size_t r0, r1; uint64_t products; uint32_t e0, e1; };
     std::vector<Batch> batches;
     uint64_t max_products = 0, max_entries = 0;
     for (size_t r = 0; r < a_rows;) {
@@ -282,9 +297,12 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
         while (r1 < a_rows && (r1 == r || p + h_sum[r1] <= budget)) p += h_sum[r1++];
         if (p >= 0x7FFFFFFFull) return fail(SMH_ERR_CAPACITY, "prod: row %zu alone generates %llu products", r, (unsigned long long)p);
         if (p) {
-            batches.push_back({r, r1, p});
+            Batch bt{r, r1, p, 0, 0};
+            SMH_HIP(hipMemcpy(&bt.e0, a_off + r, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            SMH_HIP(hipMemcpy(&bt.e1, a_off + r1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            batches.push_back(bt);
             if (p > max_products) max_products = p;
-            if ((uint64_t)(h_off[r1] - h_off[r]) > max_entries) max_entries = h_off[r1] - h_off[r];
+            if ((uint64_t)(bt.e1 - bt.e0) > max_entries) max_entries = bt.e1 - bt.e0;
         }
         r = r1;
     }
@@ -298,7 +316,7 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
     std::vector<Piece> pieces;
     uint64_t total = 0;
     for (const Batch &bt : batches) {
-        const uint64_t e0 = h_off[bt.r0], n_e = h_off[bt.r1] - e0;
+        const uint64_t e0 = bt.e0, n_e = bt.e1 - bt.e0;
         SMH_HIP(hipMemcpyAsync(base, cnt + e0, n_e * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         SMH_HIP(hipMemsetAsync(base + n_e, 0, sizeof(uint32_t), s));
         uint64_t products = 0;
@@ -307,12 +325,15 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
         hipLaunchKernelGGL((k_prod_expand<T>), dim3(mat_grid(n_e)), dim3(kBlock), 0, s, e0, n_e, row_of, a_off, as_col, as_val, b_off, b_col,
                            b_val, (uint64_t)b_rows, base, (uint32_t)bt.r0, p_row, p_col, p_val);
         SMH_HIP(hipGetLastError());
+        lap("expand");
         size_t nr = 0, nc = 0, nnz_b = 0;
         uint32_t *off_b = nullptr, *col_b = nullptr;
         void *val_b = nullptr;
         SMH_TRY(assemble_triplets(dtype, products, p_row, p_col, p_val, nullptr, false, false, false, &nr, &nc, &nnz_b, &off_b, &col_b, &val_b, s));
         bufs.p.push_back(off_b); bufs.p.push_back(col_b); bufs.p.push_back(val_b);
+        lap("fold (assembly)");
         SMH_TRY(sort_rows(dtype, off_b, col_b, val_b, nr, nnz_b, (uint32_t)(nc ? nc - 1 : 0), s));
+        lap("sort rows by column");
         uint32_t *loc = nullptr;
         SMH_TRY(bufs.alloc(&loc, nr + 1));
         hipLaunchKernelGGL((k_prod_count_kept<T>), dim3(mat_grid(nr)), dim3(kBlock), 0, s, off_b, (const T *)val_b, (uint64_t)nr, loc);
@@ -333,6 +354,7 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
         }
         SMH_HIP(hipStreamSynchronize(s));
         bufs.release(off_b); bufs.release(col_b); bufs.release(val_b); bufs.release(loc);
+        lap("drop zeros, reverse");
     }
     if (total >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "Maximum number of %u entries reached", 0xFFFFFFFFu);
     uint32_t h_dims[2] = {0, 0};
