@@ -81,6 +81,12 @@ def main():
         "expect_mvp": [[0, "34.544"]],                     # src/lib.rs:81
         "expect_get": [[0, 0, "7.12"]],                    # src/lib.rs:65
         "expect_row_dense": [[1, ["0", "2.24", "4.12"]]],  # src/lib.rs:95-98 ("0 2.24 4.12 ")
+        # src/lib.rs:85-90: sp.iter_col(2) after assemble_column_info() -- the index-list matrix lists a column's
+        # entries in INSERTION order ((1,2) was added before (2,2) before (0,2))
+        "expect_iter_col_insertion_order": [[2, [[1, "4.12"], [2, "2.12"], [0, "0.12"]]]],
+        # src/lib.rs:99-101: let mp = sp_crs.prod(&sp).unwrap(); assert_eq!(mp.get(1, 2), 17.9632)
+        # (row 1 of self = {2: 4.12, 1: 2.24}; column 2 of rhs in list order: 2.24*4.12 first, then 4.12*2.12)
+        "expect_prod_self": [[1, 2, "17.9632"]],
     })
 
     m = replay(assembly.CrsPushMatrix(np.float32), SEQ_CRS, f32_exact)
@@ -93,6 +99,9 @@ def main():
         "x": ["2.0", "4.8", "1.2", "3.4"],                 # src/lib.rs:149
         "expect_mvp": [[0, "20.16"]],                      # src/lib.rs:151
         "expect_density": [5, 16],                         # src/lib.rs:153
+        # src/lib.rs:137-142: sp_crs.iter_col(2) after assemble_column_info(): row-major storage order
+        "expect_iter_col": [[2, [[1, "4.12"], [2, "2.12"], [3, "1.12"]]]],
+        "expect_iter_row": [[0, [[1, "4.2"]]], [5, []]],   # src/lib.rs:144-148 (row 5 >= n_rows: empty)
     })
 
     m = replay(assembly.IndexListMatrix(np.float32), SEQ_INDEXLIST, f32_exact)

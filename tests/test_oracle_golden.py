@@ -143,6 +143,42 @@ def test_c_crs_replay_oracle_reproduces_reference_crs_and_container_restatement(
     assert list(rows) == [0, 0, 2, 2, 2] and list(col_ptr) == [0, 1, 3, 3, 5] and list(entries) == [2, 0, 4, 1, 3]
 
 
+def _crs_of(case):
+    crs = case["crs"]
+    return (crs["n_rows"], crs["n_cols"], np.array(crs["offset_rows"], np.uint32), np.array(crs["columns"], np.uint32),
+            _values(case))
+
+
+def test_prod_and_column_iterator_oracles_reproduce_reference_asserts():
+    """The reference's own assertions on the widened rows: `sp_crs.prod(&sp).unwrap().get(1, 2) == 17.9632`
+    (src/lib.rs:99-101) and the column iterators (src/lib.rs:85-90 index list: insertion order; :137-142 CRS: storage
+    order)."""
+    case = [c for c in CASES if c["name"] == "check_sparsemat_indexlist"][0]
+    a = _crs_of(case)
+    n_rows, n_cols, off, col, val, _ = oracle.prod(a, a)
+    for i, j, lit in case["expect_prod_self"]:
+        got = [val[q] for q in range(off[i], off[i + 1]) if col[q] == j]
+        assert got == [np.float32(float(lit))]
+    # the index-list matrix lists a column in insertion order: first appearance of (row, j) in the call sequence
+    for j, want in case["expect_iter_col_insertion_order"]:
+        seen = []
+        for _, r, c, _v in case["ops"]:
+            if c == j and r not in seen:
+                seen.append(r)
+        assert seen == [w[0] for w in want]
+        for r, lit in want:
+            q = [q for q in range(a[2][r], a[2][r + 1]) if a[3][q] == j][0]
+            assert a[4][q] == np.float32(float(lit))
+    case = [c for c in CASES if c["name"] == "check_sparsemat_crs"][0]
+    n_rows, n_cols, off, col, val = _crs_of(case)
+    rows, col_ptr, entries = oracle.column_info(off, col, n_cols)
+    for j, want in case["expect_iter_col"]:
+        got = [(int(rows[e]), val[e]) for e in entries[col_ptr[j]:col_ptr[j + 1]]]
+        assert got == [(r, np.float32(float(lit))) for r, lit in want]
+    num, den = case["expect_density"]
+    assert len(col) / (n_rows * n_cols) == num / den  # density(), sparsematrix.rs:237-241
+
+
 def test_c_prod_oracle_matches_the_loops_written_out():
     """orc_crs_prod_ops + orc_crs_replay against SparseMatrix::prod (sparsematrix.rs:186-210) written out in plain
     Python over the step-by-step CRS container: column lists of rhs in storage order, the row stably sorted,

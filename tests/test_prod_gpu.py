@@ -66,6 +66,24 @@ def test_prod_bit_exact(gpu, dtype, kind):
         assert np.all(np.diff(col[off[r]:off[r + 1]].astype(np.int64)) < 0)
 
 
+def test_reference_prod_kat_on_device(gpu):
+    """src/lib.rs:99-101: `let mp = sp_crs.prod(&sp).unwrap(); assert_eq!(mp.get(1, 2), 17.9632);` -- the matrix of
+    check_sparsemat_indexlist times itself, through the device."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")) as f:
+        case = [c for c in json.load(f)["cases"] if c["name"] == "check_sparsemat_indexlist"][0]
+    crs = case["crs"]
+    val = np.array([int(b, 16) for b in crs["values_bits"]], np.uint32).view(np.float32)
+    a = (crs["n_rows"], crs["n_cols"], np.array(crs["offset_rows"], np.uint32), np.array(crs["columns"], np.uint32), val)
+    mp = device(a).prod(device(a))
+    same_crs(mp, oracle.prod(a, a))
+    off, col, v = mp.raw_parts()
+    for i, j, lit in case["expect_prod_self"]:
+        got = [v[q] for q in range(off[i], off[i + 1]) if col[q] == j]   # mp.get(i, j)
+        assert got == [np.float32(float(lit))]
+
+
 def test_prod_in_several_batches(gpu):
     """The products of a batch of rows are bounded (SMH_PROD_BATCH, read once per process, default 2^27): with a
     budget of 500 the same product goes through ~20 batches, in a child process, and is still bit-exact."""

@@ -44,6 +44,14 @@ def test_reference_crs_kat_stream_on_device(gpu):
     y = m.mvp(x, variant="stream")
     for i, lit in case["expect_mvp"]:
         assert y[i] == np.float32(float(lit))
+    # src/lib.rs:137-148: sp_crs.iter_col(2) after assemble_column_info(), iter_row(0), iter_row(5); :153 density
+    info = m.column_info()
+    for j, want in case["expect_iter_col"]:
+        assert m.iter_col(j, info) == [(r, float(np.float32(float(lit)))) for r, lit in want]
+    for i, want in case["expect_iter_row"]:
+        assert [(int(c), float(v)) for c, v in m.iter_row(i)] == [(c, float(np.float32(float(lit)))) for c, lit in want]
+    num, den = case["expect_density"]
+    assert m.density() == num / den
 
 
 def stream(rng, n, n_r, n_c, dtype, head):
