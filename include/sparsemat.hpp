@@ -295,6 +295,12 @@ class ConjugateGradient {
         detail::check(smh_cg_solve_vec(mat.handle(), b.handle(), x.handle(), tol_, iter_max_, SMH_SPMV_AUTO, 0,
                                        &iterations_, &r_norm_squared_));
     }
+    // Jacobi-preconditioned variant -- an extension, not in the reference: z = r / diag(A); host vectors
+    template <typename T>
+    void solve_jacobi(const SparseMatCRS<T> &mat, const std::vector<T> &b, std::vector<T> &x) {
+        detail::check(smh_pcg_jacobi_solve(mat.handle(), b.data(), b.size(), x.data(), x.size(), tol_, iter_max_, SMH_SPMV_AUTO,
+                                           &iterations_, &r_norm_squared_));
+    }
     // the same solve on a row-partitioned matrix (M = SparseMatPar): host vectors, x updated in place
     template <typename T>
     void solve(const SparseMatPar<T> &mat, const std::vector<T> &b, std::vector<T> &x) {

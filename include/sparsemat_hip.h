@@ -290,6 +290,15 @@ int smh_cg_solve(smh_crs *m, const void *b_host, size_t b_len, void *x_host_inou
 int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_t iter_max,
                      int variant, size_t check_every, size_t *iters_out, double *rr_out);
 
+/* Jacobi-preconditioned CG -- an EXTENSION (the reference has no
+ * preconditioner): the recurrence of ConjugateGradient::solve with z = r / diag(A), diag_i =
+ * get(i, i) (first match in storage order); same guards, statuses, stop rule (on r.r, tested
+ * before the beta update) and outputs as smh_cg_solve.  A zero or absent diagonal entry is
+ * SMH_ERR_INVALID.  Host vectors; x is updated in place. */
+int smh_pcg_jacobi_solve(smh_crs *m, const void *b_host, size_t b_len, void *x_host_inout,
+                         size_t x_len, double tol, size_t iter_max, int variant, size_t *iters_out,
+                         double *rr_out);
+
 /* ---- SparseMatPar<SparseMatCRS<T,u32>> (sparsemat_par.rs:12-35, 86-140), one process ------
  * n_blocks row blocks of R = n_rows / n_blocks rows (with_sub_matrices :20-28; integer
  * division :21), block b = global rows [b R, (b+1) R) with local row ids and GLOBAL column ids,

@@ -86,6 +86,8 @@ def _declare(L):
         getattr(L, "orc_norm_" + suf).restype = C.c_double
         getattr(L, "orc_cg_" + suf).argtypes = [_sz, _sz, _u32p, _u32p, fp, fp, _sz, fp, _sz,
                                                  C.c_double, _sz, C.POINTER(_sz), _f64p]
+        getattr(L, "orc_pcg_jacobi_" + suf).argtypes = [_sz, _sz, _u32p, _u32p, fp, fp, _sz, fp, _sz,
+                                                         C.c_double, _sz, C.POINTER(_sz), _f64p]
         getattr(L, "orc_gen_x_" + suf).argtypes = [C.c_uint64, _sz, _sz, fp]
         getattr(L, "orc_gen_x_" + suf).restype = None
         getattr(L, "orc_gen_fixed_" + suf).argtypes = [C.c_uint64, C.c_int, _sz, C.c_uint32, _sz,
@@ -259,6 +261,21 @@ def cg(n_rows, n_cols, offset_rows, columns, values, b, x0, tol=1e-12, iter_max=
                                          _p(b, fp), len(b), _p(x, fp), len(x), tol, iter_max,
                                          C.byref(iters), C.byref(rr))
     _check(rc)
+    return x, iters.value, rr.value
+
+
+def pcg_jacobi(n_rows, n_cols, offset_rows, columns, values, b, x0, tol=1e-12, iter_max=10_000):
+    """Jacobi-preconditioned CG -- an EXTENSION, not in the reference (SURVEY 8f rank 3): ConjugateGradient::solve
+    with z = r / diag(A).  Returns (x, iters, rr); a zero / absent diagonal raises OraclePanic(ORC_ERR_ZERO_DIAGONAL)."""
+    values = np.ascontiguousarray(values)
+    suf, fp = _suf(values.dtype)
+    off, col = _c(offset_rows, np.uint32), _c(columns, np.uint32)
+    b = _c(b, values.dtype)
+    x = np.array(x0, dtype=values.dtype, copy=True)
+    iters, rr = _sz(0), C.c_double(0.0)
+    _check(getattr(lib(), "orc_pcg_jacobi_" + suf)(n_rows, n_cols, _p(off, _u32p), _p(col, _u32p), _p(values, fp),
+                                                   _p(b, fp), len(b), _p(x, fp), len(x), tol, iter_max,
+                                                   C.byref(iters), C.byref(rr)))
     return x, iters.value, rr.value
 
 

@@ -586,3 +586,66 @@ DEF_CRS_REPLAY(f64, double)
 
 DEF_PROD(f32, float)
 DEF_PROD(f64, double)
+
+/* Jacobi-preconditioned CG -- an EXTENSION: the reference has no preconditioner, so there is
+ * nothing of its own to pin this against; it is ConjugateGradient::solve (linearsolver.rs:27-61) with the same guards,
+ * the same stop rule (sqrt(f64(r.r)) < tol, tested after the update of r and before beta) and the same arithmetic
+ * conventions (sequential left folds, one rounding per operation), plus z = r / diag(A) with diag_i = get(i, i) (first
+ * match in storage order, sparsemat_crs.rs:54-67,136-142):
+ *   r = b - A x; p = z; rz = r.z;  loop: alpha = rz / (p.Ap); x += p*alpha; r -= Ap*alpha; rr = r.r; stop test;
+ *   z = r / d; rz' = r.z; beta = rz' / rz; p = p*beta + z.
+ * A zero or absent diagonal entry is ORC_ERR_ZERO_DIAGONAL. */
+#define DEF_PCG(SUF, T)                                                                     \
+    int orc_pcg_jacobi_##SUF(size_t n_rows, size_t n_cols, const uint32_t *offset_rows,      \
+                             const uint32_t *columns, const T *values, const T *b,           \
+                             size_t b_len, T *x, size_t x_len, double tol, size_t iter_max,  \
+                             size_t *iters_out, double *rr_out) {                            \
+        if (n_rows != n_cols) return ORC_ERR_NOT_SQUARE;                                     \
+        if (n_rows != b_len || n_rows != x_len) return ORC_ERR_SIZE_MISMATCH;                \
+        size_t n = n_rows;                                                                   \
+        T *r = (T *)malloc((n ? n : 1) * sizeof(T));                                         \
+        T *p = (T *)malloc((n ? n : 1) * sizeof(T));                                         \
+        T *ap = (T *)malloc((n ? n : 1) * sizeof(T));                                        \
+        T *d = (T *)malloc((n ? n : 1) * sizeof(T));                                         \
+        int rc = ORC_OK;                                                                     \
+        for (size_t i = 0; i < n && rc == ORC_OK; ++i) {                                     \
+            d[i] = (T)0;                                                                     \
+            for (size_t q = offset_rows[i]; q < offset_rows[i + 1]; ++q)                     \
+                if (columns[q] == i) { d[i] = values[q]; break; }                            \
+            if (d[i] == (T)0) rc = ORC_ERR_ZERO_DIAGONAL;                                    \
+        }                                                                                    \
+        if (rc == ORC_OK) rc = orc_spmv_##SUF(n, offset_rows, columns, values, x, x_len, ap); \
+        size_t iters = 0;                                                                    \
+        T rr = (T)0;                                                                         \
+        if (rc == ORC_OK) {                                                                  \
+            T rz = (T)0;                                                                     \
+            for (size_t i = 0; i < n; ++i) r[i] = b[i] - ap[i];                              \
+            rr = orc_norm_squared_##SUF(r, n);                                               \
+            for (size_t i = 0; i < n; ++i) { p[i] = r[i] / d[i]; T t = r[i] * p[i]; rz = rz + t; } \
+            for (size_t k = 0; k < iter_max; ++k) {                                          \
+                ++iters;                                                                     \
+                rc = orc_spmv_##SUF(n, offset_rows, columns, values, p, n, ap);              \
+                if (rc != ORC_OK) break;                                                     \
+                T alpha = rz / orc_dot_##SUF(p, ap, n);                                      \
+                orc_vec_axpy_##SUF(x, alpha, p, n);                                          \
+                for (size_t i = 0; i < n; ++i) {                                             \
+                    T t = ap[i] * alpha;                                                     \
+                    r[i] = r[i] - t;                                                         \
+                }                                                                            \
+                rr = orc_norm_squared_##SUF(r, n);                                           \
+                if (sqrt((double)rr) < tol) break;                                           \
+                T rz_new = (T)0;                                                             \
+                for (size_t i = 0; i < n; ++i) { T z = r[i] / d[i]; T t = r[i] * z; rz_new = rz_new + t; } \
+                T beta = rz_new / rz;                                                        \
+                rz = rz_new;                                                                 \
+                for (size_t i = 0; i < n; ++i) { T z = r[i] / d[i]; T t = p[i] * beta; p[i] = t + z; } \
+            }                                                                                \
+        }                                                                                    \
+        if (iters_out) *iters_out = iters;                                                   \
+        if (rr_out) *rr_out = (double)rr;                                                    \
+        free(r); free(p); free(ap); free(d);                                                 \
+        return rc;                                                                           \
+    }
+
+DEF_PCG(f32, float)
+DEF_PCG(f64, double)

@@ -32,6 +32,7 @@ extern "C" {
 #define ORC_ERR_NOT_SQUARE 2    /* linearsolver.rs:30-32 "Matrix is not symmetric" */
 #define ORC_ERR_SIZE_MISMATCH 3 /* linearsolver.rs:33-36 / densevec.rs:52-54,61-63 */
 #define ORC_ERR_CAPACITY 4      /* sparsemat_crs.rs:82-84 "Maximum number of {} entries reached" */
+#define ORC_ERR_ZERO_DIAGONAL 5 /* the Jacobi extension only: get(i, i) == 0 */
 
 /* ---- SpMV: sparsematrix.rs:146-158 over sparsemat_crs.rs:102-110 ------- */
 int orc_spmv_f32(size_t n_rows, const uint32_t *offset_rows, const uint32_t *columns,
@@ -89,6 +90,16 @@ int orc_cg_f64(size_t n_rows, size_t n_cols, const uint32_t *offset_rows,
                const uint32_t *columns, const double *values, const double *b, size_t b_len,
                double *x, size_t x_len, double tol, size_t iter_max, size_t *iters_out,
                double *rr_out);
+/* Jacobi-preconditioned CG: an EXTENSION (not in the reference) -- the recurrence above with
+ * z = r / diag(A), diag_i = get(i, i); same guards, stop rule and arithmetic conventions. */
+int orc_pcg_jacobi_f32(size_t n_rows, size_t n_cols, const uint32_t *offset_rows,
+                       const uint32_t *columns, const float *values, const float *b, size_t b_len,
+                       float *x, size_t x_len, double tol, size_t iter_max, size_t *iters_out,
+                       double *rr_out);
+int orc_pcg_jacobi_f64(size_t n_rows, size_t n_cols, const uint32_t *offset_rows,
+                       const uint32_t *columns, const double *values, const double *b, size_t b_len,
+                       double *x, size_t x_len, double tol, size_t iter_max, size_t *iters_out,
+                       double *rr_out);
 
 /* ---- SparseMatPar row-block arithmetic: sparsemat_par.rs:20-35 --------- */
 /* R = max_n_rows / n_blocks (:21).  block/row of a global row as the

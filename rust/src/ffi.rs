@@ -26,6 +26,10 @@ extern "C" {
     pub fn smh_cg_solve(m: *mut smh_crs, b_host: *const c_void, b_len: usize, x_host_inout: *mut c_void,
                         x_len: usize, tol: c_double, iter_max: usize, variant: c_int,
                         iters_out: *mut usize, rr_out: *mut c_double) -> c_int;
+    // extension (not in the reference): Jacobi-preconditioned CG, same contract as smh_cg_solve
+    pub fn smh_pcg_jacobi_solve(m: *mut smh_crs, b_host: *const c_void, b_len: usize, x_host_inout: *mut c_void,
+                                x_len: usize, tol: c_double, iter_max: usize, variant: c_int,
+                                iters_out: *mut usize, rr_out: *mut c_double) -> c_int;
     pub fn smh_crs_inner_prod(m: *mut smh_crs, lhs_host: *const c_void, lhs_len: usize, rhs_host: *const c_void,
                               rhs_len: usize, variant: c_int, out: *mut c_double) -> c_int;
     // add_to (ops[k] == 0 / ops null) or set (ops[k] == 1) stream -> the CRS `to_crs()` would return

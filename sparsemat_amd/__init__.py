@@ -12,7 +12,7 @@ needs a HIP device.
 from ._lib import SparseMatPanic, lib, LIB_PATH  # noqa: F401
 from .densevec import DenseVec  # noqa: F401
 from .sparsemat_crs import SparseMatCRS  # noqa: F401
-from .linearsolver import ConjugateGradient  # noqa: F401
+from .linearsolver import ConjugateGradient, JacobiConjugateGradient  # noqa: F401
 from . import sparsemat_par, synth  # noqa: F401
 from .sparsemat_par import SparseMatPar  # noqa: F401
 from .sparsemat_par_local import SparseMatParLocal  # noqa: F401

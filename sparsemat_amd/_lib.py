@@ -100,6 +100,8 @@ SIGNATURES = {
                             C.POINTER(C.c_double)]),
     "smh_cg_solve_vec": (_int, [_vp, _vp, _vp, C.c_double, _sz, _int, _sz, C.POINTER(_sz),
                                 C.POINTER(C.c_double)]),
+    "smh_pcg_jacobi_solve": (_int, [_vp, _vp, _sz, _vp, _sz, C.c_double, _sz, _int, C.POINTER(_sz),
+                                    C.POINTER(C.c_double)]),
     "smh_par_create": (_int, [_int, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
     "smh_par_destroy": (_int, [_vp]),
     "smh_par_n_blocks": (_sz, [_vp]),

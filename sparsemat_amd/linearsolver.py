@@ -58,6 +58,29 @@ class ConjugateGradient:
         return x
 
 
+class JacobiConjugateGradient:
+    """Jacobi-preconditioned CG -- an EXTENSION (the reference has no preconditioner): the
+    recurrence of ``ConjugateGradient::solve`` with z = r / diag(A); same guards, stop rule and panics
+    (``smh_pcg_jacobi_solve``).  Host vectors; x (numpy array of the matrix dtype) is updated in place."""
+
+    def __init__(self, tol=1e-12, iter_max=10_000, variant="auto"):
+        self.tol = float(tol)
+        self.iter_max = int(iter_max)
+        self.variant = variant
+        self.iterations = None
+        self.r_norm_squared = None
+
+    def solve(self, mat, b, x):
+        if not (isinstance(x, np.ndarray) and x.dtype == mat.dtype and x.flags.c_contiguous):
+            raise TypeError("x must be a contiguous numpy array of the matrix dtype (updated in place)")
+        bb = np.ascontiguousarray(b, dtype=mat.dtype)
+        iters, rr = C.c_size_t(), C.c_double()
+        check(lib().smh_pcg_jacobi_solve(mat._h, bb.ctypes.data if bb.size else None, bb.size, x.ctypes.data if x.size else None,
+                                         x.size, self.tol, self.iter_max, _lib.VARIANTS[self.variant], C.byref(iters), C.byref(rr)))
+        self.iterations, self.r_norm_squared = iters.value, rr.value
+        return x
+
+
 class HipVectorOps:
     """DenseVec kernels of the library on torch CUDA tensors, scalars read from device memory."""
 

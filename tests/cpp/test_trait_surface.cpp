@@ -122,6 +122,11 @@ int main() {
         cg.solve(a, b, x);
         CHECK(std::floor(x.get(0) * 10000.0) / 10000.0 == 0.0909);
         CHECK(cg.iterations() == 2);
+        // the Jacobi-preconditioned extension reaches the same solution
+        std::vector<double> bj = {1.0, 2.0}, xj = {2.0, 1.0};
+        ConjugateGradient pcg;
+        pcg.solve_jacobi(a, bj, xj);
+        CHECK(std::fabs(xj[0] - 1.0 / 11.0) < 1e-12 && std::fabs(xj[1] - 7.0 / 11.0) < 1e-12);
     }
     // DenseVec operators (densevec.rs:76-140)
     {
