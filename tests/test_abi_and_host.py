@@ -71,8 +71,9 @@ def test_compute_fails_loudly_without_a_device():
 
 
 def test_product_never_uses_the_oracle():
-    """oracle/ is test infrastructure: nothing under sparsemat_amd/ or include/ may name it."""
-    for base in ("sparsemat_amd", "include"):
+    """oracle/ is test infrastructure: nothing under sparsemat_amd/, include/, rust/ or tools/ may name it (the timing
+    scripts that run the oracle as checker / CPU baseline live under tests/bench/)."""
+    for base in ("sparsemat_amd", "include", "rust", "tools"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
             for fn in files:
                 if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
