@@ -17,6 +17,13 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")
 
 
+def sm_device_count():
+    import ctypes as C
+    n = C.c_int(0)
+    _lib.check(sm.lib().smh_device_count(C.byref(n)))
+    return n.value
+
+
 def test_reference_par_kat(gpu):
     """src/lib.rs:180-202: SparseMatPar::with_sub_matrices(4, 16), the add_to/set calls of the other container tests,
     assert_eq!(mvp.get(0), 34.544)."""
@@ -34,6 +41,10 @@ def test_reference_par_kat(gpu):
     for i, lit in case["expect_mvp"]:
         assert y[i] == np.float32(float(lit))
     assert np.all(y[crs["n_rows"]:] == 0)
+    # device_ids = NULL: block b on device b mod device count
+    auto = sm.SparseMatParLocal.with_sub_matrices(par["n_blocks"], n_rows, crs["n_cols"], off, crs["columns"], val)
+    assert [auto.block(b)[2] for b in range(4)] == [b % max(1, sm_device_count()) for b in range(4)]
+    assert auto.mvp(x, variant="stream").tobytes() == y.tobytes()
     # get_block_and_row_id (sparsemat_par.rs:31-35); beyond n_blocks * R the LAST block is taken (the reference clamps to
     # n_blocks and panics)
     assert m.get_block_and_row_id(0) == (0, 0) and m.get_block_and_row_id(7) == (1, 3) and m.get_block_and_row_id(15) == (3, 3)
