@@ -224,6 +224,14 @@ class SparseMatIndexList {
                                        ops_.data(), &m.h_));
         return m;
     }
+    // The same calls made on a SparseMatCRS directly (get_mut sparsemat_crs.rs:143-149 -> push :71-92 inserts at the
+    // START of the row, first-push quirk included): the matrix src/lib.rs:114-154 builds.  smh_crs_replay.
+    SparseMatCRS<T> as_direct_crs() const {
+        SparseMatCRS<T> m;
+        detail::check(smh_crs_replay(detail::dtype_of<T>::value, vals_.size(), rows_.data(), cols_.data(), vals_.data(),
+                                     ops_.data(), &m.h_));
+        return m;
+    }
 
   private:
     void record(size_t i, size_t j, T val, uint8_t op) {

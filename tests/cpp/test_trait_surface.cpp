@@ -64,6 +64,30 @@ int main() {
         CHECK((col == std::vector<uint32_t>{0, 1, 2, 1, 2, 2}));
         CHECK((val == std::vector<float>{7.12f, 4.2f, 0.12f, 2.24f, 4.12f, 2.12f}));
     }
+    // check_sparsemat_crs (src/lib.rs:114-154): add_to on a SparseMatCRS itself -- push prepends to the row
+    {
+        SparseMatIndexList<float> calls;     // (records the calls; as_direct_crs() applies them to a SparseMatCRS)
+        calls.add_to(0, 1, 4.2f);
+        calls.add_to(2, 2, 2.12f);
+        calls.add_to(1, 2, 4.12f);
+        calls.add_to(3, 2, 1.12f);
+        calls.add_to(3, 3, 5.12f);
+        auto sp_crs = calls.as_direct_crs();
+        std::vector<uint32_t> off, col;
+        std::vector<float> val;
+        sp_crs.raw_parts(off, col, val);
+        CHECK((off == std::vector<uint32_t>{0, 1, 2, 3, 5}));
+        CHECK((col == std::vector<uint32_t>{1, 2, 2, 3, 2}));     // lib.rs:122-128: (3,3) before (3,2)
+        CHECK((val == std::vector<float>{4.2f, 4.12f, 2.12f, 5.12f, 1.12f}));
+        std::vector<uint32_t> rows, col_ptr, entries;              // lib.rs:137-142: iter_col(2) = (1,4.12),(2,2.12),(3,1.12)
+        sp_crs.column_info(rows, col_ptr, entries);
+        std::vector<std::pair<uint32_t, float>> col2;
+        for (uint32_t e = col_ptr[2]; e < col_ptr[3]; ++e) col2.push_back({rows[entries[e]], val[entries[e]]});
+        CHECK((col2 == std::vector<std::pair<uint32_t, float>>{{1, 4.12f}, {2, 2.12f}, {3, 1.12f}}));
+        auto y = sp_crs.mvp(std::vector<float>{2.0f, 4.8f, 1.2f, 3.4f}, SMH_SPMV_STREAM);
+        CHECK(y[0] == 20.16f);               // assert_eq!(mvp.get(0), 20.16)
+        CHECK((double)sp_crs.n_non_zero_entries() / (double)(sp_crs.n_rows() * sp_crs.n_cols()) == 5.0 / 16.0);  // density()
+    }
     // SparseMatrix::transpose (sparsematrix.rs:174-184) + ColumnIter tables (sparsemat_crs.rs:180-204)
     {
         auto a = SparseMatCRS<float>::from_raw_parts(3, 4, {0, 2, 2, 5}, {1, 3, 0, 3, 1}, {1.0f, 2.0f, 3.0f, 4.0f, 5.0f});
