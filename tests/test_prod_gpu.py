@@ -179,3 +179,36 @@ def test_is_symmetric_and_is_sorted(gpu):
     assert not nan.is_symmetric()   # NaN != NaN
     empty = sm.SparseMatCRS.from_raw_parts(3, 3, np.zeros(4, np.uint32), np.zeros(0, np.uint32), np.zeros(0, f))
     assert empty.is_symmetric() and empty.is_sorted()
+
+
+def test_new_entry_points_reject_bad_arguments(gpu):
+    """NULL handles / outputs and mismatched value types come back as statuses, never as crashes."""
+    import ctypes as C
+    L = sm.lib()
+    h = C.c_void_p()
+    out_i = C.c_int()
+    assert L.smh_crs_transpose(None, C.byref(h)) == _lib.SMH_ERR_INVALID
+    assert L.smh_crs_prod(None, None, C.byref(h)) == _lib.SMH_ERR_INVALID
+    assert L.smh_crs_is_symmetric(None, C.byref(out_i)) == _lib.SMH_ERR_INVALID
+    assert L.smh_crs_is_sorted(None, C.byref(out_i)) == _lib.SMH_ERR_INVALID
+    assert L.smh_crs_column_info(None, None, None, None) == _lib.SMH_ERR_INVALID
+    assert L.smh_crs_replay(0, 3, None, None, None, None, C.byref(h)) == _lib.SMH_ERR_INVALID
+    assert L.smh_par_create(0, 2, None, 4, 4, None, None, None, 1, C.byref(h)) == _lib.SMH_ERR_INVALID
+    assert L.smh_par_spmv(None, None, 0, None, 0) == _lib.SMH_ERR_INVALID
+    assert L.smh_par_cg_solve(None, None, 0, None, 0, 1e-6, 10, 0, None, None) == _lib.SMH_ERR_INVALID
+    assert L.smh_pcg_jacobi_solve(None, None, 0, None, 0, 1e-6, 10, 0, None, None) == _lib.SMH_ERR_INVALID
+    assert L.smh_par_destroy(None) == 0 and L.smh_par_n_blocks(None) == 0
+    a32 = device((2, 2, np.array([0, 1, 2], np.uint32), np.array([0, 1], np.uint32), np.array([1.0, 2.0], np.float32)))
+    a64 = device((2, 2, np.array([0, 1, 2], np.uint32), np.array([0, 1], np.uint32), np.array([1.0, 2.0], np.float64)))
+    with pytest.raises(sm.SparseMatPanic) as e:
+        a32.prod(a64)
+    assert e.value.status == _lib.SMH_ERR_INVALID
+    # an empty left operand, an operand without entries
+    z = device((2, 2, np.zeros(3, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32)))
+    c = z.prod(a32)
+    assert (c.n_rows(), c.n_cols(), c.n_non_zero_entries()) == (0, 0, 0)
+    c = a32.prod(z)
+    assert (c.n_rows(), c.n_cols(), c.n_non_zero_entries()) == (0, 0, 0)
+    assert z.is_symmetric() and z.is_sorted()
+    t = z.transpose()
+    assert (t.n_rows(), t.n_cols(), t.n_non_zero_entries()) == (0, 0, 0)
