@@ -387,8 +387,13 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
+    // experiment knob: unused dynamic LDS per block, to cap the blocks a CU holds at once (0: whatever fits).  Unlike the
+    // element-wise kernels (fewer, fatter grids stream faster) this kernel wants every block it can get: 512^3 Laplacian,
+    // one box, 1.54 ms unconstrained, 1.64 / 2.10 / 2.62 / 3.64 ms with 8 / 16 / 24 / 36 KiB of padding
+    // (profiles/r01_k1s_blocks_per_cu.log)
+    static const unsigned lds_pad = getenv("SMH_STREAM_LDS_PAD") ? (unsigned)atoi(getenv("SMH_STREAM_LDS_PAD")) : 0u;
 #define SMH_ST_LAUNCH(XW, R, D, M, C)                                                                                    \
-    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M, kStreamCap, C>), grid, block, 0, s, off, col, val, x, y,    \
+    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M, kStreamCap, C>), grid, block, lds_pad, s, off, col, val, x, y, \
                        (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin)
 #define SMH_ST_PICK(XW, R, C)                                                     \
     do {                                                                          \
