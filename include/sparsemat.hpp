@@ -125,6 +125,10 @@ class SparseMatCRS {
     size_t n_cols() const { return smh_crs_n_cols(h_); }              // :128-130
     size_t n_non_zero_entries() const { return smh_crs_nnz(h_); }     // :132-134
     bool empty() const { return n_rows() == 0; }                      // sparsematrix.rs:119-121
+    double density() const {                                           // sparsematrix.rs:237-241
+        return (double)n_non_zero_entries() / (double)(n_rows() * n_cols());
+    }
+    double sparsity() const { return 1.0 - density(); }                // sparsematrix.rs:244-246
     void scale(T a) { detail::check(smh_crs_scale(h_, (double)a)); }  // sparsemat_crs.rs:153-157
 
     // SparseMatrix::mvp (sparsematrix.rs:146-158): returns a NEW vector with dim == n_rows

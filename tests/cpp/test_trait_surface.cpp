@@ -86,7 +86,8 @@ int main() {
         CHECK((col2 == std::vector<std::pair<uint32_t, float>>{{1, 4.12f}, {2, 2.12f}, {3, 1.12f}}));
         auto y = sp_crs.mvp(std::vector<float>{2.0f, 4.8f, 1.2f, 3.4f}, SMH_SPMV_STREAM);
         CHECK(y[0] == 20.16f);               // assert_eq!(mvp.get(0), 20.16)
-        CHECK((double)sp_crs.n_non_zero_entries() / (double)(sp_crs.n_rows() * sp_crs.n_cols()) == 5.0 / 16.0);  // density()
+        CHECK(sp_crs.density() == 5.0 / 16.0);   // assert_eq!(sp_crs.density(), 5.0 / 16.0), lib.rs:153
+        CHECK(sp_crs.sparsity() == 1.0 - 5.0 / 16.0);
     }
     // SparseMatrix::transpose (sparsematrix.rs:174-184) + ColumnIter tables (sparsemat_crs.rs:180-204)
     {
