@@ -26,6 +26,13 @@
 // one 3 radix passes + the row replay (2.3 ms).
 // Also here: Sortable::sort_row (sparsemat_crs.rs:163-172; slice::sort_by is stable) for all rows at once --
 // one segmented stable sort by column over the CRS offsets.
+// The same pipeline serves streams replayed on a SparseMatCRS itself (smh_crs_replay, transpose, prod: `reverse_rows`
+// emits every row's list backwards because push inserts at the row's start, sparsemat_crs.rs:85-87; the container's
+// first-push quirk is resolved by the caller from the first two operations, capi.hip), with two shortcuts for
+// transpose: `all_set` (no ops array) and `repeats_adjacent` (no (row, column) pair repeats -> the sorted operations
+// ARE the entries: k_asm_direct_emit).  Row expansion (k_expand_rows), the column tables of
+// ColumnIter::assemble_column_info (one stable sort of the entry indices by column) and append_to_row (the twin entry
+// of the quirk) live here too.
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
