@@ -173,36 +173,54 @@ k_prod_expand(uint64_t e0, uint64_t n_e, const uint32_t *__restrict__ row_of, co
     }
 }
 
-// kept sums per row (sum != 0), then the compaction: ascending row reversed, largest kept row / column recorded
+// kept sums (sum != 0, sparsematrix.rs:203): entry-parallel.  flag[k] = entry k is kept (flag[nnz] = 0); its exclusive
+// scan `rank` numbers the kept entries in (row, ascending column) order, so rank[off[r]] is row r's offset in the compacted
+// arrays and rank[off[r + 1]] - rank[off[r]] its kept count; a kept entry of row r goes to the MIRRORED place inside the row's
+// range -- descending columns, what ascending `set` calls leave in a SparseMatCRS (push prepends, sparsemat_crs.rs:85-87).
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_prod_count_kept(const uint32_t *__restrict__ off, const T *__restrict__ val, uint64_t n_rows, uint32_t *__restrict__ kept) {
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t c = 0;
-        for (uint64_t q = off[r]; q < off[r + 1]; ++q) c += val[q] != T(0) ? 1u : 0u;
-        kept[r] = c;
-    }
+k_prod_flags(const T *__restrict__ val, uint64_t nnz, uint32_t *__restrict__ flag) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= nnz; k += (uint64_t)gridDim.x * blockDim.x)
+        flag[k] = (k < nnz && val[k] != T(0)) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_prod_row_kept(const uint32_t *__restrict__ off, const uint32_t *__restrict__ rank, uint64_t n_rows, uint32_t *__restrict__ kept) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x)
+        kept[r] = rank[off[r + 1]] - rank[off[r]];
 }
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_prod_compact(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val, uint64_t n_rows,
-               const uint32_t *__restrict__ out_off, uint32_t r0, uint32_t *__restrict__ out_col, T *__restrict__ out_val,
+               const uint32_t *__restrict__ rank, uint32_t r0, uint32_t *__restrict__ out_col, T *__restrict__ out_val,
                uint32_t *dims /* [0] largest kept row + 1, [1] largest kept column + 1 */) {
+    __shared__ uint32_t s_off[kBlock + 1];
     uint32_t mr = 0, mc = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t w = out_off[r];
-        const uint64_t a = off[r], b = off[r + 1];
-        for (uint64_t q = b; q > a; --q) {  // descending columns
-            const T v = val[q - 1];
-            if (v != T(0)) {
-                const uint32_t c = col[q - 1];
-                out_col[w] = c;
-                out_val[w] = v;
-                ++w;
-                mc = max(mc, c + 1u);
-                mr = (uint32_t)r + r0 + 1u;
+    const uint64_t n_groups = (n_rows + kBlock - 1) / kBlock;
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t g0 = g * kBlock, g1 = g0 + kBlock < n_rows ? g0 + kBlock : n_rows;
+        const uint32_t nr = (uint32_t)(g1 - g0);
+        __syncthreads();
+        if (threadIdx.x <= nr) s_off[threadIdx.x] = off[g0 + threadIdx.x];
+        if (threadIdx.x == 0 && nr == (uint32_t)kBlock) s_off[kBlock] = off[g1];
+        __syncthreads();
+        const uint32_t base = s_off[0], total = s_off[nr] - base;
+        for (uint32_t p = threadIdx.x; p < total; p += kBlock) {
+            const uint64_t e = (uint64_t)base + p;
+            const T v = val[e];
+            if (!(v != T(0))) continue;  // same test as the flags (NaN != 0: kept; -0 == 0: dropped)
+            uint32_t lo = 0, hi = nr;  // last row with s_off[row] - base <= p
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_off[mid] - base <= p) lo = mid; else hi = mid;
             }
+            const uint32_t c = col[e];
+            const uint64_t w = (uint64_t)rank[s_off[lo]] + rank[s_off[lo + 1]] - 1u - rank[e];
+            out_col[w] = c;
+            out_val[w] = v;
+            mc = max(mc, c + 1u);
+            mr = max(mr, (uint32_t)(g0 + lo) + r0 + 1u);
         }
     }
 #pragma unroll
@@ -334,26 +352,26 @@ static int prod_t(const uint32_t *a_off, const uint32_t *a_col, const T *a_val, 
         lap("fold (assembly)");
         SMH_TRY(sort_rows(dtype, off_b, col_b, val_b, nr, nnz_b, (uint32_t)(nc ? nc - 1 : 0), s));
         lap("sort rows by column");
-        uint32_t *loc = nullptr;
-        SMH_TRY(bufs.alloc(&loc, nr + 1));
-        hipLaunchKernelGGL((k_prod_count_kept<T>), dim3(mat_grid(nr)), dim3(kBlock), 0, s, off_b, (const T *)val_b, (uint64_t)nr, loc);
+        uint32_t *rank = nullptr;
+        SMH_TRY(bufs.alloc(&rank, nnz_b + 1));
+        hipLaunchKernelGGL((k_prod_flags<T>), dim3(mat_grid(nnz_b + 1)), dim3(kBlock), 0, s, (const T *)val_b, (uint64_t)nnz_b, rank);
         SMH_HIP(hipGetLastError());
-        SMH_HIP(hipMemsetAsync(loc + nr, 0, sizeof(uint32_t), s));
-        SMH_HIP(hipMemcpyAsync(kept + bt.r0, loc, nr * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         uint64_t n_kept = 0;
-        SMH_TRY(device_exclusive_scan_u32(loc, nr + 1, s, &n_kept));
+        SMH_TRY(device_exclusive_scan_u32(rank, nnz_b + 1, s, &n_kept));
+        hipLaunchKernelGGL(k_prod_row_kept, dim3(mat_grid(nr)), dim3(kBlock), 0, s, off_b, rank, (uint64_t)nr, kept + bt.r0);
+        SMH_HIP(hipGetLastError());
         Piece pc{nullptr, nullptr, n_kept};
         if (n_kept) {
             SMH_TRY(bufs.alloc(&pc.col, n_kept));
             SMH_TRY(bufs.alloc(&pc.val, n_kept));
-            hipLaunchKernelGGL((k_prod_compact<T>), dim3(mat_grid(nr)), dim3(kBlock), 0, s, off_b, col_b, (const T *)val_b, (uint64_t)nr, loc,
+            hipLaunchKernelGGL((k_prod_compact<T>), dim3(mat_grid(nr)), dim3(kBlock), 0, s, off_b, col_b, (const T *)val_b, (uint64_t)nr, rank,
                                (uint32_t)bt.r0, pc.col, pc.val, dims);
             SMH_HIP(hipGetLastError());
             pieces.push_back(pc);
             total += n_kept;
         }
         SMH_HIP(hipStreamSynchronize(s));
-        bufs.release(off_b); bufs.release(col_b); bufs.release(val_b); bufs.release(loc);
+        bufs.release(off_b); bufs.release(col_b); bufs.release(val_b); bufs.release(rank);
         lap("drop zeros, reverse");
     }
     if (total >= 0xFFFFFFFFull) return fail(SMH_ERR_CAPACITY, "Maximum number of %u entries reached", 0xFFFFFFFFu);
