@@ -76,3 +76,53 @@ def test_fuzz_all_kernels(gpu, dtype):
             if (n_cols + (1 << shift) - 1) >> shift <= 128:
                 assert_spmv_close(m.mvp(x, variant="colblock"), off, col, val, x, "%s %s colblock 2^%d" % (what, tag, shift))
             m.set_colblock_shift(0)
+
+
+def test_fuzz_replay_transpose_prod_against_the_container_restatement(gpu):
+    """Many small random cases for the widened rows: streams replayed on a SparseMatCRS, transpose
+    and prod, each bit-exact against the literal C restatement of the reference's container -- shapes chosen so that
+    every form of the first-push quirk, duplicates, empty rows and exact cancellations come up."""
+    import oracle
+    rng = np.random.default_rng(2024)
+
+    def same(m, e):
+        off, col, val = m.raw_parts()
+        assert (m.n_rows(), m.n_cols(), len(col)) == (e[0], e[1], len(e[3]))
+        assert np.array_equal(off[:e[0] + 1], e[2]) and np.array_equal(col, e[3]) and val.tobytes() == e[4].tobytes()
+
+    quirks = 0
+    for t in range(120):
+        dt = np.float32 if t % 2 else np.float64
+        # replay
+        n = int(rng.integers(0, 120))
+        n_r, n_c = int(rng.integers(1, 12)), int(rng.integers(1, 9))
+        rows, cols = rng.integers(0, n_r, n), rng.integers(0, n_c, n)
+        vals = rng.integers(-2, 3, n).astype(dt) if t % 3 == 0 else rng.uniform(-1, 1, n).astype(dt)
+        ops = None if t % 4 == 0 else rng.integers(0, 2, n).astype(np.uint8)
+        e = oracle.crs_replay(rows, cols, vals, ops)
+        same(sm.SparseMatCRS.from_triplets(rows, cols, vals, ops, into_crs=True), e)
+        quirks += e[5] != len(e[3])
+        # transpose and prod of small random matrices (unsorted rows, duplicates, empty rows)
+        a_rows, a_cols = int(rng.integers(1, 14)), int(rng.integers(1, 14))
+        lens = rng.integers(0, 6, a_rows)
+        lens[-1] = max(lens[-1], 1)
+        off = np.zeros(a_rows + 1, np.uint32)
+        np.cumsum(lens, out=off[1:])
+        col = rng.integers(0, a_cols, int(off[-1])).astype(np.uint32)
+        col[-1] = a_cols - 1
+        val = rng.integers(-2, 3, len(col)).astype(dt) if t % 3 == 0 else rng.uniform(-1, 1, len(col)).astype(dt)
+        a = sm.SparseMatCRS.from_raw_parts(a_rows, a_cols, off, col, val)
+        et = oracle.transpose(off, col, val)
+        same(a.transpose(), et)
+        quirks += et[5] != len(et[3])
+        # b with the dimensions the reference's prod demands: b.n_rows == a.n_cols, b.n_cols == a.n_rows
+        lens_b = rng.integers(0, 6, a_cols)
+        lens_b[-1] = max(lens_b[-1], 1)
+        off_b = np.zeros(a_cols + 1, np.uint32)
+        np.cumsum(lens_b, out=off_b[1:])
+        col_b = rng.integers(0, a_rows, int(off_b[-1])).astype(np.uint32)
+        col_b[-1] = a_rows - 1
+        val_b = rng.integers(-2, 3, len(col_b)).astype(dt) if t % 3 == 0 else rng.uniform(-1, 1, len(col_b)).astype(dt)
+        b = sm.SparseMatCRS.from_raw_parts(a_cols, a_rows, off_b, col_b, val_b)
+        same(a.prod(b), oracle.prod((a_rows, a_cols, off, col, val), (a_cols, a_rows, off_b, col_b, val_b)))
+    assert quirks > 5  # orphaned first entries did occur
