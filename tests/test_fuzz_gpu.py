@@ -126,3 +126,53 @@ def test_fuzz_replay_transpose_prod_against_the_container_restatement(gpu):
         b = sm.SparseMatCRS.from_raw_parts(a_cols, a_rows, off_b, col_b, val_b)
         same(a.prod(b), oracle.prod((a_rows, a_cols, off, col, val), (a_cols, a_rows, off_b, col_b, val_b)))
     assert quirks > 5  # orphaned first entries did occur
+
+
+def test_fuzz_column_tables_and_predicates(gpu):
+    """Random small matrices (unsorted rows, duplicate columns, partly symmetric by construction): the column tables
+    equal the oracle's restatement of assemble_column_info, is_sorted / is_symmetric equal the trait defaults written
+    out in Python (get = first match in storage order, zero when absent: sparsemat_crs.rs:54-67,136-142)."""
+    import oracle
+    rng = np.random.default_rng(77)
+    seen = {"sym": 0, "asym": 0, "sorted": 0, "unsorted": 0}
+    for t in range(150):
+        n = int(rng.integers(1, 10))
+        dense = np.zeros((n, n))
+        if t % 3 == 0:  # symmetric pattern and values
+            m = rng.integers(-2, 3, (n, n)).astype(np.float64) * (rng.random((n, n)) < 0.4)
+            dense = np.triu(m) + np.triu(m, 1).T
+        else:
+            dense = rng.integers(-2, 3, (n, n)).astype(np.float64) * (rng.random((n, n)) < 0.35)
+        rows_l, cols_l, vals_l = [], [], []
+        off = [0]
+        for i in range(n):
+            js = [j for j in range(n) if dense[i, j] != 0 or rng.random() < 0.05]  # a few stored zeros
+            if t % 2:
+                js = list(rng.permutation(js))  # storage order
+            if js and rng.random() < 0.2:
+                js.append(js[0])  # a duplicate column; get() sees the first one only
+            for j in js:
+                cols_l.append(int(j))
+                vals_l.append(dense[i, j])
+            off.append(len(cols_l))
+        off = np.array(off, np.uint32)
+        col = np.array(cols_l, np.uint32)
+        val = np.array(vals_l, np.float64)
+        a = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val, validate=False)
+
+        def get(i, j):
+            if i >= n:
+                return 0.0
+            for q in range(off[i], off[i + 1]):
+                if col[q] == j:
+                    return val[q]
+            return 0.0
+        want_sym = all(get(int(col[q]), i) == val[q] for i in range(n) for q in range(off[i], off[i + 1]))
+        want_sorted = all(col[q] >= col[q - 1] for i in range(n) for q in range(off[i] + 1, off[i + 1]))
+        assert a.is_symmetric() == want_sym and a.is_sorted() == want_sorted
+        seen["sym" if want_sym else "asym"] += 1
+        seen["sorted" if want_sorted else "unsorted"] += 1
+        rows, col_ptr, entries = a.column_info()
+        e_rows, e_ptr, e_entries = oracle.column_info(off, col, n)
+        assert np.array_equal(rows, e_rows) and np.array_equal(col_ptr, e_ptr) and np.array_equal(entries, e_entries)
+    assert min(seen.values()) > 10, seen
