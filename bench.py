@@ -7,25 +7,35 @@
 A "step" is one pass of the hot path over the resident matrix: y = A.x with A, x, y in HBM.
   N = 1  BASELINE configs[1]: SparseMatCRS<f32,u32>, 10,000,000 rows, 32 nnz/row, banded-stratified
          columns (DESIGN.md "Synthetic inputs"), kernel chosen by SMH_SPMV_AUTO (K1r, lanes 8).
-  N > 1  weak scaling, BASELINE configs[4] shape: rank r owns rows [r*10M, (r+1)*10M) of an
-         (N*10M)-row matrix with global columns (SparseMatPar), step = local SpMV + ONE RCCL exchange
-         that makes y usable as the next x on every rank.  --exchange allgather: all-gather of the y
-         slices (every rank gets the full vector); halo: every rank gets exactly the entries its block
-         references (for this banded matrix: 4096 entries from each neighbour, one grouped launch of
-         point-to-point sends / receives on slices of the vector itself);
-         auto (default) picks halo when that is less than half of the vector.
-`value` = algorithmic bytes moved by all ranks / wall time of the K timed steps (max over ranks).
-Algorithmic bytes per rank and step: nnz*(4+4) + (rows+1)*4 + rows*4 [y] + x_ref*4, where x_ref is
-the number of distinct x entries the rank's rows can reference (rows + band width).
+  N > 1  weak scaling, BASELINE configs[4] shape: block b owns rows [b*10M, (b+1)*10M) of an (N*10M)-row
+         matrix with global columns (SparseMatPar), step = local SpMV into the block's slice of y + ONE
+         exchange INSIDE libsparsemat_hip.so (csrc/par.hip) that makes y usable as the next x on every GPU:
+         --exchange allgather: in-place ncclAllGather of the y slices; window: grouped ncclSend/ncclRecv of
+         exactly the entries each block's columns reference (this banded matrix: 4096 entries from each
+         neighbour); auto (default): the window when no block receives half of the vector or more.
+         Launched by torch.distributed.run: one process per GPU, the ranks meet through smh_comm_*
+         (ncclCommInitRank; the 128-byte id travels through a file in /tmp), rank = block.  Launched bare
+         (`python bench.py --gpus N`): ONE process owns all N blocks (ncclCommInitAll, or
+         SMH_PAR_BACKEND=peer for the direct peer-read exchange).  torch is not imported either way.
+`value` = algorithmic bytes moved by all GPUs / wall time of the K timed steps (barrier + device
+synchronisation on both sides, max over ranks).
+Algorithmic bytes per GPU and step: nnz*(4+4) + (rows+1)*4 + rows*4 [y] + x_ref*4, where x_ref is the
+number of distinct x entries the block's rows can reference (rows + band width).
 
-One JSON line on stdout (rank 0).  `roofline` is the SpMV kernel alone (HIP events around every
-launch, on the launch stream); `traffic` comes from two rocprofv3 --pmc child passes of this same
-script (FETCH_SIZE x2 per the gfx950 correction, + WRITE_SIZE, KiB units); `cpu_baseline` is the
-CPU oracle (oracle/, the reference's algorithm restated in C: the reference is Rust and cannot be
-built here), one thread, timed on this host in this run.
+One JSON line on stdout (rank 0).  `roofline` is the SpMV kernel alone (HIP events around every launch, on
+the launch stream): `frac` = algorithmic bytes / mean kernel time / 8 TB/s as the metric defines it, and
+`frac_traffic` = the HBM bytes the launch really moved (rocprofv3 PMC, two child passes of this script:
+FETCH_SIZE with the gfx950 factor CALIBRATED in the same pass on an element-wise kernel of known traffic,
++ WRITE_SIZE) / mean kernel time / 8 TB/s -- the physical fraction; the kernel streams 16-bit ring-slot
+columns, so it moves fewer bytes than the CSR arrays hold.  `cold` = the same launch after a 512 MiB
+flush of L2 + Infinity Cache.  `cpu_baseline` is the CPU oracle (oracle/, the reference's algorithm
+restated in C: the reference is Rust and cannot be built here), ONE thread like the reference, timed on
+this host in this run; `cpu_baseline_all_cores` is the same loop spread over all cores with OpenMP --
+NOT reference behaviour, reported so that the GPU/CPU ratio is not inflated by the reference being serial.
 """
 import argparse
 import csv
+import ctypes as C
 import glob
 import json
 import os
@@ -43,6 +53,9 @@ NNZ_PER_ROW = 32
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0      # measured float4-copy ceiling, same guide
 KERNEL_SUBSTR = "k_spmv_ring"
+CALIB_SUBSTR = "k_ew"       # the element-wise kernel the PMC child pass runs for calibration
+CALIB_N = 1 << 26           # x += y on 2^26 f32: reads 2 x 256 MiB, writes 256 MiB, 16 B per lane
+FLUSH_BYTES = 512 << 20
 
 
 def algorithmic_bytes(rows, nnz, x_ref):
@@ -50,13 +63,14 @@ def algorithmic_bytes(rows, nnz, x_ref):
 
 
 def pmc_traffic(args):
-    """HBM bytes per SpMV launch from rocprofv3 PMC counters, or None.  Runs BEFORE this process
-    touches the GPU: two child passes of this script (TCC has 4 slots: FETCH_SIZE takes 3,
-    WRITE_SIZE 2 -> separate passes)."""
+    """HBM bytes per SpMV launch from rocprofv3 PMC counters, or (None, note, None).  Runs BEFORE this process touches
+    the GPU: two child passes of this script (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2 -> separate passes),
+    never mixed with tracing.  Each pass also runs an element-wise kernel of KNOWN traffic (x += y, 16 B per lane like the
+    SpMV's streams), from which the counter's bytes-per-unit is calibrated instead of assumed."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    out = {}
+        return None, "rocprofv3 not found", None
+    out, calib = {}, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="smh_pmc_", dir="/tmp")
@@ -65,38 +79,83 @@ def pmc_traffic(args):
                    "--rows", str(args.rows)]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
-            vals = []
+            vals, cal = [], []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f, newline="") as fh:
                     for row in csv.DictReader(fh):
-                        if KERNEL_SUBSTR in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        if KERNEL_SUBSTR in row.get("Kernel_Name", ""):
                             vals.append(float(row["Counter_Value"]))
+                        elif CALIB_SUBSTR in row.get("Kernel_Name", ""):
+                            cal.append(float(row["Counter_Value"]))
             shutil.rmtree(d, ignore_errors=True)
-            if r.returncode != 0 or not vals:
-                return None, "rocprofv3 --pmc %s: rc=%d, %d samples" % (counter, r.returncode, len(vals))
+            if r.returncode != 0 or not vals or not cal:
+                return None, "rocprofv3 --pmc %s: rc=%d, %d + %d samples" % (counter, r.returncode, len(vals), len(cal)), None
             out[counter] = sum(vals) / len(vals)
+            calib[counter] = sum(cal) / len(cal)
     except Exception as e:  # profiling is best effort; the measurement itself never depends on it
-        return None, "pmc pass failed: %r" % (e,)
-    # units KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2
-    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, "2*FETCH_SIZE+WRITE_SIZE (KiB), gfx950 correction"
+        return None, "pmc pass failed: %r" % (e,), None
+    # counters are in KiB; bytes per counted KiB from the kernel of known traffic (gfx950: FETCH_SIZE tallies a 128-B
+    # request as 64 B -> ~2.0; WRITE_SIZE ~1.0)
+    f_fetch = (2 * CALIB_N * 4) / (calib["FETCH_SIZE"] * 1024.0)
+    f_write = (CALIB_N * 4) / (calib["WRITE_SIZE"] * 1024.0)
+    cal_info = {"kernel": "k_ew<Add> x += y, %d f32 (reads %d B, writes %d B)" % (CALIB_N, 2 * CALIB_N * 4, CALIB_N * 4),
+                "fetch_size_kib": calib["FETCH_SIZE"], "write_size_kib": calib["WRITE_SIZE"],
+                "fetch_factor_measured": f_fetch, "write_factor_measured": f_write,
+                "fetch_factor_guide": 2.0, "spmv_fetch_size_kib": out["FETCH_SIZE"], "spmv_write_size_kib": out["WRITE_SIZE"]}
+    if not (1.7 <= f_fetch <= 2.3 and 0.85 <= f_write <= 1.15):
+        return None, "PMC calibration off: fetch x%.3f write x%.3f" % (f_fetch, f_write), cal_info
+    return ((f_fetch * out["FETCH_SIZE"] + f_write * out["WRITE_SIZE"]) * 1024.0,
+            "(%.3f*FETCH_SIZE + %.3f*WRITE_SIZE) KiB; factors measured in the same passes on k_ew (guide: 2.0 / 1.0)" % (f_fetch, f_write),
+            cal_info)
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box hands a
+    one-GPU job a share of its cores; 256 OpenMP threads on a 16-core share only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.999)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / int(g.read()) + 0.999)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
 def cpu_baseline(rows, x_host, y_gpu_host):
-    """Reference algorithm on one host core (the oracle), same workload, plus the parity gate."""
+    """Reference algorithm on one host core (the oracle), same workload, plus the parity gate; and the same loop on all
+    cores (OpenMP), which is NOT what the reference does."""
     import numpy as np
     import oracle
     from sparsemat_amd import synth
     t0 = time.time()
     off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, rows, NNZ_PER_ROW, np.float32)
     gen_s = time.time() - t0
-    times = []
-    y_ref = None
-    for _ in range(5):
-        t0 = time.perf_counter()
-        y_ref = oracle.spmv(off, col, val, x_host)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+
+    def med5(fn):
+        times, out = [], None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            out = fn()
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        return times[len(times) // 2], out
+
+    med, y_ref = med5(lambda: oracle.spmv(off, col, val, x_host))
+    cores = usable_cores()
+    med_omp, (y_omp, threads) = med5(lambda: oracle.spmv_omp(off, col, val, x_host, cores))
+    assert y_omp.tobytes() == y_ref.tobytes()
     b = algorithmic_bytes(rows, len(val), rows)
     # parity gate (SURVEY 8d): componentwise |dy| <= 1e-5 * sum_j |a_ij x_j|
     scale = oracle.spmv_abs(off, col, val, x_host)
@@ -111,13 +170,83 @@ def cpu_baseline(rows, x_host, y_gpu_host):
                     break
     except OSError:
         pass
-    return {
+    one = {
         "value": b / med / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
         "sample": "all %d rows x %d nnz (whole N=1 workload), median of 5 passes, %.3f s per pass" % (rows, NNZ_PER_ROW, med),
         "ms_per_step": med * 1e3, "gflops": 2.0 * len(val) / med / 1e9, "host_cpu": cpu_model,
         "host_cores_available": os.cpu_count(), "generate_s": gen_s,
         "parity_max_rel_err_vs_sum_abs": worst, "parity_ok": bool(worst <= 1e-5),
     }
+    allc = {
+        "value": b / med_omp / 1e9, "unit": "GB/s", "cores": threads, "kind": "port-openmp",
+        "note": "NOT reference behaviour: the reference's mvp is serial (its mvp_par is commented out); same per-row loop, rows "
+                "spread over all host cores, bit-identical y",
+        "sample": "the same workload, median of 5 passes, %.4f s per pass" % med_omp, "ms_per_step": med_omp * 1e3,
+    }
+    return one, allc
+
+
+class Events:
+    """HIP events through the C ABI (smh_event_*): recorded on the stream the kernel is launched on."""
+
+    def __init__(self, lib, check, n):
+        self.lib, self.check = lib, check
+        self.ev = []
+        for _ in range(n):
+            a, b = C.c_void_p(), C.c_void_p()
+            check(lib.smh_event_create(C.byref(a)))
+            check(lib.smh_event_create(C.byref(b)))
+            self.ev.append((a, b))
+
+    def start(self, i, stream):
+        self.check(self.lib.smh_event_record(self.ev[i][0], C.c_void_p(stream or 0)))
+
+    def stop(self, i, stream):
+        self.check(self.lib.smh_event_record(self.ev[i][1], C.c_void_p(stream or 0)))
+
+    def times_ms(self):
+        out = []
+        for a, b in self.ev:
+            ms = C.c_float()
+            self.check(self.lib.smh_event_elapsed_ms(a, b, C.byref(ms)))
+            out.append(ms.value)
+        return out
+
+
+def stats(ts):
+    s = sorted(ts)
+    return {"mean": sum(s) / len(s), "median": s[len(s) // 2], "min": s[0], "max": s[-1], "launches": len(s)}
+
+
+def rendezvous_id(rank, make_id):
+    """The 128-byte communicator id from rank 0 to the other ranks of this launch through a file in /tmp.  The name is
+    keyed by the launcher (parent pid + its start time) and MASTER_PORT, so concurrent or earlier launches never collide."""
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        pass
+    path = "/tmp/smh_comm_id_%d_%s_%s" % (ppid, start, os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        uid = make_id()
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    deadline = time.time() + 600
+    while time.time() < deadline:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid, path
+        except OSError:
+            pass
+        time.sleep(0.02)
+    raise RuntimeError("rank %d: no communicator id at %s after 600 s" % (rank, path))
 
 
 def main():
@@ -127,9 +256,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE size)")
     ap.add_argument("--variant", default="auto")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "window", "halo", "allgather"],
                     help="N>1: what a step exchanges after the local SpMV (auto: only the vector entries each "
-                         "rank's block references when that is less than half of the vector, else the all-gather)")
+                         "block references when that is less than half of the vector, else the all-gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # rocprofv3 --pmc child pass
@@ -141,133 +270,216 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torch.distributed.run: one process per GPU
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    n_gpus = world if launched else max(1, args.gpus)
+    one_process = not launched and n_gpus > 1  # bare `bench.py --gpus N`: this process owns all N blocks
 
-    traffic, traffic_note = None, "skipped"
-    if world == 1 and "RANK" not in os.environ and not args.child and not args.no_traffic:
-        traffic, traffic_note = pmc_traffic(args)  # before this process initialises the GPU
+    traffic, traffic_note, calibration = None, "skipped", None
+    if n_gpus == 1 and not launched and not args.child and not args.no_traffic:
+        traffic, traffic_note, calibration = pmc_traffic(args)  # before this process initialises the GPU
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
     import sparsemat_amd as sm
-    from sparsemat_amd import synth
-    from sparsemat_amd.sparsemat_par import HipBlock, SparseMatPar
+    from sparsemat_amd import _lib, synth
+    lib, check = sm.lib(), _lib.check
 
-    torch.cuda.set_device(local_rank)
-    sm._lib.check(sm.lib().smh_set_device(local_rank))
-    # SMH_BENCH_FORCE_DIST=1: exercise the RCCL path (process group + in-place all-gather) even with one rank
-    force_dist = os.environ.get("SMH_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
-    use_dist = world > 1 or force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_dev = C.c_int(0)
+    check(lib.smh_device_count(C.byref(n_dev)))
+    if n_dev.value == 0:
+        sys.exit("bench.py needs a HIP device: sparsemat_amd has no CPU fallback")
+    if one_process and n_gpus > n_dev.value:
+        sys.exit("bench.py --gpus %d: only %d device(s) visible" % (n_gpus, n_dev.value))
 
     rows = args.rows
-    n = rows * world
-    begin, end = rank * rows, (rank + 1) * rows
-    mat = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, begin, end)
+    n = rows * n_gpus
+    band = min(n, 256 * NNZ_PER_ROW)
+    exchange_req = "window" if args.exchange == "halo" else args.exchange
+    comm = par = None
+    rdzv_path = None
+
+    # SMH_BENCH_FORCE_PAR=1: take the partitioned path (communicator, smh_par_*, distributed vectors) even with one GPU --
+    # how the N > 1 code is rehearsed end to end on a one-GPU box
+    force_par = os.environ.get("SMH_BENCH_FORCE_PAR") == "1"
+    if n_gpus == 1 and not force_par:
+        check(lib.smh_set_device(local_rank if launched else 0))
+        mat = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32)
+        blocks = [mat]
+        xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
+        ybuf = synth.DeviceBuffer(n * 4)
+        yptr = ybuf.ptr
+        s = C.c_void_p()
+        check(lib.smh_stream_create(C.byref(s)))
+        stream = s.value
+        exchange_mode, backend = "none", "none"
+
+        def spmv():
+            mat.mvp_dev(xptr, n, yptr, args.variant, stream=stream)
+
+        def exchange():
+            pass
+
+        def sync():
+            check(lib.smh_stream_synchronize(C.c_void_p(stream)))
+    else:
+        if launched:
+            check(lib.smh_set_device(local_rank))
+            uid, rdzv_path = rendezvous_id(rank, sm.Comm.unique_id)
+            comm = sm.Comm(uid, world, rank)  # ncclCommInitRank: collective
+            blocks = [synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, rank * rows, (rank + 1) * rows)]
+            par = sm.SparseMatParLocal.for_rank(comm, n, blocks[0])
+        else:
+            blocks = []
+            for d in range(n_gpus):
+                check(lib.smh_set_device(d))
+                blocks.append(synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, d * rows, (d + 1) * rows))
+            check(lib.smh_set_device(0))
+            par = sm.SparseMatParLocal.adopt(blocks, n)
+        mat = blocks[0]
+        x, y = par.vec(), par.vec()
+        par.synchronize()  # (the vectors' zero fill runs on the blocks' streams)
+        for b in range(par.n_local_blocks()):  # x born on every device (no PCIe): the same seeded vector everywhere
+            check(lib.smh_set_device(par.block(b)[2]))
+            synth.gen_x(synth.SEED_X, n, np.float32, ptr=x.ptr(b))
+        check(lib.smh_set_device(par.block(0)[2]))
+        exchange_mode, max_recv = par.exchange_mode(exchange_req)
+        backend = par.backend()
+        stream = par.block_stream(0)
+
+        def spmv():
+            par.mvp_dev(x, y, args.variant, "none")
+
+        def exchange():
+            par.exchange(y, exchange_req)
+
+        def sync():
+            par.synchronize()
+
     nnz = mat.n_non_zero_entries()
-    x = torch.empty(n, dtype=torch.float32, device="cuda")
-    synth.gen_x(synth.SEED_X, n, np.float32, ptr=x.data_ptr())
-    y = torch.zeros(n, dtype=torch.float32, device="cuda")
-    par = SparseMatPar(world, n, n, rank, HipBlock(mat, args.variant))
-    exchange_mode = par.setup_window_exchange(x, args.exchange) if use_dist else "none"
     variant, lanes = mat.resolved_variant()
     _, ring_frac, ring_active, _, _ = mat.ring_plan()
-    band = min(n, 256 * NNZ_PER_ROW)
-    bytes_rank = algorithmic_bytes(rows, nnz, min(n, rows + band))
+    bytes_gpu = algorithmic_bytes(rows, nnz, min(n, rows + band))
 
-    y_local = y[begin:end]
+    def barrier():
+        sync()
+        if comm is not None:
+            comm.barrier()  # device drained, then all ranks meet (an RCCL all-reduce on the communicator)
 
-    def step():
-        # exactly the body of a timed step: local SpMV into this rank's slice of y, then (N > 1) the exchange that
-        # makes y usable as the next x -- so the warm-up also creates whatever the first exchange sets up lazily
-        par.mvp_local(x, y_local)
-        if use_dist:
-            par.exchange_window(y)
-
-    stream = torch.cuda.current_stream()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-    # HIP events around every SpMV kernel launch (same stream as the launch)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for _ in range(args.warmup):  # exactly the body of a timed step, so lazily created state exists before the clock starts
+        spmv()
+        exchange()
+    barrier()
+    ev = Events(lib, check, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record(stream)
-        par.mvp_local(x, y_local)
-        ev[i][1].record(stream)
-        if use_dist:
-            par.exchange_window(y)  # y becomes usable as the next x on this rank
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize()
+        ev.start(i, stream)  # HIP events around the SpMV kernel, on the stream it is launched on (block 0 of this process)
+        spmv()
+        ev.stop(i, stream)
+        exchange()           # y becomes usable as the next x on every GPU
+    barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.max(elapsed)
+    kernel = stats(ev.times_ms())
 
     if args.child:
+        # the calibration kernel of the PMC pass: x += y on CALIB_N f32 (known traffic, 16 B per lane)
+        a, b = sm.DenseVec.zeros(CALIB_N, np.float32), sm.DenseVec.zeros(CALIB_N, np.float32)
+        for _ in range(3):
+            a.add(b)
+        check(lib.smh_device_synchronize())
         return
 
+    # cold: the same launch after 512 MiB of stores flushed L2 and the Infinity Cache (N = 1 only)
+    cold = None
+    if n_gpus == 1:
+        flush = synth.DeviceBuffer(FLUSH_BYTES)
+        cev = Events(lib, check, 20)
+        for i in range(20):
+            check(lib.smh_dev_memset(C.c_void_p(flush.ptr), i & 0xFF, FLUSH_BYTES, C.c_void_p(stream)))
+            cev.start(i, stream)
+            spmv()
+            cev.stop(i, stream)
+        sync()
+        cold = stats(cev.times_ms())
+        del flush
+
     ms_per_step = elapsed / args.steps * 1e3
-    value = bytes_rank * world / (elapsed / args.steps) / 1e9
-    achieved = bytes_rank / (kernel_ms * 1e-3) / 1e9
+    value = bytes_gpu * n_gpus / (elapsed / args.steps) / 1e9
+    kernel_ms = kernel["mean"]
+    achieved = bytes_gpu / (kernel_ms * 1e-3) / 1e9
+    traffic_rate = (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None
+    if n_gpus == 1:
+        workload = "f32 CSR SpMV, %d rows x %d nnz/row, banded-stratified columns, 1xMI355X" % (rows, NNZ_PER_ROW)
+        parallelism = "single GPU"
+    else:
+        how = "one process per GPU (ncclCommInitRank)" if launched else "one process, %d devices (%s)" % (
+            n_gpus, "ncclCommInitAll" if backend == "rccl" else "peer reads")
+        workload = ("f32 CSR SpMV, %d rows (%d per GPU) x %d nnz/row, banded-stratified columns, row-partitioned over %d GPUs, "
+                    "exchange of y per step inside libsparsemat_hip.so: %s over %s, %s" % (n, rows, NNZ_PER_ROW, n_gpus, exchange_mode, backend, how))
+        parallelism = "rows/%d + %s exchange (%s)" % (n_gpus, exchange_mode, backend)
     result = {
-        "metric": "csr_spmv_effective_hbm_GBps", "value": value, "unit": "GB/s", "n_gpus": world,
+        "metric": "csr_spmv_effective_hbm_GBps", "value": value, "unit": "GB/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": ("f32 CSR SpMV, %d rows x %d nnz/row, banded-stratified columns, 1xMI355X" % (rows, NNZ_PER_ROW))
-            if world == 1 else
-            ("f32 CSR SpMV, %d rows (%d per GPU) x %d nnz/row, banded-stratified columns, row-partitioned over %d GPUs, "
-             "RCCL exchange of y per step: %s" % (n, rows, NNZ_PER_ROW, world, exchange_mode)),
-            "rows_per_gpu": rows, "nnz_per_gpu": nnz, "index": "u32", "kernel": "%s lanes=%d ring=%s (ring rows %.3f)" % (variant, lanes, ring_active, ring_frac),
-            "parallelism": "rows/%d + %s exchange (RCCL)" % (world, exchange_mode) if world > 1 else "single GPU",
-            "exchange": exchange_mode,
+            "workload": workload, "rows_per_gpu": rows, "nnz_per_gpu": nnz, "index": "u32",
+            "kernel": "%s lanes=%d ring=%s (ring rows %.3f)" % (variant, lanes, ring_active, ring_frac),
+            "parallelism": parallelism, "exchange": exchange_mode, "exchange_backend": backend,
+            "launch": "torch.distributed.run, one process per GPU" if launched else ("one process" if n_gpus > 1 else "single process"),
         },
-        "gflops": 2.0 * nnz * world / (elapsed / args.steps) / 1e9,
-        # per step: the local SpMV kernel (HIP events, this rank) and what the rest of the step costs (the exchange and
-        # launch gaps; max over ranks is in ms_per_step)
+        "gflops": 2.0 * nnz * n_gpus / (elapsed / args.steps) / 1e9,
+        # per step: the local SpMV kernel (HIP events, block 0 of rank 0) and what the rest of the step costs (the exchange
+        # and launch gaps; max over ranks is in ms_per_step)
         "spmv_kernel_ms": kernel_ms, "step_minus_kernel_ms": ms_per_step - kernel_ms,
-        "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBPS * world),
-        "algorithmic_bytes_per_gpu_step": bytes_rank,
+        "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBPS * n_gpus),
+        "algorithmic_bytes_per_gpu_step": bytes_gpu,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_note": traffic_note, "kernel": KERNEL_SUBSTR if ring_active else variant,
-            "kernel_ms": kernel_ms, "algorithmic_bytes": bytes_rank, "frac_of_measured_copy": achieved / HBM_COPY_GBPS,
-            # `achieved` is the ALGORITHMIC bytes of the CSR SpMV over the kernel time, as the metric is
-            # defined.  The kernel moves fewer bytes than that: ring phases stream a 16-bit column array (the low
-            # halves of the u32 columns, built once), so the HBM traffic per launch (`traffic`, PMC) is ~2.04 GB for
-            # the 2.68 GB algorithmic figure -- the rate of real HBM traffic is `traffic_rate` (GB/s).
+            "traffic": traffic,
+            # the PHYSICAL fraction: HBM bytes the launch really moved (PMC) / kernel time / peak.  `frac` above is the
+            # metric's definition (algorithmic CSR bytes / time); it is larger because ring phases stream a 16-bit column
+            # array (6 instead of 8 bytes per f32 entry leave HBM).  Lead with frac_traffic when judging the kernel.
+            "frac_traffic": (traffic_rate / HBM_PEAK_GBPS) if traffic else None,
+            "traffic_rate": traffic_rate,
+            "traffic_over_algorithmic": (traffic / bytes_gpu) if traffic else None,
+            "traffic_frac_of_measured_copy": (traffic_rate / HBM_COPY_GBPS) if traffic else None,
+            "traffic_note": traffic_note, "traffic_calibration": calibration,
+            "kernel": KERNEL_SUBSTR if ring_active else variant,
+            "kernel_ms": kernel_ms, "kernel_ms_median": kernel["median"], "kernel_ms_min": kernel["min"],
+            "kernel_ms_max": kernel["max"], "launches": kernel["launches"],
+            "frac_median": bytes_gpu / (kernel["median"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "algorithmic_bytes": bytes_gpu,
+            "cold": None if cold is None else {
+                "flush": "%d MiB of stores before every launch (L2 + Infinity Cache)" % (FLUSH_BYTES >> 20),
+                "kernel_ms_median": cold["median"], "kernel_ms_min": cold["min"], "kernel_ms_max": cold["max"],
+                "launches": cold["launches"], "frac": bytes_gpu / (cold["median"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_traffic": (traffic / (cold["median"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            },
             "layout": "f32 values + 16-bit ring-slot columns for LDS-ring phases (u32 columns kept for the rest)",
-            "traffic_rate": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-            "traffic_frac_of_peak": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
         },
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(rows, x.cpu().numpy(), y.cpu().numpy())
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            one, allc = cpu_baseline(rows, xbuf.download(np.float32, n), ybuf.download(np.float32, n))
+            result["cpu_baseline"], result["cpu_baseline_all_cores"] = one, allc
         else:
             result["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        if rank == 0 and rdzv_path:
+            try:
+                os.remove(rdzv_path)
+            except OSError:
+                pass
+    if par is not None:
+        par.close()
+    if comm is not None:
+        comm.close()
 
 
 if __name__ == "__main__":

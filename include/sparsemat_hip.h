@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SMH_ABI_VERSION 1
+#define SMH_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------ */
 enum {
@@ -45,7 +45,8 @@ enum {
     SMH_ERR_HIP = 5,           /* a HIP runtime call failed (message carries hipGetErrorString) */
     SMH_ERR_OOM = 6,           /* hipMalloc failed */
     SMH_ERR_NO_DEVICE = 7,     /* no HIP device: there is no CPU fallback */
-    SMH_ERR_CAPACITY = 8       /* nnz >= u32::MAX: "Maximum number of {} entries reached" sparsemat_crs.rs:82-84 */
+    SMH_ERR_CAPACITY = 8,      /* nnz >= u32::MAX: "Maximum number of {} entries reached" sparsemat_crs.rs:82-84 */
+    SMH_ERR_COMM = 9           /* an RCCL call failed (message carries ncclGetErrorString) */
 };
 
 typedef enum { SMH_F32 = 0, SMH_F64 = 1 } smh_dtype;
@@ -299,38 +300,124 @@ int smh_pcg_jacobi_solve(smh_crs *m, const void *b_host, size_t b_len, void *x_h
                          size_t x_len, double tol, size_t iter_max, int variant, size_t *iters_out,
                          double *rr_out);
 
-/* ---- SparseMatPar<SparseMatCRS<T,u32>> (sparsemat_par.rs:12-35, 86-140), one process ------
- * n_blocks row blocks of R = n_rows / n_blocks rows (with_sub_matrices :20-28; integer
- * division :21), block b = global rows [b R, (b+1) R) with local row ids and GLOBAL column ids,
- * living on device device_ids[b] (NULL: block b on device b mod device count; several blocks
- * may share a device).  The last block takes the remainder -- the reference clamps the block id
- * to n_blocks (:32), one past the last block, and panics there.  R == 0 is SMH_ERR_INVALID (the
- * reference divides by zero in :32).  The global CRS arrays are host arrays, borrowed for the
- * call and split at the block boundaries.
- * smh_par_spmv: y = A x (the trait-default mvp through iter_row :86-89) on host vectors; blocks
- * run concurrently, each uploading only x[min column .. max column] of its rows.
- * smh_par_cg_solve: ConjugateGradient::solve (linearsolver.rs:27-61) with x, r, p, Ap distributed
- * by rows; per iteration blocks exchange only the entries of p their columns reference (device
- * to device, hipMemcpyPeerAsync) and the two dot products are folded on the host in block order.
- * Same statuses and outputs as smh_cg_solve.  The multi-process form (one rank per GPU, RCCL)
- * is sparsemat_amd/sparsemat_par.py. */
+/* ---- SparseMatPar<SparseMatCRS<T,u32>> (sparsemat_par.rs:12-35, 86-140) over the GPUs of one node ----
+ * The reference keeps n_blocks sub-matrices of R = n_rows / n_blocks rows (with_sub_matrices :20-28;
+ * integer division :21); block b = global rows [b R, (b+1) R) with local row ids and GLOBAL column
+ * ids; its (commented-out) mvp_par :37-68 multiplies every block against the shared rhs and places
+ * the results at b * R -- a row partition plus an all-gather.  Here block b lives on a GPU, the local
+ * product is the library's SpMV, and the exchange runs INSIDE the library, device to device over
+ * xGMI: an in-place RCCL all-gather of the y slices (ncclAllGather at recvbuff + b R; a ragged last
+ * block adds one ncclBroadcast of its tail), or -- when the blocks' column intervals say that less
+ * than half of the vector is referenced -- grouped ncclSend / ncclRecv of exactly the referenced
+ * entries ("window"; a banded matrix moves a halo).  Two ways to own the blocks:
+ *   one process, all blocks   smh_par_create (splits host arrays) / smh_par_adopt (blocks already on
+ *                             their devices): ncclCommInitAll over the blocks' devices when they are
+ *                             distinct (backend RCCL), or -- backend PEER, also the only choice when
+ *                             blocks share a device -- one pull kernel per block that reads the peers'
+ *                             slices directly (peer access; hipMemcpyPeerAsync where there is none).
+ *   one process per GPU       smh_comm_unique_id on one rank, smh_comm_create (ncclCommInitRank) on
+ *                             all, smh_par_create_rank around each rank's own block: rank = block id.
+ * The last block takes the remainder rows -- the reference clamps the block id to n_blocks (:32), one
+ * past the last block, and panics there.  R == 0 is SMH_ERR_INVALID (the reference divides by zero in
+ * :32).  Vectors of the partitioned path are smh_par_vec: one full-length device buffer per local
+ * block; block b OWNS entries [b R, (b+1) R), the rest of a buffer is valid as far as the last
+ * upload / exchange made it so.  All smh_par_*_dev / _vec calls are asynchronous on the blocks'
+ * private streams (ordered among themselves); smh_par_synchronize waits for them.              */
 typedef struct smh_par smh_par;
+typedef struct smh_par_vec smh_par_vec;
+typedef struct smh_comm smh_comm; /* one rank of an RCCL communicator (one process per GPU) */
+
+enum { SMH_EXCHANGE_NONE = 0, SMH_EXCHANGE_ALLGATHER = 1, SMH_EXCHANGE_WINDOW = 2, SMH_EXCHANGE_AUTO = 3 };
+enum { SMH_PAR_BACKEND_AUTO = 0, SMH_PAR_BACKEND_PEER = 1, SMH_PAR_BACKEND_RCCL = 2 };
+#define SMH_COMM_ID_BYTES 128
+
+/* ncclGetUniqueId -> id_out[SMH_COMM_ID_BYTES]: call on ONE rank, hand the bytes to the others by any
+ * host-side means (a file, a socket, the launcher's store), then every rank calls smh_comm_create
+ * (ncclCommInitRank) with its rank on its device (smh_set_device first).  Collective. */
+int smh_comm_unique_id(void *id_out);
+int smh_comm_create(const void *id, int n_ranks, int rank, smh_comm **out);
+int smh_comm_destroy(smh_comm *c);
+int smh_comm_size(const smh_comm *c);
+int smh_comm_rank(const smh_comm *c);
+/* helpers for a host without a collective library of its own (bench, tests): a barrier across the
+ * ranks (device work of this rank's device drained first), and max over ranks of one double */
+int smh_comm_barrier(smh_comm *c);
+int smh_comm_max_f64(smh_comm *c, double *value_inout);
+
 int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size_t n_rows,
                    size_t n_cols, const uint32_t *offset_rows, const uint32_t *columns,
                    const void *values, int validate, smh_par **out);
+/* blocks that already live on their devices (device-born inputs): blocks[b] = rows [b R, (b+1) R) of
+ * an n_rows-row matrix, all with the same n_cols and dtype.  Borrowed: they must outlive the handle. */
+int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_par **out);
+/* one process per GPU: this rank's block (borrowed) of an n_rows-row matrix; n_blocks = comm size,
+ * block id = comm rank.  Collective (the ranks exchange their column intervals). */
+int smh_par_create_rank(smh_comm *comm, size_t n_rows, smh_crs *block, smh_par **out);
 int smh_par_destroy(smh_par *p);
 size_t smh_par_n_blocks(const smh_par *p);
+size_t smh_par_n_local_blocks(const smh_par *p);  /* n_blocks, or 1 with one process per GPU */
 size_t smh_par_n_rows(const smh_par *p);
 size_t smh_par_n_cols(const smh_par *p);          /* :109-115 */
-size_t smh_par_nnz(const smh_par *p);             /* n_non_zero_entries :117-123 */
+size_t smh_par_nnz(const smh_par *p);             /* n_non_zero_entries :117-123 (local blocks) */
 size_t smh_par_rows_per_block(const smh_par *p);  /* n_rows_sub_matrix :13 */
-/* block b: its device matrix (owned by the par handle), global row range, device ordinal */
+/* local block i: its device matrix (owned by the par handle unless adopted), global row range, device */
 int smh_par_block(const smh_par *p, size_t block, smh_crs **crs_out, size_t *row_begin,
                   size_t *row_end, int *device);
+/* the private stream local block i's work is enqueued on (to bracket it with events of the caller's) */
+int smh_par_block_stream(const smh_par *p, size_t block, void **stream_out);
 /* get_block_and_row_id (:31-35), clamped to the last block */
 int smh_par_get_block_and_row_id(const smh_par *p, size_t row, size_t *block_out, size_t *row_out);
 int smh_par_scale(smh_par *p, double a);          /* :135-139 */
+/* exchange backend of a one-process handle (AUTO: RCCL when every block has a device of its own, else
+ * PEER); SMH_PAR_BACKEND=peer|rccl in the environment overrides AUTO.  RCCL with blocks sharing a
+ * device is SMH_ERR_INVALID; a per-rank handle is always RCCL. */
+int smh_par_set_backend(smh_par *p, int backend);
+int smh_par_backend(const smh_par *p);
+/* what SMH_EXCHANGE_AUTO resolves to for this matrix (WINDOW when the matrix is square and no block
+ * receives half of the vector or more, else ALLGATHER; NONE for one block) and the largest number of
+ * entries any block receives in a window exchange */
+int smh_par_exchange_mode(const smh_par *p, int mode, int *resolved_out, size_t *max_recv_out);
+/* The plan arithmetic on its own (pure host code, no device): block `block` of n_blocks over n_rows
+ * rows, needs[q] != 0 iff block q has entries, referencing columns [lo[q], hi[q]] (inclusive).
+ * recv_begin/end[q] = the range of q's slice this block receives in a window exchange, send_begin/
+ * end[q] = the range of its own slice it sends to q (empty: begin == end == 0).  auto_mode_out /
+ * max_recv_out as smh_par_exchange_mode (for a square matrix). */
+int smh_par_plan(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo,
+                 const uint32_t *hi, size_t block, size_t *recv_begin, size_t *recv_end,
+                 size_t *send_begin, size_t *send_end, int *auto_mode_out, size_t *max_recv_out);
+
+/* distributed DenseVec: n entries in one device buffer per local block.  upload replicates a host
+ * vector into every local buffer; download collects the OWNED slices (n == n_rows) of the local
+ * blocks at their global offsets (with one process per GPU: this rank's rows only);
+ * download_block copies local block i's whole buffer; ptr gives its device pointer. */
+int smh_par_vec_create(smh_par *p, size_t n, smh_par_vec **out);
+int smh_par_vec_destroy(smh_par_vec *v);
+size_t smh_par_vec_dim(const smh_par_vec *v);
+int smh_par_vec_upload(smh_par_vec *v, const void *host);
+int smh_par_vec_download(const smh_par_vec *v, void *host);
+int smh_par_vec_download_block(const smh_par_vec *v, size_t local_block, void *host);
+int smh_par_vec_ptr(const smh_par_vec *v, size_t local_block, void **dev_ptr_out);
+/* the intended mvp_par (:37-68), device resident: every local block writes y[b R ..) = A_b x into ITS
+ * slice of y (x must be valid on the columns the block references), then ONE exchange of y
+ * (SMH_EXCHANGE_*): afterwards y is valid everywhere (ALLGATHER) or on every block's own slice plus the
+ * columns it references (WINDOW) -- ready to be the next x.  x != y.  Asynchronous. */
+int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int variant, int exchange);
+/* the exchange on its own: v (n == n_rows) holds every block's owned slice */
+int smh_par_exchange(smh_par *p, smh_par_vec *v, int mode);
+int smh_par_synchronize(smh_par *p);
+/* y = A x on host vectors (the trait-default mvp through iter_row :86-89): blocks run concurrently,
+ * each uploading only x[min column .. max column] of its rows.  One-process handles only. */
 int smh_par_spmv(smh_par *p, const void *x_host, size_t x_len, void *y_host, int variant);
+/* ConjugateGradient::solve (linearsolver.rs:27-61) with x, r, p, Ap distributed by rows: per iteration
+ * ONE window exchange of p, the local SpMV, and two cross-block folds (p.Ap, r.r) of device-resident
+ * scalars -- each block reduces its rows to one value, the values meet (peer-visible slots / a
+ * 1-element ncclAllGather) and every block folds the same n_blocks values in the same fixed order, so
+ * all blocks take the same alpha, beta and stop decision without the host; the host polls the stop
+ * flag every check_every iterations (0: default) like smh_cg_solve.  _vec: b and x hold the owned
+ * slices (x in/out).  The host-vector form takes full-length vectors (with one process per GPU only
+ * this rank's rows of b are read and of x written).  Same statuses and outputs as smh_cg_solve. */
+int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, double tol, size_t iter_max,
+                         int variant, size_t check_every, size_t *iters_out, double *rr_out);
 int smh_par_cg_solve(smh_par *p, const void *b_host, size_t b_len, void *x_host_inout, size_t x_len,
                      double tol, size_t iter_max, int variant, size_t *iters_out, double *rr_out);
 
@@ -360,6 +447,15 @@ int smh_dev_alloc(size_t bytes, void **out);
 int smh_dev_free(void *p);
 int smh_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int smh_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+int smh_dev_memset(void *dst_dev, int value, size_t bytes, void *stream); /* asynchronous */
+/* streams and timing events (hipStream_t / hipEvent_t as void*): what bench.py brackets every launch with */
+int smh_stream_create(void **stream_out);
+int smh_stream_destroy(void *stream);
+int smh_stream_synchronize(void *stream);
+int smh_event_create(void **event_out);
+int smh_event_destroy(void *event);
+int smh_event_record(void *event, void *stream);
+int smh_event_elapsed_ms(void *start, void *stop, float *ms_out); /* waits for `stop` */
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,7 @@ def _declare(L):
     for suf, fp, ft in (("f32", _f32p, C.c_float), ("f64", _f64p, C.c_double)):
         getattr(L, "orc_spmv_" + suf).argtypes = [_sz, _u32p, _u32p, fp, fp, _sz, fp]
         getattr(L, "orc_spmv_rows_" + suf).argtypes = [_sz, _sz, _u32p, _u32p, fp, fp, _sz, fp]
+        getattr(L, "orc_spmv_omp_" + suf).argtypes = [_sz, _u32p, _u32p, fp, fp, _sz, fp, C.c_int, C.POINTER(C.c_int)]
         getattr(L, "orc_spmv_abs_" + suf).argtypes = [_sz, _u32p, _u32p, fp, fp, _f64p]
         getattr(L, "orc_spmv_abs_" + suf).restype = None
         getattr(L, "orc_mat_inner_prod_" + suf).argtypes = [_sz, _u32p, _u32p, fp, fp, fp]
@@ -161,6 +162,21 @@ def spmv(offset_rows, columns, values, x, rows=None):
                                                     _p(values, fp), _p(x, fp), len(x), _p(y, fp))
     _check(rc)
     return y
+
+
+def spmv_omp(offset_rows, columns, values, x, threads=0):
+    """orc_spmv's loop with the rows spread over all host cores -- NOT reference behaviour (the reference is serial);
+    the second CPU row of bench.py.  Returns (y, threads used); y is bit-identical to spmv()."""
+    values = np.ascontiguousarray(values)
+    suf, fp = _suf(values.dtype)
+    off, col = _c(offset_rows, np.uint32), _c(columns, np.uint32)
+    x = _c(x, values.dtype)
+    n_rows = len(off) - 1
+    y = np.zeros(n_rows, dtype=values.dtype)
+    nt = C.c_int(0)
+    _check(getattr(lib(), "orc_spmv_omp_" + suf)(n_rows, _p(off, _u32p), _p(col, _u32p), _p(values, fp), _p(x, fp), len(x),
+                                                 _p(y, fp), int(threads), C.byref(nt)))
+    return y, nt.value
 
 
 def spmv_abs(offset_rows, columns, values, x):

@@ -9,6 +9,7 @@
 #include "sparsemat_oracle.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,6 +41,28 @@
     int orc_spmv_##SUF(size_t n_rows, const uint32_t *offset_rows, const uint32_t *columns, \
                        const T *values, const T *x, size_t x_len, T *y) {                   \
         return orc_spmv_rows_##SUF(0, n_rows, offset_rows, columns, values, x, x_len, y);   \
+    }                                                                                       \
+    /* NOT reference behaviour (the reference's mvp is serial; its mvp_par is commented out,   \
+     * sparsemat_par.rs:37-68): the same per-row loop with the rows spread over all host     \
+     * cores.  Reported by bench.py beside the one-core figure so that the GPU/CPU ratio is   \
+     * not inflated by the reference being single-threaded.  Per row the       \
+     * arithmetic is identical, so y equals orc_spmv's bit for bit.  threads <= 0: OpenMP's   \
+     * default; the count actually used comes back through *threads_out. */                                                              \
+    int orc_spmv_omp_##SUF(size_t n_rows, const uint32_t *offset_rows,                      \
+                           const uint32_t *columns, const T *values, const T *x,            \
+                           size_t x_len, T *y, int threads, int *threads_out) {             \
+        int bad = 0, nt = 1;                                                                \
+        if (threads <= 0) threads = omp_get_max_threads();                                  \
+        _Pragma("omp parallel num_threads(threads)")                                        \
+        {                                                                                   \
+            _Pragma("omp single") nt = omp_get_num_threads();                               \
+            _Pragma("omp for schedule(static) reduction(|:bad)")                            \
+            for (size_t i = 0; i < n_rows; ++i)                                             \
+                bad |= orc_spmv_rows_##SUF(i, i + 1, offset_rows, columns, values, x,       \
+                                           x_len, y) != ORC_OK;                             \
+        }                                                                                   \
+        if (threads_out) *threads_out = nt;                                                 \
+        return bad ? ORC_ERR_INDEX_OOB : ORC_OK;                                            \
     }                                                                                       \
     void orc_spmv_abs_##SUF(size_t n_rows, const uint32_t *offset_rows,                     \
                             const uint32_t *columns, const T *values, const T *x,           \

@@ -46,6 +46,12 @@ int orc_spmv_rows_f32(size_t row_begin, size_t row_end, const uint32_t *offset_r
 int orc_spmv_rows_f64(size_t row_begin, size_t row_end, const uint32_t *offset_rows,
                       const uint32_t *columns, const double *values, const double *x,
                       size_t x_len, double *y);
+/* the same per-row loop with rows spread over all host cores (OpenMP) -- NOT reference behaviour (the
+ * reference is serial); bench.py's second CPU row.  y is bit-identical to orc_spmv's. */
+int orc_spmv_omp_f32(size_t n_rows, const uint32_t *offset_rows, const uint32_t *columns,
+                     const float *values, const float *x, size_t x_len, float *y, int threads, int *threads_out);
+int orc_spmv_omp_f64(size_t n_rows, const uint32_t *offset_rows, const uint32_t *columns,
+                     const double *values, const double *x, size_t x_len, double *y, int threads, int *threads_out);
 /* sum_j |a_ij * x_j| per row in f64: the scale of the componentwise parity bound */
 void orc_spmv_abs_f32(size_t n_rows, const uint32_t *offset_rows, const uint32_t *columns,
                       const float *values, const float *x, double *out);

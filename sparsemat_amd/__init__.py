@@ -15,7 +15,7 @@ from .sparsemat_crs import SparseMatCRS  # noqa: F401
 from .linearsolver import ConjugateGradient, JacobiConjugateGradient  # noqa: F401
 from . import sparsemat_par, synth  # noqa: F401
 from .sparsemat_par import SparseMatPar  # noqa: F401
-from .sparsemat_par_local import SparseMatParLocal  # noqa: F401
+from .sparsemat_par_local import Comm, ParVec, SparseMatParLocal  # noqa: F401
 
-__all__ = ["SparseMatCRS", "DenseVec", "ConjugateGradient", "SparseMatPar", "SparseMatParLocal", "SparseMatPanic", "synth",
+__all__ = ["SparseMatCRS", "DenseVec", "ConjugateGradient", "SparseMatPar", "SparseMatParLocal", "ParVec", "Comm", "SparseMatPanic", "synth",
            "sparsemat_par", "lib", "LIB_PATH"]

@@ -12,8 +12,14 @@ LIB_PATH = os.environ.get("SPARSEMAT_HIP_LIB") or os.path.join(_HERE, "libsparse
 
 SMH_OK = 0
 SMH_ERR_DIM_MISMATCH, SMH_ERR_NOT_SQUARE, SMH_ERR_INDEX_RANGE, SMH_ERR_INVALID = 1, 2, 3, 4
-SMH_ERR_HIP, SMH_ERR_OOM, SMH_ERR_NO_DEVICE, SMH_ERR_CAPACITY = 5, 6, 7, 8
+SMH_ERR_HIP, SMH_ERR_OOM, SMH_ERR_NO_DEVICE, SMH_ERR_CAPACITY, SMH_ERR_COMM = 5, 6, 7, 8, 9
 SMH_F32, SMH_F64 = 0, 1
+EXCHANGE_NONE, EXCHANGE_ALLGATHER, EXCHANGE_WINDOW, EXCHANGE_AUTO = 0, 1, 2, 3
+EXCHANGES = {"none": EXCHANGE_NONE, "allgather": EXCHANGE_ALLGATHER, "window": EXCHANGE_WINDOW, "halo": EXCHANGE_WINDOW, "auto": EXCHANGE_AUTO}
+EXCHANGE_NAMES = {EXCHANGE_NONE: "none", EXCHANGE_ALLGATHER: "allgather", EXCHANGE_WINDOW: "window", EXCHANGE_AUTO: "auto"}
+PAR_BACKEND_AUTO, PAR_BACKEND_PEER, PAR_BACKEND_RCCL = 0, 1, 2
+PAR_BACKENDS = {"auto": PAR_BACKEND_AUTO, "peer": PAR_BACKEND_PEER, "rccl": PAR_BACKEND_RCCL}
+COMM_ID_BYTES = 128
 SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ, SPMV_STREAM, SPMV_COLBLOCK = 0, 1, 2, 3, 4, 5
 VARIANTS = {"auto": SPMV_AUTO, "vector": SPMV_VECTOR, "merge": SPMV_MERGE, "seq": SPMV_SEQ, "stream": SPMV_STREAM,
             "colblock": SPMV_COLBLOCK}
@@ -102,7 +108,32 @@ SIGNATURES = {
                                 C.POINTER(C.c_double)]),
     "smh_pcg_jacobi_solve": (_int, [_vp, _vp, _sz, _vp, _sz, C.c_double, _sz, _int, C.POINTER(_sz),
                                     C.POINTER(C.c_double)]),
+    "smh_comm_unique_id": (_int, [_vp]),
+    "smh_comm_create": (_int, [_vp, _int, _int, C.POINTER(_vp)]),
+    "smh_comm_destroy": (_int, [_vp]),
+    "smh_comm_size": (_int, [_vp]),
+    "smh_comm_rank": (_int, [_vp]),
+    "smh_comm_barrier": (_int, [_vp]),
+    "smh_comm_max_f64": (_int, [_vp, C.POINTER(C.c_double)]),
     "smh_par_create": (_int, [_int, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
+    "smh_par_adopt": (_int, [_sz, C.POINTER(_vp), _sz, C.POINTER(_vp)]),
+    "smh_par_create_rank": (_int, [_vp, _sz, _vp, C.POINTER(_vp)]),
+    "smh_par_n_local_blocks": (_sz, [_vp]),
+    "smh_par_set_backend": (_int, [_vp, _int]),
+    "smh_par_backend": (_int, [_vp]),
+    "smh_par_exchange_mode": (_int, [_vp, _int, C.POINTER(_int), C.POINTER(_sz)]),
+    "smh_par_plan": (_int, [_sz, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_int), C.POINTER(_sz)]),
+    "smh_par_vec_create": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "smh_par_vec_destroy": (_int, [_vp]),
+    "smh_par_vec_dim": (_sz, [_vp]),
+    "smh_par_vec_upload": (_int, [_vp, _vp]),
+    "smh_par_vec_download": (_int, [_vp, _vp]),
+    "smh_par_vec_download_block": (_int, [_vp, _sz, _vp]),
+    "smh_par_vec_ptr": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "smh_par_spmv_dev": (_int, [_vp, _vp, _vp, _int, _int]),
+    "smh_par_exchange": (_int, [_vp, _vp, _int]),
+    "smh_par_synchronize": (_int, [_vp]),
+    "smh_par_cg_solve_vec": (_int, [_vp, _vp, _vp, C.c_double, _sz, _int, _sz, C.POINTER(_sz), C.POINTER(C.c_double)]),
     "smh_par_destroy": (_int, [_vp]),
     "smh_par_n_blocks": (_sz, [_vp]),
     "smh_par_n_rows": (_sz, [_vp]),
@@ -110,6 +141,7 @@ SIGNATURES = {
     "smh_par_nnz": (_sz, [_vp]),
     "smh_par_rows_per_block": (_sz, [_vp]),
     "smh_par_block": (_int, [_vp, _sz, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_int)]),
+    "smh_par_block_stream": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "smh_par_get_block_and_row_id": (_int, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     "smh_par_scale": (_int, [_vp, C.c_double]),
     "smh_par_spmv": (_int, [_vp, _vp, _sz, _vp, _int]),
@@ -125,6 +157,14 @@ SIGNATURES = {
     "smh_dev_free": (_int, [_vp]),
     "smh_dev_upload": (_int, [_vp, _vp, _sz]),
     "smh_dev_download": (_int, [_vp, _vp, _sz]),
+    "smh_dev_memset": (_int, [_vp, _int, _sz, _vp]),
+    "smh_stream_create": (_int, [C.POINTER(_vp)]),
+    "smh_stream_destroy": (_int, [_vp]),
+    "smh_stream_synchronize": (_int, [_vp]),
+    "smh_event_create": (_int, [C.POINTER(_vp)]),
+    "smh_event_destroy": (_int, [_vp]),
+    "smh_event_record": (_int, [_vp, _vp]),
+    "smh_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
 }
 
 _LIB = None

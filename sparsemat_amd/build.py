@@ -2,7 +2,8 @@
 
     python -m sparsemat_amd.build [--force]
 
-hipcc cross-compiles without a GPU.  The library links only against the HIP runtime.
+hipcc cross-compiles without a GPU.  The library links against the HIP runtime and RCCL (librccl.so.1: the
+multi-GPU exchange of csrc/par.hip).
 """
 import os
 import subprocess
@@ -61,7 +62,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, objsuffix=""):
             print(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join("%s:\n%s" % f for f in failed))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return lib
 

@@ -631,6 +631,7 @@ const char *smh_status_string(int status) {
         case SMH_ERR_OOM: return "out of device memory";
         case SMH_ERR_NO_DEVICE: return "no HIP device (no CPU fallback)";
         case SMH_ERR_CAPACITY: return "Maximum number of entries reached";
+        case SMH_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -1495,6 +1496,50 @@ int smh_dev_upload(void *dst_dev, const void *src_host, size_t bytes) {
 }
 int smh_dev_download(void *dst_host, const void *src_dev, size_t bytes) {
     if (bytes) SMH_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+int smh_dev_memset(void *dst_dev, int value, size_t bytes, void *stream) {
+    if (bytes) SMH_HIP(hipMemsetAsync(dst_dev, value, bytes, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+// ---- streams and timing events for hosts without a HIP binding (bench.py: HIP events around every launch) ----
+int smh_stream_create(void **stream_out) {
+    if (!stream_out) return fail(SMH_ERR_INVALID, "stream_out is NULL");
+    SMH_TRY(require_device());
+    hipStream_t s = nullptr;
+    SMH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = s;
+    return SMH_OK;
+}
+int smh_stream_destroy(void *stream) {
+    if (stream) SMH_HIP(hipStreamDestroy((hipStream_t)stream));
+    return SMH_OK;
+}
+int smh_stream_synchronize(void *stream) {
+    SMH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SMH_OK;
+}
+int smh_event_create(void **event_out) {
+    if (!event_out) return fail(SMH_ERR_INVALID, "event_out is NULL");
+    SMH_TRY(require_device());
+    hipEvent_t e = nullptr;
+    SMH_HIP(hipEventCreate(&e));
+    *event_out = e;
+    return SMH_OK;
+}
+int smh_event_destroy(void *event) {
+    if (event) SMH_HIP(hipEventDestroy((hipEvent_t)event));
+    return SMH_OK;
+}
+int smh_event_record(void *event, void *stream) {
+    SMH_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return SMH_OK;
+}
+int smh_event_elapsed_ms(void *start, void *stop, float *ms_out) {
+    if (!ms_out) return fail(SMH_ERR_INVALID, "ms_out is NULL");
+    SMH_HIP(hipEventSynchronize((hipEvent_t)stop));
+    SMH_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop));
     return SMH_OK;
 }
 

@@ -283,3 +283,83 @@ void cg_read_scalars(int dtype, const void *host_copy, int *converged, uint64_t 
 }
 
 }  // namespace smh
+
+// ---- pieces of the row-partitioned solver (par.hip) ----------------------------------------------------------------
+// The same kernels as above, cut where the partitioned solver has to fold across row blocks: a block reduces its own
+// rows to ONE value (cg_fold), the blocks' values meet (peer-visible slots or an RCCL all-gather, par.hip), and every
+// block folds the same `nb` values in the same fixed tree -- so all blocks take identical alpha / beta / stop decisions
+// without a host round trip, and the result is bitwise reproducible.
+namespace smh {
+
+template <typename T>
+static int cg_fold_t(const T *partials, uint32_t count, T *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_stage1<T>, dim3(1), dim3(kBlock), 0, s, partials, (uint64_t)count, out);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+int cg_fold(int dtype, const void *partials, uint32_t count, void *out, hipStream_t s) {
+    if (dtype == SMH_F64) return cg_fold_t<double>((const double *)partials, count, (double *)out, s);
+    return cg_fold_t<float>((const float *)partials, count, (float *)out, s);
+}
+
+#define SMH_CG_PAR_SCALAR(NAME, KERNEL)                                                                            \
+    int NAME(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s) {                                  \
+        if (dtype == SMH_F64)                                                                                      \
+            hipLaunchKernelGGL(KERNEL<double>, dim3(1), dim3(kBlock), 0, s, (CgScalars<double> *)sc, (const double *)vals, nb); \
+        else                                                                                                       \
+            hipLaunchKernelGGL(KERNEL<float>, dim3(1), dim3(kBlock), 0, s, (CgScalars<float> *)sc, (const float *)vals, nb);    \
+        SMH_HIP(hipGetLastError());                                                                                \
+        return SMH_OK;                                                                                             \
+    }
+SMH_CG_PAR_SCALAR(cg_par_set_rr, k_cg_set_rr)  // rr = fold(vals)                         linearsolver.rs:40
+SMH_CG_PAR_SCALAR(cg_par_alpha, k_cg_alpha)    // p.Ap = fold(vals); alpha; "active"       :45
+SMH_CG_PAR_SCALAR(cg_par_beta, k_cg_beta)      // r.r = fold(vals); stop test; beta        :51-56
+#undef SMH_CG_PAR_SCALAR
+
+int cg_par_init(int dtype, void *sc, double tol, size_t iter_max, hipStream_t s) {
+    if (dtype == SMH_F64) hipLaunchKernelGGL(k_cg_init<double>, dim3(1), dim3(1), 0, s, (CgScalars<double> *)sc, tol, (uint64_t)iter_max);
+    else hipLaunchKernelGGL(k_cg_init<float>, dim3(1), dim3(1), 0, s, (CgScalars<float> *)sc, tol, (uint64_t)iter_max);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+// x += round(p*alpha); r -= round(Ap*alpha) on this block's rows; partials[0..*count_out) of r.r   (:47-51)
+template <typename T>
+static int cg_par_update_t(void *sc, T *x, T *r, const T *p, const T *ap, size_t n, T *partials, uint32_t *count_out, hipStream_t s) {
+    unsigned rb = reduce_blocks(n);
+    if (rb > 512u) rb = 512u;
+    const bool vec = cg_aligned16(x) && cg_aligned16(r) && cg_aligned16(p) && cg_aligned16(ap);
+    if (vec) hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, x, r, p, ap, (uint64_t)n, partials);
+    else hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, x, r, p, ap, (uint64_t)n, partials);
+    SMH_HIP(hipGetLastError());
+    *count_out = rb;
+    return SMH_OK;
+}
+
+int cg_par_update(int dtype, void *sc, void *x, void *r, const void *p, const void *ap, size_t n, void *partials, uint32_t *count_out,
+                  hipStream_t s) {
+    if (dtype == SMH_F64)
+        return cg_par_update_t<double>(sc, (double *)x, (double *)r, (const double *)p, (const double *)ap, n, (double *)partials, count_out, s);
+    return cg_par_update_t<float>(sc, (float *)x, (float *)r, (const float *)p, (const float *)ap, n, (float *)partials, count_out, s);
+}
+
+// p = round(p*beta) + r on this block's rows   (:58-59)
+template <typename T>
+static int cg_par_p_t(void *sc, T *p, const T *r, size_t n, hipStream_t s) {
+    uint64_t pb = (n / CgVec<T>::N + kBlock) / kBlock;
+    if (pb > 512) pb = 512;
+    if (cg_aligned16(p) && cg_aligned16(r))
+        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, (uint64_t)n);
+    else
+        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, (uint64_t)n);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+int cg_par_p(int dtype, void *sc, void *p, const void *r, size_t n, hipStream_t s) {
+    if (dtype == SMH_F64) return cg_par_p_t<double>(sc, (double *)p, (const double *)r, n, s);
+    return cg_par_p_t<float>(sc, (float *)p, (const float *)r, n, s);
+}
+
+}  // namespace smh

@@ -1,50 +1,146 @@
-// par.hip -- SparseMatPar<SparseMatCRS<T,u32>> behind the C ABI: one process, one row block per device.
+// par.hip -- SparseMatPar<SparseMatCRS<T,u32>> behind the C ABI: row blocks on the GPUs of one node, the exchange of
+// the dense vector INSIDE the library (RCCL over xGMI, or direct peer reads), device-resident CG.
 //
 // Reference (sparsemat_par.rs:12-35, 86-107): n_blocks sub-matrices of R = max_n_rows / n_blocks local rows each, block b
 // owning the global rows [b R, (b+1) R) with local row ids and GLOBAL column ids; `mvp` is the serial trait default
-// walking iter_row(row) -> sub_matrices[block].iter_row(local) (the parallel mvp_par :37-68 is commented out).  Its
-// get_block_and_row_id clamps the block id to n_blocks (:32) -- one past the last block -- so a row beyond n_blocks R
-// panics; here, as SURVEY 8b prescribes, the LAST block takes the remainder (clamp to n_blocks - 1).
-// Device formulation: block b lives on device_ids[b] as an ordinary smh_crs (all kernel families apply); y = A x runs
-// the blocks concurrently, each on its own stream, on the part of x its columns reference ([min column, max column],
-// smh_crs_col_range).  The CG (linearsolver.rs:27-61) keeps x, r, p, Ap distributed by rows; per iteration the blocks
-// exchange exactly the entries of p their neighbours' columns reference (hipMemcpyPeerAsync, device to device over
-// xGMI -- a banded matrix moves a halo, not the vector), and the two dot products are folded on the host in block
-// order (deterministic).  The multi-PROCESS variant (one rank per GPU, RCCL) is sparsemat_amd/sparsemat_par.py; this
-// is the single-process drop-in for a host like the reference's, and it is testable on one GPU by placing several
-// blocks on the same device.
+// walking iter_row(row) -> sub_matrices[block].iter_row(local).  Its commented-out mvp_par (:37-68) is the design this
+// file completes: every block multiplies against the shared rhs, the results go to offset b * R, the pieces are
+// gathered.  get_block_and_row_id clamps the block id to n_blocks (:32) -- one past the last block -- so a row beyond
+// n_blocks R panics; here, as SURVEY 8b prescribes, the LAST block takes the remainder (clamp to n_blocks - 1).
+//
+// Device formulation.  Block b is an ordinary smh_crs on its device (all kernel families apply) with a stream of its
+// own.  A distributed vector (smh_par_vec) is one FULL-LENGTH buffer per local block; block b owns [b R, (b+1) R) of it.
+// y = A x: every block writes its slice of y, then ONE exchange makes y usable as the next x:
+//   ALLGATHER  in-place ncclAllGather at recvbuff + b R (+ ncclBroadcast of a ragged last block's tail)
+//   WINDOW     block q receives exactly [lo_q, hi_q] \ own slice (its column interval, a create-time statistic):
+//              grouped ncclSend / ncclRecv on slices of the vector itself -- a banded matrix moves a halo
+// Backends: RCCL (ncclCommInitAll over the blocks' devices in one process; ncclCommInitRank with one process per GPU,
+// smh_comm_*), or PEER for a one-process handle: one pull kernel per block reads the peers' slices straight through
+// peer access (all xGMI links of the destination at once; hipMemcpyPeerAsync where peer access is unavailable).  PEER is
+// also what runs when several blocks share a device, which is how the whole path -- partition, plans, exchanges, folds,
+// solver -- is exercised on a one-GPU box.
+// CG (linearsolver.rs:27-61): x, r, p, Ap distributed by rows; per iteration one WINDOW exchange of p, the local SpMV,
+// and two cross-block folds whose operands stay on the devices: each block reduces its rows to one value, the values
+// meet (PEER: slots in pinned host memory every device maps, ordered by events; RCCL: a 1-element ncclAllGather) and
+// every block folds the same n_blocks values with the same fixed tree -> identical alpha / beta / stop decision on all
+// blocks, no host round trip, bitwise reproducible.  The host polls the stop flag every check_every iterations; the
+// gated kernels of later iterations are no-ops (cg.hip), so x is exactly the x of the iteration that converged.
 #include "internal.hpp"
 
+#include <rccl/rccl.h>
+
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 using namespace smh;
 
+namespace smh {
+// cg.hip
+size_t cg_scalars_bytes(int dtype);
+void cg_read_scalars(int dtype, const void *host_copy, int *converged, uint64_t *iters, double *rr);
+int cg_fold(int dtype, const void *partials, uint32_t count, void *out, hipStream_t s);
+int cg_par_init(int dtype, void *sc, double tol, size_t iter_max, hipStream_t s);
+int cg_par_set_rr(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
+int cg_par_alpha(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
+int cg_par_beta(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
+int cg_par_update(int dtype, void *sc, void *x, void *r, const void *p, const void *ap, size_t n, void *partials,
+                  uint32_t *count_out, hipStream_t s);
+int cg_par_p(int dtype, void *sc, void *p, const void *r, size_t n, hipStream_t s);
+}  // namespace smh
+
+#define SMH_NCCL(call)                                                                                    \
+    do {                                                                                                  \
+        ncclResult_t r__ = (call);                                                                        \
+        if (r__ != ncclSuccess)                                                                           \
+            return ::smh::fail(SMH_ERR_COMM, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r__), __FILE__, __LINE__); \
+    } while (0)
+
+struct smh_comm {
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0, device = 0;
+    hipStream_t s = nullptr;  // for the host-facing helpers (barrier, max)
+    void *d_scratch = nullptr;
+};
+
 namespace {
 
 struct ParBlock {
+    size_t index = 0;             // global block id
     int device = 0;
     smh_crs *m = nullptr;
+    bool owns_m = true;
     size_t r0 = 0, r1 = 0;        // global rows [r0, r1)
-    bool needs = false;           // has entries: references x[lo..hi]
-    uint32_t lo = 0, hi = 0;
     hipStream_t s = nullptr;
-    hipEvent_t ready = nullptr;   // own slice of p written
-    void *d_x = nullptr;          // full-length staging for smh_par_spmv (n_cols entries)
-    void *d_y = nullptr;          // r1 - r0 entries
-    // CG state, allocated by the first solve
-    void *d_p = nullptr;          // full length n; valid: own slice + [lo, hi]
-    void *d_r = nullptr, *d_xl = nullptr, *d_ap = nullptr, *d_red = nullptr;
-    void *h_part = nullptr;       // pinned: one value
+    hipEvent_t ev_slice = nullptr;  // own slice of the vector being exchanged is written
+    hipEvent_t ev_done = nullptr;   // this block's pulls from its peers are complete
+    hipEvent_t ev_red[2] = {nullptr, nullptr};  // its value of fold slot 0 / 1 is written
+    ncclComm_t comm = nullptr;    // RCCL backend: this block's rank of the communicator
+    // staging of the host-vector API (smh_par_spmv)
+    void *d_x = nullptr, *d_y = nullptr;
+    // CG state (first solve)
+    void *d_r = nullptr, *d_ap = nullptr, *d_partials = nullptr, *d_sc = nullptr;
+    void *d_redv = nullptr;       // RCCL backend: 2 x n_blocks values (fold slots)
 };
+
+constexpr int kMaxPull = 32;  // segments per pull-kernel launch
+struct PullArgs {
+    const uint32_t *src[kMaxPull];
+    uint64_t w0[kMaxPull], w1[kMaxPull];  // 32-bit words [w0, w1) of the full-length buffers
+    int n;
+};
+
+// dst[w] = src_k[w] for every word w of every segment k: the peers' slices are read where they lie (peer access over
+// xGMI; plain device memory when the "peer" block shares the device).  16-byte accesses where both sides allow.
+__global__ void __launch_bounds__(kBlock) k_peer_pull(uint32_t *__restrict__ dst, PullArgs a) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    for (int k = 0; k < a.n; ++k) {
+        const uint32_t *__restrict__ src = a.src[k];
+        const uint64_t w0 = a.w0[k], w1 = a.w1[k];
+        // words [w0, head_end) one by one, [head_end, body_end) as 16-byte pieces, [body_end, w1) one by one.  A word has
+        // the same index in both buffers, so the pieces are aligned in both iff the base pointers are equally misaligned.
+        uint64_t head_end = w1, body_end = w1;
+        const uintptr_t da = reinterpret_cast<uintptr_t>(dst), sa = reinterpret_cast<uintptr_t>(src);
+        if (((da ^ sa) & 15u) == 0) {
+            const uint64_t mis = (da >> 2) & 3u;  // words by which word 0 is past a 16-byte boundary
+            const uint64_t a0 = ((w0 + mis + 3) & ~uint64_t(3)) - mis;
+            const uint64_t up = (w1 + mis) & ~uint64_t(3);
+            if (up >= mis && a0 < up - mis) { head_end = a0; body_end = up - mis; }
+        }
+        for (uint64_t w = w0 + tid; w < head_end; w += nthreads) dst[w] = src[w];
+        const uint64_t pieces = (body_end - head_end) / 4;
+        for (uint64_t q = tid; q < pieces; q += nthreads)
+            reinterpret_cast<u32x4 *>(dst + head_end)[q] = reinterpret_cast<const u32x4 *>(src + head_end)[q];
+        for (uint64_t w = body_end + tid; w < w1; w += nthreads) dst[w] = src[w];
+    }
+}
 
 }  // namespace
 
 struct smh_par {
     int dtype = SMH_F32;
-    size_t n_rows = 0, n_cols = 0, rows_per_block = 0;
-    std::vector<ParBlock> b;
+    size_t n_rows = 0, n_cols = 0, rows_per_block = 0, n_blocks = 0;
+    std::vector<ParBlock> b;        // LOCAL blocks: all of them (one process), or this rank's (one process per GPU)
+    smh_comm *rank_comm = nullptr;  // one process per GPU (borrowed)
+    int backend = SMH_PAR_BACKEND_PEER;  // resolved
+    bool comms_ready = false;
+    // column intervals of ALL blocks: block q references [lo[q], hi[q]] when needs[q]
+    std::vector<uint32_t> lo, hi;
+    std::vector<uint8_t> needs;
+    std::vector<uint8_t> peer_ok;   // [dst local * n_local + src local]: dst's device can read src's memory directly
+    void *h_red = nullptr;          // PEER backend: 2 x n_blocks fold slots in pinned host memory (all devices map it)
+    void *h_sc = nullptr;           // pinned copy of block 0's CG scalars
+    smh_par_vec *cg_p = nullptr;    // the search direction of the solver (full-length per block)
+    smh_par_vec *io_b = nullptr, *io_x = nullptr;  // staging of the host-vector solve
+};
+
+struct smh_par_vec {
+    smh_par *p = nullptr;
+    size_t n = 0;
+    std::vector<void *> d;  // per local block, n entries on its device
 };
 
 namespace {
@@ -54,6 +150,12 @@ int use(const ParBlock &blk) {
     return SMH_OK;
 }
 
+struct DeviceGuard {
+    int prev = 0;
+    DeviceGuard() { (void)hipGetDevice(&prev); }
+    ~DeviceGuard() { (void)hipSetDevice(prev); }
+};
+
 int sync_all(smh_par *p) {
     for (ParBlock &blk : p->b) {
         SMH_TRY(use(blk));
@@ -62,73 +164,432 @@ int sync_all(smh_par *p) {
     return SMH_OK;
 }
 
-// every block receives the entries of the distributed vector (own slices inside the full-length buffers `full(b)`)
-// that its columns reference and that other blocks own
-template <typename F>
-int exchange(smh_par *p, F full) {
-    const size_t vs = dtype_size(p->dtype);
-    for (ParBlock &q : p->b) {
-        if (!q.needs) continue;
-        SMH_TRY(use(q));
-        for (ParBlock &src : p->b) {
-            if (&src == &q) continue;
-            const size_t a = q.lo > src.r0 ? q.lo : src.r0, e = (size_t)q.hi + 1 < src.r1 ? (size_t)q.hi + 1 : src.r1;
-            if (a >= e) continue;
-            SMH_HIP(hipStreamWaitEvent(q.s, src.ready, 0));
-            SMH_HIP(hipMemcpyPeerAsync((char *)full(q) + a * vs, q.device, (const char *)full(src) + a * vs, src.device, (e - a) * vs, q.s));
+void block_rows(size_t n_blocks, size_t n_rows, size_t k, size_t *r0, size_t *r1) {
+    const size_t rpb = n_rows / n_blocks;  // sparsemat_par.rs:21
+    *r0 = k * rpb;
+    *r1 = k + 1 == n_blocks ? n_rows : (k + 1) * rpb;  // the last block takes the remainder
+}
+
+// the part of block src's slice that block q's columns reference (empty: *a == *e == 0)
+void recv_range(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, size_t q, size_t src,
+                size_t *a, size_t *e) {
+    *a = *e = 0;
+    if (q == src || !needs[q]) return;
+    size_t s0, s1;
+    block_rows(n_blocks, n_rows, src, &s0, &s1);
+    const size_t x0 = lo[q] > s0 ? lo[q] : s0, x1 = (size_t)hi[q] + 1 < s1 ? (size_t)hi[q] + 1 : s1;
+    if (x0 < x1) { *a = x0; *e = x1; }
+}
+
+void plan_summary(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, int *auto_mode,
+                  size_t *max_recv) {
+    size_t worst = 0;
+    for (size_t q = 0; q < n_blocks; ++q) {
+        size_t got = 0;
+        for (size_t src = 0; src < n_blocks; ++src) {
+            size_t a, e;
+            recv_range(n_blocks, n_rows, needs, lo, hi, q, src, &a, &e);
+            got += e - a;
         }
+        worst = got > worst ? got : worst;
+    }
+    if (max_recv) *max_recv = worst;
+    if (auto_mode) *auto_mode = n_blocks <= 1 ? SMH_EXCHANGE_NONE : (worst * 2 < n_rows ? SMH_EXCHANGE_WINDOW : SMH_EXCHANGE_ALLGATHER);
+}
+
+// One block has nobody to exchange with.  SMH_PAR_EXCHANGE_SINGLE=1 (test knob) still sends a lone RANK through the RCCL
+// calls -- an in-place all-gather of one rank, an empty send/receive group, the 1-element gathers of the folds -- so that
+// a one-GPU box executes the very call sequence the ranks of a node run.
+bool lone_block_skips(const smh_par *p) {
+    if (p->n_blocks > 1) return false;
+    static const bool forced = getenv("SMH_PAR_EXCHANGE_SINGLE") && atoi(getenv("SMH_PAR_EXCHANGE_SINGLE")) != 0;
+    return !(forced && p->rank_comm);
+}
+
+int resolve_mode(const smh_par *p, int mode, int *out) {
+    if (mode < SMH_EXCHANGE_NONE || mode > SMH_EXCHANGE_AUTO) return fail(SMH_ERR_INVALID, "unknown exchange mode %d", mode);
+    if (lone_block_skips(p)) { *out = SMH_EXCHANGE_NONE; return SMH_OK; }
+    if (p->n_blocks <= 1) { *out = mode == SMH_EXCHANGE_AUTO ? SMH_EXCHANGE_ALLGATHER : mode; return SMH_OK; }
+    if (mode == SMH_EXCHANGE_AUTO) {
+        int m = SMH_EXCHANGE_ALLGATHER;
+        // a window is addressed by column AND owned by row: only meaningful when the vector is both (square matrix)
+        if (p->n_rows == p->n_cols) plan_summary(p->n_blocks, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), &m, nullptr);
+        *out = m;
+        return SMH_OK;
+    }
+    if (mode == SMH_EXCHANGE_WINDOW && p->n_rows != p->n_cols)
+        return fail(SMH_ERR_INVALID, "a window exchange needs a square matrix (%zu x %zu)", p->n_rows, p->n_cols);
+    *out = mode;
+    return SMH_OK;
+}
+
+ncclDataType_t nccl_type(int dtype) { return dtype == SMH_F64 ? ncclDouble : ncclFloat; }
+
+ncclComm_t comm_of(const smh_par *p, const ParBlock &blk) { return p->rank_comm ? p->rank_comm->comm : blk.comm; }
+
+// RCCL backend of a one-process handle: one communicator rank per block, rank id = block id
+int ensure_comms(smh_par *p) {
+    if (p->comms_ready || p->rank_comm || p->n_blocks <= 1) return SMH_OK;
+    std::vector<int> devs(p->b.size());
+    for (size_t k = 0; k < p->b.size(); ++k) devs[k] = p->b[k].device;
+    for (size_t i = 0; i < devs.size(); ++i)
+        for (size_t j = i + 1; j < devs.size(); ++j)
+            if (devs[i] == devs[j])
+                return fail(SMH_ERR_INVALID, "RCCL backend: blocks %zu and %zu share device %d (one device per block needed; use the PEER backend)", i, j, devs[i]);
+    std::vector<ncclComm_t> comms(p->b.size(), nullptr);
+    SMH_NCCL(ncclCommInitAll(comms.data(), (int)p->b.size(), devs.data()));
+    for (size_t k = 0; k < p->b.size(); ++k) p->b[k].comm = comms[k];
+    p->comms_ready = true;
+    return SMH_OK;
+}
+
+// ---- the exchange -------------------------------------------------------------------------------------------------
+int exchange_rccl(smh_par *p, smh_par_vec *v, int mode) {
+    SMH_TRY(ensure_comms(p));
+    const size_t vs = dtype_size(p->dtype), nb = p->n_blocks, R = p->rows_per_block;
+    const ncclDataType_t dt = nccl_type(p->dtype);
+    if (mode == SMH_EXCHANGE_ALLGATHER) {
+        // in place: block b's slice already sits at b R of every gathered vector (count R from every rank) ...
+        SMH_NCCL(ncclGroupStart());
+        for (size_t k = 0; k < p->b.size(); ++k) {
+            ParBlock &blk = p->b[k];
+            SMH_TRY(use(blk));
+            char *buf = (char *)v->d[k];
+            SMH_NCCL(ncclAllGather(buf + blk.index * R * vs, buf, R, dt, comm_of(p, blk), blk.s));
+        }
+        SMH_NCCL(ncclGroupEnd());
+        // ... and the last block's remainder rows [n_blocks R, n_rows) follow as one broadcast from their owner
+        const size_t rem = p->n_rows - nb * R;
+        if (rem) {
+            SMH_NCCL(ncclGroupStart());
+            for (size_t k = 0; k < p->b.size(); ++k) {
+                ParBlock &blk = p->b[k];
+                SMH_TRY(use(blk));
+                char *tail = (char *)v->d[k] + nb * R * vs;
+                SMH_NCCL(ncclBroadcast(tail, tail, rem, dt, (int)(nb - 1), comm_of(p, blk), blk.s));
+            }
+            SMH_NCCL(ncclGroupEnd());
+        }
+        return SMH_OK;
+    }
+    // WINDOW: every piece is a contiguous slice of the vector itself -- sends read the block's own slice, receives land
+    // in the peers' slices (disjoint from it): ONE grouped launch of point-to-point operations, no staging, no packing
+    SMH_NCCL(ncclGroupStart());
+    for (size_t k = 0; k < p->b.size(); ++k) {
+        ParBlock &blk = p->b[k];
+        SMH_TRY(use(blk));
+        char *buf = (char *)v->d[k];
+        for (size_t q = 0; q < nb; ++q) {
+            if (q == blk.index) continue;
+            size_t a, e;
+            recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), blk.index, q, &a, &e);  // what I need of q's slice
+            if (a < e) SMH_NCCL(ncclRecv(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), blk.s));
+            recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q, blk.index, &a, &e);  // what q needs of mine
+            if (a < e) SMH_NCCL(ncclSend(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), blk.s));
+        }
+    }
+    SMH_NCCL(ncclGroupEnd());
+    return SMH_OK;
+}
+
+int exchange_peer(smh_par *p, smh_par_vec *v, int mode) {
+    const size_t vs = dtype_size(p->dtype), nb = p->n_blocks, nl = p->b.size();
+    const size_t wpe = vs / 4;  // 32-bit words per entry
+    // 1. every block's slice is complete once what its stream holds so far has run
+    for (ParBlock &blk : p->b) {
+        SMH_TRY(use(blk));
+        SMH_HIP(hipEventRecord(blk.ev_slice, blk.s));
+    }
+    // 2. every block pulls what it needs from the owners' buffers
+    std::vector<uint8_t> pulled(nl * nl, 0);  // [q * nl + src]: q read from src
+    for (size_t qi = 0; qi < nl; ++qi) {
+        ParBlock &q = p->b[qi];
+        SMH_TRY(use(q));
+        PullArgs args;
+        args.n = 0;
+        uint64_t words = 0;
+        auto flush = [&]() -> int {
+            if (args.n == 0) return SMH_OK;
+            uint64_t blocks = (words / 4 + kBlock - 1) / kBlock;
+            blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+            hipLaunchKernelGGL(k_peer_pull, dim3((unsigned)blocks), dim3(kBlock), 0, q.s, (uint32_t *)v->d[qi], args);
+            SMH_HIP(hipGetLastError());
+            args.n = 0;
+            words = 0;
+            return SMH_OK;
+        };
+        for (size_t si = 0; si < nl; ++si) {
+            if (si == qi) continue;
+            ParBlock &src = p->b[si];
+            size_t a = src.r0, e = src.r1;
+            if (mode == SMH_EXCHANGE_WINDOW)
+                recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q.index, src.index, &a, &e);
+            if (a >= e) continue;
+            pulled[qi * nl + si] = 1;
+            SMH_HIP(hipStreamWaitEvent(q.s, src.ev_slice, 0));
+            if (p->peer_ok[qi * nl + si]) {
+                args.src[args.n] = (const uint32_t *)v->d[si];
+                args.w0[args.n] = (uint64_t)a * wpe;
+                args.w1[args.n] = (uint64_t)e * wpe;
+                words += (uint64_t)(e - a) * wpe;
+                if (++args.n == kMaxPull) SMH_TRY(flush());
+            } else {  // no direct access between the two devices: the runtime stages the copy
+                SMH_HIP(hipMemcpyPeerAsync((char *)v->d[qi] + a * vs, q.device, (const char *)v->d[si] + a * vs, src.device, (e - a) * vs, q.s));
+            }
+        }
+        SMH_TRY(flush());
+        SMH_HIP(hipEventRecord(q.ev_done, q.s));
+    }
+    // 3. nobody overwrites its slice while a peer may still be reading it
+    for (size_t si = 0; si < nl; ++si) {
+        ParBlock &src = p->b[si];
+        SMH_TRY(use(src));
+        for (size_t qi = 0; qi < nl; ++qi)
+            if (pulled[qi * nl + si]) SMH_HIP(hipStreamWaitEvent(src.s, p->b[qi].ev_done, 0));
     }
     return SMH_OK;
 }
 
-double host_value(const smh_par *p, const ParBlock &blk) {
-    return p->dtype == SMH_F64 ? *(const double *)blk.h_part : (double)*(const float *)blk.h_part;
+int exchange(smh_par *p, smh_par_vec *v, int mode) {
+    int m = SMH_EXCHANGE_NONE;
+    SMH_TRY(resolve_mode(p, mode, &m));
+    if (m == SMH_EXCHANGE_NONE) return SMH_OK;
+    if (v->n != p->n_rows)
+        return fail(SMH_ERR_DIM_MISMATCH, "exchange: the vector has %zu entries, the partition owns %zu rows", v->n, p->n_rows);
+    return p->backend == SMH_PAR_BACKEND_RCCL ? exchange_rccl(p, v, m) : exchange_peer(p, v, m);
 }
 
-// sum of the blocks' partial results in block order, in the matrix's value type (one rounding per add)
-double fold(const smh_par *p) {
-    if (p->dtype == SMH_F64) {
-        double s = 0.0;
-        for (const ParBlock &blk : p->b) s = s + host_value(p, blk);
-        return s;
-    }
-    float s = 0.0f;
-    for (const ParBlock &blk : p->b) s = s + (float)host_value(p, blk);
-    return (double)s;
+// ---- cross-block folds of device-resident scalars ---------------------------------------------------------------------
+// slot s of block blk: where ITS value goes / where all n_blocks values are read by its fold kernel
+void *red_all(const smh_par *p, const ParBlock &blk, int slot) {
+    const size_t vs = dtype_size(p->dtype);
+    char *base = p->backend == SMH_PAR_BACKEND_RCCL ? (char *)blk.d_redv : (char *)p->h_red;
+    return base + (size_t)slot * p->n_blocks * vs;
 }
+void *red_mine(const smh_par *p, const ParBlock &blk, int slot) { return (char *)red_all(p, blk, slot) + blk.index * dtype_size(p->dtype); }
 
-// dot of two block-local vectors -> the block's pinned host slot (asynchronous on the block's stream)
-int enqueue_dot(smh_par *p, ParBlock &blk, const void *x, const void *y) {
-    const size_t vs = dtype_size(p->dtype), n = blk.r1 - blk.r0;
-    char *res = (char *)blk.d_red + (size_t)kReducePartials * vs;
-    if (n == 0) {
-        SMH_HIP(hipMemsetAsync(res, 0, vs, blk.s));
-    } else {
-        SMH_TRY(launch_dot(p->dtype, x, y, n, blk.d_red, res, blk.s));
+// after every local block wrote red_mine(slot): make all n_blocks values visible to every block's stream
+int combine(smh_par *p, int slot) {
+    if (lone_block_skips(p)) return SMH_OK;
+    if (p->backend == SMH_PAR_BACKEND_RCCL) {
+        SMH_TRY(ensure_comms(p));
+        SMH_NCCL(ncclGroupStart());
+        for (ParBlock &blk : p->b) {
+            SMH_TRY(use(blk));
+            SMH_NCCL(ncclAllGather(red_mine(p, blk, slot), red_all(p, blk, slot), 1, nccl_type(p->dtype), comm_of(p, blk), blk.s));
+        }
+        SMH_NCCL(ncclGroupEnd());
+        return SMH_OK;
     }
-    SMH_HIP(hipMemcpyAsync(blk.h_part, res, vs, hipMemcpyDeviceToHost, blk.s));
+    for (ParBlock &blk : p->b) {
+        SMH_TRY(use(blk));
+        SMH_HIP(hipEventRecord(blk.ev_red[slot], blk.s));
+    }
+    for (ParBlock &q : p->b) {
+        SMH_TRY(use(q));
+        for (ParBlock &src : p->b)
+            if (&src != &q) SMH_HIP(hipStreamWaitEvent(q.s, src.ev_red[slot], 0));
+    }
     return SMH_OK;
 }
 
 int ensure_cg_state(smh_par *p) {
     const size_t vs = dtype_size(p->dtype);
     for (ParBlock &blk : p->b) {
-        if (blk.d_p) continue;
+        if (blk.d_sc) continue;
         SMH_TRY(use(blk));
         const size_t n_loc = blk.r1 - blk.r0;
-        SMH_HIP(hipMalloc(&blk.d_p, (p->n_rows ? p->n_rows : 1) * vs));
         SMH_HIP(hipMalloc(&blk.d_r, (n_loc ? n_loc : 1) * vs));
-        SMH_HIP(hipMalloc(&blk.d_xl, (n_loc ? n_loc : 1) * vs));
         SMH_HIP(hipMalloc(&blk.d_ap, (n_loc ? n_loc : 1) * vs));
-        SMH_HIP(hipMalloc(&blk.d_red, ((size_t)kReducePartials + 8) * vs));
-        SMH_HIP(hipHostMalloc(&blk.h_part, 8, hipHostMallocDefault));
+        SMH_HIP(hipMalloc(&blk.d_partials, ((size_t)kReducePartials + 8) * vs));
+        SMH_HIP(hipMalloc(&blk.d_redv, 2 * p->n_blocks * vs));
+        SMH_HIP(hipMemset(blk.d_redv, 0, 2 * p->n_blocks * vs));
+        SMH_HIP(hipMalloc(&blk.d_sc, cg_scalars_bytes(p->dtype)));
     }
+    if (!p->h_red) {
+        SMH_HIP(hipHostMalloc(&p->h_red, 2 * p->n_blocks * sizeof(double), hipHostMallocPortable | hipHostMallocMapped));
+        memset(p->h_red, 0, 2 * p->n_blocks * sizeof(double));
+    }
+    if (!p->h_sc) SMH_HIP(hipHostMalloc(&p->h_sc, cg_scalars_bytes(p->dtype), hipHostMallocDefault));
+    return SMH_OK;
+}
+
+int vec_create(smh_par *p, size_t n, smh_par_vec **out) {
+    smh_par_vec *v = new (std::nothrow) smh_par_vec();
+    if (!v) return fail(SMH_ERR_OOM, "host allocation failed");
+    v->p = p;
+    v->n = n;
+    v->d.assign(p->b.size(), nullptr);
+    const size_t vs = dtype_size(p->dtype);
+    for (size_t k = 0; k < p->b.size(); ++k) {
+        int rc = use(p->b[k]);
+        if (rc == SMH_OK) {
+            hipError_t e = hipMalloc(&v->d[k], (n ? n : 1) * vs);
+            if (e == hipSuccess) e = hipMemsetAsync(v->d[k], 0, (n ? n : 1) * vs, p->b[k].s);
+            if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(par vec)", __FILE__, __LINE__);
+        }
+        if (rc != SMH_OK) {
+            for (size_t j = 0; j <= k; ++j) { (void)hipSetDevice(p->b[j].device); (void)hipFree(v->d[j]); }
+            delete v;
+            return rc;
+        }
+    }
+    *out = v;
+    return SMH_OK;
+}
+
+void vec_destroy(smh_par_vec *v) {
+    if (!v) return;
+    for (size_t k = 0; k < v->d.size(); ++k) {
+        (void)hipSetDevice(v->p->b[k].device);
+        (void)hipStreamSynchronize(v->p->b[k].s);
+        (void)hipFree(v->d[k]);
+    }
+    (void)hipGetLastError();
+    delete v;
+}
+
+int check_vec(const smh_par *p, const smh_par_vec *v, const char *what) {
+    if (!v) return fail(SMH_ERR_INVALID, "NULL %s", what);
+    if (v->p != p) return fail(SMH_ERR_INVALID, "%s belongs to another partition", what);
+    return SMH_OK;
+}
+
+// streams, events, peer access, the table of column intervals, the backend: everything after the blocks exist
+int finish_par(smh_par *p) {
+    const size_t nl = p->b.size();
+    for (ParBlock &blk : p->b) {
+        SMH_TRY(use(blk));
+        SMH_HIP(hipStreamCreateWithFlags(&blk.s, hipStreamNonBlocking));
+        SMH_HIP(hipEventCreateWithFlags(&blk.ev_slice, hipEventDisableTiming));
+        SMH_HIP(hipEventCreateWithFlags(&blk.ev_done, hipEventDisableTiming));
+        SMH_HIP(hipEventCreateWithFlags(&blk.ev_red[0], hipEventDisableTiming));
+        SMH_HIP(hipEventCreateWithFlags(&blk.ev_red[1], hipEventDisableTiming));
+    }
+    // direct device-to-device reads where the hardware offers them (xGMI)
+    p->peer_ok.assign(nl * nl, 0);
+    for (size_t a = 0; a < nl; ++a)
+        for (size_t c = 0; c < nl; ++c) {
+            if (p->b[a].device == p->b[c].device) { p->peer_ok[a * nl + c] = 1; continue; }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, p->b[a].device, p->b[c].device) == hipSuccess && can) {
+                (void)hipSetDevice(p->b[a].device);
+                const hipError_t e = hipDeviceEnablePeerAccess(p->b[c].device, 0);
+                if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) p->peer_ok[a * nl + c] = 1;
+            }
+            (void)hipGetLastError();
+        }
+    bool distinct = true;
+    for (size_t a = 0; a < nl; ++a)
+        for (size_t c = a + 1; c < nl; ++c)
+            if (p->b[a].device == p->b[c].device) distinct = false;
+    if (p->rank_comm) {
+        p->backend = SMH_PAR_BACKEND_RCCL;
+    } else {
+        p->backend = distinct && nl > 1 ? SMH_PAR_BACKEND_RCCL : SMH_PAR_BACKEND_PEER;
+        if (const char *e = getenv("SMH_PAR_BACKEND")) {
+            if (!strcmp(e, "peer")) p->backend = SMH_PAR_BACKEND_PEER;
+            else if (!strcmp(e, "rccl") && distinct) p->backend = SMH_PAR_BACKEND_RCCL;
+        }
+    }
+    return SMH_OK;
+}
+
+int own_interval(ParBlock &blk, size_t n_cols, uint8_t *needs, uint32_t *lo, uint32_t *hi) {
+    *needs = smh_crs_nnz(blk.m) != 0;
+    SMH_TRY(smh_crs_col_range(blk.m, lo, hi));
+    if (*needs && (size_t)*hi >= n_cols)
+        return fail(SMH_ERR_INDEX_RANGE, "block %zu: column %u out of range for %zu columns", blk.index, *hi, n_cols);
     return SMH_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+// ---- one rank of an RCCL communicator (one process per GPU) ----------------------------------------------------------
+int smh_comm_unique_id(void *id_out) {
+    if (!id_out) return fail(SMH_ERR_INVALID, "NULL id buffer");
+    static_assert(sizeof(ncclUniqueId) == SMH_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    SMH_NCCL(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return SMH_OK;
+}
+
+int smh_comm_create(const void *id, int n_ranks, int rank, smh_comm **out) {
+    if (!id || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(SMH_ERR_INVALID, "rank %d of %d", rank, n_ranks);
+    SMH_TRY(require_device());
+    smh_comm *c = new (std::nothrow) smh_comm();
+    if (!c) return fail(SMH_ERR_OOM, "host allocation failed");
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    c->device = current_device();
+    auto go = [&]() -> int {
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        SMH_NCCL(ncclCommInitRank(&c->comm, n_ranks, uid, rank));
+        SMH_HIP(hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking));
+        SMH_HIP(hipMalloc(&c->d_scratch, 64));
+        return SMH_OK;
+    };
+    const int rc = go();
+    if (rc != SMH_OK) {
+        char keep[512];
+        strncpy(keep, smh_last_error(), sizeof keep);
+        keep[sizeof keep - 1] = 0;
+        smh_comm_destroy(c);
+        return fail(rc, "%s", keep);
+    }
+    *out = c;
+    return SMH_OK;
+}
+
+int smh_comm_destroy(smh_comm *c) {
+    if (!c) return SMH_OK;
+    DeviceGuard g;
+    (void)hipSetDevice(c->device);
+    if (c->s) { (void)hipStreamSynchronize(c->s); (void)hipStreamDestroy(c->s); }
+    (void)hipFree(c->d_scratch);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    (void)hipGetLastError();
+    delete c;
+    return SMH_OK;
+}
+
+int smh_comm_size(const smh_comm *c) { return c ? c->n_ranks : 0; }
+int smh_comm_rank(const smh_comm *c) { return c ? c->rank : -1; }
+
+int smh_comm_max_f64(smh_comm *c, double *value_inout) {
+    if (!c || !value_inout) return fail(SMH_ERR_INVALID, "NULL argument");
+    DeviceGuard g;
+    SMH_HIP(hipSetDevice(c->device));
+    SMH_HIP(hipMemcpyAsync(c->d_scratch, value_inout, sizeof(double), hipMemcpyHostToDevice, c->s));
+    SMH_NCCL(ncclAllReduce(c->d_scratch, c->d_scratch, 1, ncclDouble, ncclMax, c->comm, c->s));
+    SMH_HIP(hipMemcpyAsync(value_inout, c->d_scratch, sizeof(double), hipMemcpyDeviceToHost, c->s));
+    SMH_HIP(hipStreamSynchronize(c->s));
+    return SMH_OK;
+}
+
+int smh_comm_barrier(smh_comm *c) {
+    if (!c) return fail(SMH_ERR_INVALID, "NULL communicator");
+    DeviceGuard g;
+    SMH_HIP(hipSetDevice(c->device));
+    SMH_HIP(hipDeviceSynchronize());  // this rank's device work first: the barrier then orders the ranks' host timelines
+    double one = 1.0;
+    return smh_comm_max_f64(c, &one);
+}
+
+// ---- construction ----------------------------------------------------------------------------------------------------
+static int par_fail_cleanup(smh_par *p, int rc, int prev_device) {
+    char keep[512];
+    strncpy(keep, smh_last_error(), sizeof keep);
+    keep[sizeof keep - 1] = 0;
+    smh_par_destroy(p);
+    (void)hipSetDevice(prev_device);
+    return fail(rc, "%s", keep);
+}
 
 int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size_t n_rows, size_t n_cols,
                    const uint32_t *offset_rows, const uint32_t *columns, const void *values, int validate, smh_par **out) {
@@ -145,17 +606,18 @@ int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size
     (void)hipGetDevice(&prev);
     smh_par *p = new (std::nothrow) smh_par();
     if (!p) return fail(SMH_ERR_OOM, "host allocation failed");
-    p->dtype = dtype; p->n_rows = n_rows; p->n_cols = n_cols; p->rows_per_block = rpb;
+    p->dtype = dtype; p->n_rows = n_rows; p->n_cols = n_cols; p->rows_per_block = rpb; p->n_blocks = n_blocks;
     p->b.resize(n_blocks);
+    p->lo.assign(n_blocks, 0); p->hi.assign(n_blocks, 0); p->needs.assign(n_blocks, 0);
     const size_t vs = dtype_size(dtype);
     auto go = [&]() -> int {
         std::vector<uint32_t> off;
         for (size_t k = 0; k < n_blocks; ++k) {
             ParBlock &blk = p->b[k];
+            blk.index = k;
             blk.device = device_ids ? device_ids[k] : (int)(k % (size_t)n_dev);
             if (blk.device < 0 || blk.device >= n_dev) return fail(SMH_ERR_INVALID, "block %zu: device %d of %d", k, blk.device, n_dev);
-            blk.r0 = k * rpb;
-            blk.r1 = k + 1 == n_blocks ? n_rows : (k + 1) * rpb;  // the last block takes the remainder
+            block_rows(n_blocks, n_rows, k, &blk.r0, &blk.r1);
             SMH_TRY(use(blk));
             const size_t rows = blk.r1 - blk.r0;
             const uint32_t base = offset_rows[blk.r0];
@@ -165,37 +627,103 @@ int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size
             for (size_t i = 0; i <= rows; ++i) off[i] = offset_rows[blk.r0 + i] - base;  // local offsets, global columns
             SMH_TRY(smh_crs_create(dtype, rows, n_cols, nnz, off.data(), columns ? columns + base : nullptr,
                                    values ? (const char *)values + (size_t)base * vs : nullptr, validate, &blk.m));
-            blk.needs = nnz != 0;
-            SMH_TRY(smh_crs_col_range(blk.m, &blk.lo, &blk.hi));
-            if (blk.needs && (size_t)blk.hi >= n_cols)
-                return fail(SMH_ERR_INDEX_RANGE, "block %zu: column %u out of range for %zu columns", k, blk.hi, n_cols);
-            SMH_HIP(hipStreamCreateWithFlags(&blk.s, hipStreamNonBlocking));
-            SMH_HIP(hipEventCreateWithFlags(&blk.ready, hipEventDisableTiming));
-            SMH_HIP(hipMalloc(&blk.d_x, (n_cols ? n_cols : 1) * vs));
-            SMH_HIP(hipMalloc(&blk.d_y, (rows ? rows : 1) * vs));
+            SMH_TRY(own_interval(blk, n_cols, &p->needs[k], &p->lo[k], &p->hi[k]));
         }
-        // direct device-to-device copies where the hardware offers them (xGMI); staged by the runtime otherwise
-        for (const ParBlock &a : p->b)
-            for (const ParBlock &c : p->b)
-                if (a.device != c.device) {
-                    int can = 0;
-                    if (hipDeviceCanAccessPeer(&can, a.device, c.device) == hipSuccess && can) {
-                        (void)hipSetDevice(a.device);
-                        (void)hipDeviceEnablePeerAccess(c.device, 0);  // (already enabled is fine)
-                    }
-                    (void)hipGetLastError();
-                }
+        return finish_par(p);
+    };
+    const int rc = go();
+    if (rc != SMH_OK) return par_fail_cleanup(p, rc, prev);
+    (void)hipSetDevice(prev);
+    *out = p;
+    return SMH_OK;
+}
+
+int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_par **out) {
+    if (!out || !blocks) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (n_blocks == 0) return fail(SMH_ERR_INVALID, "SparseMatPar needs at least one block");
+    const size_t rpb = n_rows / n_blocks;
+    if (rpb == 0) return fail(SMH_ERR_INVALID, "fewer rows (%zu) than blocks (%zu): rows per block would be 0 (sparsemat_par.rs:21,32)", n_rows, n_blocks);
+    for (size_t k = 0; k < n_blocks; ++k)
+        if (!blocks[k]) return fail(SMH_ERR_INVALID, "block %zu is NULL", k);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    smh_par *p = new (std::nothrow) smh_par();
+    if (!p) return fail(SMH_ERR_OOM, "host allocation failed");
+    p->dtype = blocks[0]->dtype; p->n_rows = n_rows; p->n_cols = blocks[0]->n_cols; p->rows_per_block = rpb; p->n_blocks = n_blocks;
+    p->b.resize(n_blocks);
+    p->lo.assign(n_blocks, 0); p->hi.assign(n_blocks, 0); p->needs.assign(n_blocks, 0);
+    auto go = [&]() -> int {
+        for (size_t k = 0; k < n_blocks; ++k) {
+            ParBlock &blk = p->b[k];
+            blk.index = k;
+            blk.m = blocks[k];
+            blk.owns_m = false;
+            blk.device = blk.m->device;
+            block_rows(n_blocks, n_rows, k, &blk.r0, &blk.r1);
+            if (blk.m->dtype != p->dtype || blk.m->n_cols != p->n_cols)
+                return fail(SMH_ERR_INVALID, "block %zu: dtype / n_cols differ from block 0", k);
+            if (blk.m->n_rows != blk.r1 - blk.r0)
+                return fail(SMH_ERR_DIM_MISMATCH, "block %zu has %zu rows, the partition of %zu rows into %zu blocks gives it %zu", k,
+                            blk.m->n_rows, n_rows, n_blocks, blk.r1 - blk.r0);
+            SMH_TRY(use(blk));
+            SMH_TRY(own_interval(blk, p->n_cols, &p->needs[k], &p->lo[k], &p->hi[k]));
+        }
+        return finish_par(p);
+    };
+    const int rc = go();
+    if (rc != SMH_OK) return par_fail_cleanup(p, rc, prev);
+    (void)hipSetDevice(prev);
+    *out = p;
+    return SMH_OK;
+}
+
+int smh_par_create_rank(smh_comm *comm, size_t n_rows, smh_crs *block, smh_par **out) {
+    if (!out || !comm || !block) return fail(SMH_ERR_INVALID, "NULL argument");
+    const size_t n_blocks = (size_t)comm->n_ranks, k = (size_t)comm->rank;
+    const size_t rpb = n_rows / n_blocks;
+    if (rpb == 0) return fail(SMH_ERR_INVALID, "fewer rows (%zu) than blocks (%zu): rows per block would be 0 (sparsemat_par.rs:21,32)", n_rows, n_blocks);
+    if (block->device != comm->device) return fail(SMH_ERR_INVALID, "the block lives on device %d, the communicator rank on device %d", block->device, comm->device);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    smh_par *p = new (std::nothrow) smh_par();
+    if (!p) return fail(SMH_ERR_OOM, "host allocation failed");
+    p->dtype = block->dtype; p->n_rows = n_rows; p->n_cols = block->n_cols; p->rows_per_block = rpb; p->n_blocks = n_blocks;
+    p->rank_comm = comm;
+    p->b.resize(1);
+    p->lo.assign(n_blocks, 0); p->hi.assign(n_blocks, 0); p->needs.assign(n_blocks, 0);
+    auto go = [&]() -> int {
+        ParBlock &blk = p->b[0];
+        blk.index = k;
+        blk.m = block;
+        blk.owns_m = false;
+        blk.device = block->device;
+        block_rows(n_blocks, n_rows, k, &blk.r0, &blk.r1);
+        if (block->n_rows != blk.r1 - blk.r0)
+            return fail(SMH_ERR_DIM_MISMATCH, "rank %zu holds %zu rows, the partition of %zu rows into %zu blocks gives it %zu", k, block->n_rows,
+                        n_rows, n_blocks, blk.r1 - blk.r0);
+        SMH_TRY(use(blk));
+        SMH_TRY(own_interval(blk, p->n_cols, &p->needs[k], &p->lo[k], &p->hi[k]));
+        SMH_TRY(finish_par(p));
+        // the ranks publish their column intervals (the exchange plan is global): 3 u32 per rank, all-gathered in place
+        std::vector<uint32_t> table(3 * n_blocks, 0);
+        table[3 * k] = p->needs[k]; table[3 * k + 1] = p->lo[k]; table[3 * k + 2] = p->hi[k];
+        uint32_t *d_table = nullptr;
+        SMH_HIP(hipMalloc((void **)&d_table, 3 * n_blocks * sizeof(uint32_t)));
+        auto gather = [&]() -> int {
+            SMH_HIP(hipMemcpyAsync(d_table, table.data(), 3 * n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, blk.s));
+            SMH_NCCL(ncclAllGather(d_table + 3 * k, d_table, 3, ncclUint32, comm->comm, blk.s));
+            SMH_HIP(hipMemcpyAsync(table.data(), d_table, 3 * n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, blk.s));
+            SMH_HIP(hipStreamSynchronize(blk.s));
+            return SMH_OK;
+        };
+        const int grc = gather();
+        (void)hipFree(d_table);
+        SMH_TRY(grc);
+        for (size_t q = 0; q < n_blocks; ++q) { p->needs[q] = (uint8_t)table[3 * q]; p->lo[q] = table[3 * q + 1]; p->hi[q] = table[3 * q + 2]; }
         return SMH_OK;
     };
     const int rc = go();
-    if (rc != SMH_OK) {
-        char keep[512];
-        strncpy(keep, smh_last_error(), sizeof keep);
-        keep[sizeof keep - 1] = 0;
-        smh_par_destroy(p);
-        (void)hipSetDevice(prev);
-        return fail(rc, "%s", keep);
-    }
+    if (rc != SMH_OK) return par_fail_cleanup(p, rc, prev);
     (void)hipSetDevice(prev);
     *out = p;
     return SMH_OK;
@@ -207,20 +735,31 @@ int smh_par_destroy(smh_par *p) {
     (void)hipGetDevice(&prev);
     for (ParBlock &blk : p->b) {
         (void)hipSetDevice(blk.device);
-        if (blk.s) { (void)hipStreamSynchronize(blk.s); (void)hipStreamDestroy(blk.s); }
-        if (blk.ready) (void)hipEventDestroy(blk.ready);
-        (void)smh_crs_destroy(blk.m);
-        (void)hipFree(blk.d_x); (void)hipFree(blk.d_y); (void)hipFree(blk.d_p); (void)hipFree(blk.d_r);
-        (void)hipFree(blk.d_xl); (void)hipFree(blk.d_ap); (void)hipFree(blk.d_red);
-        if (blk.h_part) (void)hipHostFree(blk.h_part);
+        if (blk.s) (void)hipStreamSynchronize(blk.s);
     }
+    vec_destroy(p->cg_p); vec_destroy(p->io_b); vec_destroy(p->io_x);
+    for (ParBlock &blk : p->b) {
+        (void)hipSetDevice(blk.device);
+        if (blk.comm) (void)ncclCommDestroy(blk.comm);
+        if (blk.s) (void)hipStreamDestroy(blk.s);
+        if (blk.ev_slice) (void)hipEventDestroy(blk.ev_slice);
+        if (blk.ev_done) (void)hipEventDestroy(blk.ev_done);
+        if (blk.ev_red[0]) (void)hipEventDestroy(blk.ev_red[0]);
+        if (blk.ev_red[1]) (void)hipEventDestroy(blk.ev_red[1]);
+        if (blk.owns_m) (void)smh_crs_destroy(blk.m);
+        (void)hipFree(blk.d_x); (void)hipFree(blk.d_y); (void)hipFree(blk.d_r); (void)hipFree(blk.d_ap);
+        (void)hipFree(blk.d_partials); (void)hipFree(blk.d_sc); (void)hipFree(blk.d_redv);
+    }
+    if (p->h_red) (void)hipHostFree(p->h_red);
+    if (p->h_sc) (void)hipHostFree(p->h_sc);
     (void)hipGetLastError();
     (void)hipSetDevice(prev);
     delete p;
     return SMH_OK;
 }
 
-size_t smh_par_n_blocks(const smh_par *p) { return p ? p->b.size() : 0; }
+size_t smh_par_n_blocks(const smh_par *p) { return p ? p->n_blocks : 0; }
+size_t smh_par_n_local_blocks(const smh_par *p) { return p ? p->b.size() : 0; }
 size_t smh_par_n_rows(const smh_par *p) { return p ? p->n_rows : 0; }
 size_t smh_par_n_cols(const smh_par *p) { return p ? p->n_cols : 0; }
 size_t smh_par_rows_per_block(const smh_par *p) { return p ? p->rows_per_block : 0; }
@@ -241,10 +780,16 @@ int smh_par_block(const smh_par *p, size_t block, smh_crs **crs_out, size_t *row
     return SMH_OK;
 }
 
+int smh_par_block_stream(const smh_par *p, size_t block, void **stream_out) {
+    if (!p || !stream_out || block >= p->b.size()) return fail(SMH_ERR_INVALID, "no such block");
+    *stream_out = p->b[block].s;
+    return SMH_OK;
+}
+
 int smh_par_get_block_and_row_id(const smh_par *p, size_t row, size_t *block_out, size_t *row_out) {
     if (!p || !block_out || !row_out) return fail(SMH_ERR_INVALID, "NULL argument");
     size_t k = row / p->rows_per_block;  // sparsemat_par.rs:32, clamped to the last block instead of one past it
-    if (k > p->b.size() - 1) k = p->b.size() - 1;
+    if (k > p->n_blocks - 1) k = p->n_blocks - 1;
     *block_out = k;
     *row_out = row - k * p->rows_per_block;
     return SMH_OK;
@@ -252,32 +797,171 @@ int smh_par_get_block_and_row_id(const smh_par *p, size_t row, size_t *block_out
 
 int smh_par_scale(smh_par *p, double a) {  // sparsemat_par.rs:135-139
     if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    int rc = SMH_OK;
+    DeviceGuard g;
     for (ParBlock &blk : p->b) {
-        if ((rc = use(blk)) != SMH_OK) break;
-        if ((rc = smh_crs_scale(blk.m, a)) != SMH_OK) break;
+        SMH_TRY(use(blk));
+        SMH_HIP(hipStreamSynchronize(blk.s));
+        SMH_TRY(smh_crs_scale(blk.m, a));
     }
-    (void)hipSetDevice(prev);
-    return rc;
+    return SMH_OK;
+}
+
+int smh_par_set_backend(smh_par *p, int backend) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (p->rank_comm) {
+        if (backend == SMH_PAR_BACKEND_PEER) return fail(SMH_ERR_INVALID, "one process per GPU: the exchange is RCCL");
+        return SMH_OK;
+    }
+    bool distinct = true;
+    for (size_t a = 0; a < p->b.size(); ++a)
+        for (size_t c = a + 1; c < p->b.size(); ++c)
+            if (p->b[a].device == p->b[c].device) distinct = false;
+    if (backend == SMH_PAR_BACKEND_AUTO) backend = distinct && p->b.size() > 1 ? SMH_PAR_BACKEND_RCCL : SMH_PAR_BACKEND_PEER;
+    if (backend != SMH_PAR_BACKEND_PEER && backend != SMH_PAR_BACKEND_RCCL) return fail(SMH_ERR_INVALID, "unknown backend %d", backend);
+    if (backend == SMH_PAR_BACKEND_RCCL && !distinct && p->b.size() > 1)
+        return fail(SMH_ERR_INVALID, "RCCL backend: several blocks share a device (one device per block needed)");
+    DeviceGuard g;
+    SMH_TRY(sync_all(p));
+    p->backend = backend;
+    return SMH_OK;
+}
+
+int smh_par_backend(const smh_par *p) { return p ? p->backend : SMH_PAR_BACKEND_AUTO; }
+
+int smh_par_exchange_mode(const smh_par *p, int mode, int *resolved_out, size_t *max_recv_out) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    int m = SMH_EXCHANGE_NONE;
+    SMH_TRY(resolve_mode(p, mode, &m));
+    if (resolved_out) *resolved_out = m;
+    if (max_recv_out) plan_summary(p->n_blocks, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), nullptr, max_recv_out);
+    return SMH_OK;
+}
+
+int smh_par_plan(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, size_t block,
+                 size_t *recv_begin, size_t *recv_end, size_t *send_begin, size_t *send_end, int *auto_mode_out, size_t *max_recv_out) {
+    if (n_blocks == 0 || n_rows / n_blocks == 0) return fail(SMH_ERR_INVALID, "rows per block would be 0 (sparsemat_par.rs:21,32)");
+    if (!needs || !lo || !hi || block >= n_blocks) return fail(SMH_ERR_INVALID, "bad plan arguments");
+    for (size_t q = 0; q < n_blocks; ++q) {
+        size_t a, e;
+        recv_range(n_blocks, n_rows, needs, lo, hi, block, q, &a, &e);
+        if (recv_begin) recv_begin[q] = a;
+        if (recv_end) recv_end[q] = e;
+        recv_range(n_blocks, n_rows, needs, lo, hi, q, block, &a, &e);
+        if (send_begin) send_begin[q] = a;
+        if (send_end) send_end[q] = e;
+    }
+    plan_summary(n_blocks, n_rows, needs, lo, hi, auto_mode_out, max_recv_out);
+    return SMH_OK;
+}
+
+// ---- distributed vectors -----------------------------------------------------------------------------------------------
+int smh_par_vec_create(smh_par *p, size_t n, smh_par_vec **out) {
+    if (!p || !out) return fail(SMH_ERR_INVALID, "NULL argument");
+    DeviceGuard g;
+    return vec_create(p, n, out);
+}
+
+int smh_par_vec_destroy(smh_par_vec *v) {
+    DeviceGuard g;
+    vec_destroy(v);
+    return SMH_OK;
+}
+
+size_t smh_par_vec_dim(const smh_par_vec *v) { return v ? v->n : 0; }
+
+int smh_par_vec_upload(smh_par_vec *v, const void *host) {
+    if (!v || (v->n && !host)) return fail(SMH_ERR_INVALID, "NULL argument");
+    DeviceGuard g;
+    smh_par *p = v->p;
+    const size_t vs = dtype_size(p->dtype);
+    for (size_t k = 0; k < p->b.size(); ++k) {
+        SMH_TRY(use(p->b[k]));
+        if (v->n) SMH_HIP(hipMemcpyAsync(v->d[k], host, v->n * vs, hipMemcpyHostToDevice, p->b[k].s));
+    }
+    return sync_all(p);  // the host buffer is borrowed for the call only
+}
+
+int smh_par_vec_download(const smh_par_vec *v, void *host) {
+    if (!v || !host) return fail(SMH_ERR_INVALID, "NULL argument");
+    smh_par *p = v->p;
+    if (v->n != p->n_rows) return fail(SMH_ERR_DIM_MISMATCH, "the vector has %zu entries, the partition owns %zu rows", v->n, p->n_rows);
+    DeviceGuard g;
+    const size_t vs = dtype_size(p->dtype);
+    for (size_t k = 0; k < p->b.size(); ++k) {
+        const ParBlock &blk = p->b[k];
+        SMH_TRY(use(blk));
+        if (blk.r1 > blk.r0)
+            SMH_HIP(hipMemcpyAsync((char *)host + blk.r0 * vs, (const char *)v->d[k] + blk.r0 * vs, (blk.r1 - blk.r0) * vs, hipMemcpyDeviceToHost, blk.s));
+    }
+    return sync_all(p);
+}
+
+int smh_par_vec_download_block(const smh_par_vec *v, size_t local_block, void *host) {
+    if (!v || !host || local_block >= v->d.size()) return fail(SMH_ERR_INVALID, "bad argument");
+    DeviceGuard g;
+    const ParBlock &blk = v->p->b[local_block];
+    SMH_TRY(use(blk));
+    if (v->n) SMH_HIP(hipMemcpyAsync(host, v->d[local_block], v->n * dtype_size(v->p->dtype), hipMemcpyDeviceToHost, blk.s));
+    SMH_HIP(hipStreamSynchronize(blk.s));
+    return SMH_OK;
+}
+
+int smh_par_vec_ptr(const smh_par_vec *v, size_t local_block, void **dev_ptr_out) {
+    if (!v || !dev_ptr_out || local_block >= v->d.size()) return fail(SMH_ERR_INVALID, "bad argument");
+    *dev_ptr_out = v->d[local_block];
+    return SMH_OK;
+}
+
+// ---- y = A x, device resident ---------------------------------------------------------------------------------------------
+int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int variant, int mode) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(check_vec(p, x, "x"));
+    SMH_TRY(check_vec(p, y, "y"));
+    if (x == y) return fail(SMH_ERR_INVALID, "x and y must be different vectors");
+    if (y->n != p->n_rows) return fail(SMH_ERR_DIM_MISMATCH, "Dimension mismatch");
+    DeviceGuard g;
+    const size_t vs = dtype_size(p->dtype);
+    for (size_t k = 0; k < p->b.size(); ++k) {
+        ParBlock &blk = p->b[k];
+        SMH_TRY(use(blk));
+        SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s));  // results at b R (:64)
+    }
+    return exchange(p, y, mode);
+}
+
+int smh_par_exchange(smh_par *p, smh_par_vec *v, int mode) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(check_vec(p, v, "vector"));
+    DeviceGuard g;
+    return exchange(p, v, mode);
+}
+
+int smh_par_synchronize(smh_par *p) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    DeviceGuard g;
+    return sync_all(p);
 }
 
 // y[0..n_rows) = A x on host vectors: every block gets the part of x its columns reference, all blocks run concurrently
 int smh_par_spmv(smh_par *p, const void *x_host, size_t x_len, void *y_host, int variant) {
     if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (p->rank_comm) return fail(SMH_ERR_INVALID, "smh_par_spmv takes whole host vectors: one-process handles only (use smh_par_spmv_dev)");
     if (!y_host || (x_len && !x_host)) return fail(SMH_ERR_INVALID, "NULL host vector");
     const size_t vs = dtype_size(p->dtype);
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard g;
     auto go = [&]() -> int {
         for (ParBlock &blk : p->b) {
             SMH_TRY(use(blk));
-            if (blk.needs) {
-                if ((size_t)blk.hi >= x_len)  // rhs.get(j): densevec.rs:41
-                    return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, blk.hi);
-                SMH_HIP(hipMemcpyAsync((char *)blk.d_x + (size_t)blk.lo * vs, (const char *)x_host + (size_t)blk.lo * vs,
-                                       ((size_t)blk.hi - blk.lo + 1) * vs, hipMemcpyHostToDevice, blk.s));
+            if (!blk.d_x) {
+                SMH_HIP(hipMalloc(&blk.d_x, (p->n_cols ? p->n_cols : 1) * vs));
+                SMH_HIP(hipMalloc(&blk.d_y, (blk.r1 > blk.r0 ? blk.r1 - blk.r0 : 1) * vs));
+            }
+            if (p->needs[blk.index]) {
+                const uint32_t lo = p->lo[blk.index], hi = p->hi[blk.index];
+                if ((size_t)hi >= x_len)  // rhs.get(j): densevec.rs:41
+                    return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, hi);
+                SMH_HIP(hipMemcpyAsync((char *)blk.d_x + (size_t)lo * vs, (const char *)x_host + (size_t)lo * vs, ((size_t)hi - lo + 1) * vs,
+                                       hipMemcpyHostToDevice, blk.s));
             }
             SMH_TRY(smh_crs_spmv_dev(blk.m, blk.d_x, x_len < p->n_cols ? x_len : p->n_cols, blk.d_y, variant, blk.s));
             if (blk.r1 > blk.r0)
@@ -287,93 +971,122 @@ int smh_par_spmv(smh_par *p, const void *x_host, size_t x_len, void *y_host, int
     };
     const int rc = go();
     if (rc != SMH_OK) (void)sync_all(p);
-    (void)hipSetDevice(prev);
     return rc;
 }
 
-// ConjugateGradient::solve (linearsolver.rs:27-61) on the partitioned matrix; x is updated in place.
+// ---- ConjugateGradient::solve (linearsolver.rs:27-61) on the partitioned matrix --------------------------------------------
+int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, double tol, size_t iter_max, int variant,
+                         size_t check_every, size_t *iters_out, double *rr_out) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(check_vec(p, b, "b"));
+    SMH_TRY(check_vec(p, x, "x"));
+    if (b == x) return fail(SMH_ERR_INVALID, "b and x must be different vectors");
+    if (p->n_rows != p->n_cols) return fail(SMH_ERR_NOT_SQUARE, "Matrix is not symmetric");                        // :30-32
+    if (p->n_rows != b->n || p->n_rows != x->n) return fail(SMH_ERR_DIM_MISMATCH, "Matrix and vector size mismatch");  // :33-36
+    if (check_every == 0) check_every = 8;
+    const size_t vs = dtype_size(p->dtype), n = p->n_rows;
+    const int dt = p->dtype;
+    const uint32_t nb = (uint32_t)p->n_blocks;
+    DeviceGuard g;
+    size_t iters = 0;
+    double rr = 0.0;
+    auto go = [&]() -> int {
+        SMH_TRY(ensure_cg_state(p));
+        if (!p->cg_p) SMH_TRY(vec_create(p, n, &p->cg_p));
+        smh_par_vec *pv = p->cg_p;
+        int mode = SMH_EXCHANGE_NONE;
+        SMH_TRY(resolve_mode(p, SMH_EXCHANGE_AUTO, &mode));
+        // r = b - A x (:38); p = r.clone() (:39); rr = r.r (:40)
+        SMH_TRY(exchange(p, x, mode));  // x on every block's column interval
+        for (size_t k = 0; k < p->b.size(); ++k) {
+            ParBlock &blk = p->b[k];
+            SMH_TRY(use(blk));
+            const size_t n_loc = blk.r1 - blk.r0;
+            SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], n, blk.d_r, variant, blk.s));
+            SMH_TRY(launch_ew(dt, Ew::RSubInto, blk.d_r, (const char *)b->d[k] + blk.r0 * vs, n_loc, 0.0, nullptr, blk.s));
+            SMH_HIP(hipMemcpyAsync((char *)pv->d[k] + blk.r0 * vs, blk.d_r, n_loc * vs, hipMemcpyDeviceToDevice, blk.s));
+            SMH_TRY(cg_par_init(dt, blk.d_sc, tol, iter_max, blk.s));
+            SMH_TRY(launch_dot(dt, blk.d_r, blk.d_r, n_loc, blk.d_partials, red_mine(p, blk, 1), blk.s));
+        }
+        SMH_TRY(combine(p, 1));
+        for (ParBlock &blk : p->b) {
+            SMH_TRY(use(blk));
+            SMH_TRY(cg_par_set_rr(dt, blk.d_sc, red_all(p, blk, 1), nb, blk.s));
+        }
+        size_t launched = 0;
+        int converged = 0;
+        auto poll = [&]() -> int {
+            ParBlock &b0 = p->b[0];
+            SMH_TRY(use(b0));
+            SMH_HIP(hipMemcpyAsync(p->h_sc, b0.d_sc, cg_scalars_bytes(dt), hipMemcpyDeviceToHost, b0.s));
+            SMH_TRY(sync_all(p));
+            uint64_t it64 = 0;
+            cg_read_scalars(dt, p->h_sc, &converged, &it64, &rr);
+            iters = (size_t)it64;
+            return SMH_OK;
+        };
+        while (launched < iter_max) {
+            const size_t batch = iter_max - launched < check_every ? iter_max - launched : check_every;
+            for (size_t i = 0; i < batch; ++i) {
+                SMH_TRY(exchange(p, pv, mode));  // the entries of p a block references and another owns
+                for (size_t k = 0; k < p->b.size(); ++k) {
+                    ParBlock &blk = p->b[k];
+                    SMH_TRY(use(blk));
+                    SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));                                   // :43
+                    SMH_TRY(launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, blk.r1 - blk.r0, blk.d_partials,
+                                       red_mine(p, blk, 0), blk.s));                                                            // :45
+                }
+                SMH_TRY(combine(p, 0));
+                for (size_t k = 0; k < p->b.size(); ++k) {
+                    ParBlock &blk = p->b[k];
+                    SMH_TRY(use(blk));
+                    uint32_t cnt = 0;
+                    SMH_TRY(cg_par_alpha(dt, blk.d_sc, red_all(p, blk, 0), nb, blk.s));
+                    SMH_TRY(cg_par_update(dt, blk.d_sc, (char *)x->d[k] + blk.r0 * vs, blk.d_r, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap,
+                                          blk.r1 - blk.r0, blk.d_partials, &cnt, blk.s));                                        // :47-51
+                    SMH_TRY(cg_fold(dt, blk.d_partials, cnt, red_mine(p, blk, 1), blk.s));
+                }
+                SMH_TRY(combine(p, 1));
+                for (size_t k = 0; k < p->b.size(); ++k) {
+                    ParBlock &blk = p->b[k];
+                    SMH_TRY(use(blk));
+                    SMH_TRY(cg_par_beta(dt, blk.d_sc, red_all(p, blk, 1), nb, blk.s));                                          // :52-56
+                    SMH_TRY(cg_par_p(dt, blk.d_sc, (char *)pv->d[k] + blk.r0 * vs, blk.d_r, blk.r1 - blk.r0, blk.s));           // :58-59
+                }
+            }
+            launched += batch;
+            SMH_TRY(poll());
+            if (converged) break;
+        }
+        if (iter_max == 0) SMH_TRY(poll());
+        return SMH_OK;
+    };
+    const int rc = go();
+    if (rc != SMH_OK) {
+        char keep[512];
+        strncpy(keep, smh_last_error(), sizeof keep);
+        keep[sizeof keep - 1] = 0;
+        (void)sync_all(p);
+        return fail(rc, "%s", keep);
+    }
+    if (iters_out) *iters_out = iters;
+    if (rr_out) *rr_out = rr;
+    return SMH_OK;
+}
+
 int smh_par_cg_solve(smh_par *p, const void *b_host, size_t b_len, void *x_host_inout, size_t x_len, double tol, size_t iter_max,
                      int variant, size_t *iters_out, double *rr_out) {
     if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
     if (p->n_rows != p->n_cols) return fail(SMH_ERR_NOT_SQUARE, "Matrix is not symmetric");                    // :30-32
     if (p->n_rows != b_len || p->n_rows != x_len) return fail(SMH_ERR_DIM_MISMATCH, "Matrix and vector size mismatch");  // :33-36
     if (!b_host || !x_host_inout) return fail(SMH_ERR_INVALID, "NULL host vector");
-    const size_t vs = dtype_size(p->dtype), n = p->n_rows;
-    const int dt = p->dtype;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    size_t iters = 0;
-    double rr = 0.0;
-    auto quotient = [&](double a, double c) { return dt == SMH_F64 ? a / c : (double)((float)a / (float)c); };
-    auto go = [&]() -> int {
-        SMH_TRY(ensure_cg_state(p));
-        // r = b - A x; p = r; rr = r.r
-        for (ParBlock &blk : p->b) {
-            SMH_TRY(use(blk));
-            const size_t n_loc = blk.r1 - blk.r0;
-            if (n_loc) {
-                SMH_HIP(hipMemcpyAsync(blk.d_r, (const char *)b_host + blk.r0 * vs, n_loc * vs, hipMemcpyHostToDevice, blk.s));
-                SMH_HIP(hipMemcpyAsync(blk.d_xl, (const char *)x_host_inout + blk.r0 * vs, n_loc * vs, hipMemcpyHostToDevice, blk.s));
-            }
-            if (blk.needs)
-                SMH_HIP(hipMemcpyAsync((char *)blk.d_p + (size_t)blk.lo * vs, (const char *)x_host_inout + (size_t)blk.lo * vs,
-                                       ((size_t)blk.hi - blk.lo + 1) * vs, hipMemcpyHostToDevice, blk.s));
-            SMH_TRY(smh_crs_spmv_dev(blk.m, blk.d_p, n, blk.d_ap, variant, blk.s));
-            if (n_loc) {
-                SMH_TRY(launch_ew(dt, Ew::Sub, blk.d_r, blk.d_ap, n_loc, 0.0, nullptr, blk.s));
-                SMH_HIP(hipMemcpyAsync((char *)blk.d_p + blk.r0 * vs, blk.d_r, n_loc * vs, hipMemcpyDeviceToDevice, blk.s));
-            }
-            SMH_HIP(hipEventRecord(blk.ready, blk.s));
-            SMH_TRY(enqueue_dot(p, blk, blk.d_r, blk.d_r));
-        }
-        SMH_TRY(sync_all(p));
-        rr = fold(p);
-        for (size_t k = 0; k < iter_max; ++k) {
-            // Ap = A p on every block, after the halo of p arrived; p.Ap
-            SMH_TRY(exchange(p, [](ParBlock &blk) { return blk.d_p; }));
-            for (ParBlock &blk : p->b) {
-                SMH_TRY(use(blk));
-                SMH_TRY(smh_crs_spmv_dev(blk.m, blk.d_p, n, blk.d_ap, variant, blk.s));
-                SMH_TRY(enqueue_dot(p, blk, (const char *)blk.d_p + blk.r0 * vs, blk.d_ap));
-            }
-            SMH_TRY(sync_all(p));
-            const double alpha = quotient(rr, fold(p));
-            // x += p * alpha; r -= Ap * alpha; r.r
-            for (ParBlock &blk : p->b) {
-                SMH_TRY(use(blk));
-                const size_t n_loc = blk.r1 - blk.r0;
-                if (n_loc) {
-                    SMH_TRY(launch_ew(dt, Ew::Axpy, blk.d_xl, (const char *)blk.d_p + blk.r0 * vs, n_loc, alpha, nullptr, blk.s));
-                    SMH_TRY(launch_ew(dt, Ew::Axpy, blk.d_r, blk.d_ap, n_loc, -alpha, nullptr, blk.s));
-                }
-                SMH_TRY(enqueue_dot(p, blk, blk.d_r, blk.d_r));
-            }
-            SMH_TRY(sync_all(p));
-            const double rr_prev = rr;
-            rr = fold(p);
-            ++iters;
-            if (std::sqrt(rr) < tol) break;                                                                          // :52-54
-            const double beta = quotient(rr, rr_prev);
-            for (ParBlock &blk : p->b) {  // p = p * beta + r
-                SMH_TRY(use(blk));
-                const size_t n_loc = blk.r1 - blk.r0;
-                if (n_loc) SMH_TRY(launch_ew(dt, Ew::Xpby, (char *)blk.d_p + blk.r0 * vs, blk.d_r, n_loc, beta, nullptr, blk.s));
-                SMH_HIP(hipEventRecord(blk.ready, blk.s));
-            }
-        }
-        for (ParBlock &blk : p->b) {
-            SMH_TRY(use(blk));
-            if (blk.r1 > blk.r0)
-                SMH_HIP(hipMemcpyAsync((char *)x_host_inout + blk.r0 * vs, blk.d_xl, (blk.r1 - blk.r0) * vs, hipMemcpyDeviceToHost, blk.s));
-        }
-        return sync_all(p);
-    };
-    const int rc = go();
-    if (rc != SMH_OK) (void)sync_all(p);
-    (void)hipSetDevice(prev);
-    if (iters_out) *iters_out = iters;
-    if (rr_out) *rr_out = rr;
-    return rc;
+    DeviceGuard g;
+    if (!p->io_b) SMH_TRY(vec_create(p, p->n_rows, &p->io_b));
+    if (!p->io_x) SMH_TRY(vec_create(p, p->n_rows, &p->io_x));
+    SMH_TRY(smh_par_vec_upload(p->io_b, b_host));
+    SMH_TRY(smh_par_vec_upload(p->io_x, x_host_inout));
+    SMH_TRY(smh_par_cg_solve_vec(p, p->io_b, p->io_x, tol, iter_max, variant, 0, iters_out, rr_out));
+    return smh_par_vec_download(p->io_x, x_host_inout);
 }
 
 }  // extern "C"

@@ -19,6 +19,8 @@
 //   a one-thread fix-up kernel (in storage order: they are the last entries of their rows).
 #include "internal.hpp"
 
+#include <atomic>
+
 namespace smh {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -345,11 +347,15 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
         // dynamic LDS above 64 KiB must be allowed per kernel (idempotent, cheap)
 #define SMH_R2_LAUNCH1(L, C, N)                                                                                          \
     do {                                                                                                                 \
-        static bool attr_set = false; /* once per instantiation (and never inside a stream capture) */                  \
-        if (!attr_set) {                                                                                                 \
+        /* once per (instantiation, DEVICE): function attributes are per device, and smh_par_* places blocks on       \
+           several devices.  Bit d of the mask = device d has the opt-in; a second thread racing on the same bit only   \
+           repeats an idempotent call.  (Set by the first launch, so never inside a later stream capture.) */          \
+        static std::atomic<uint64_t> attr_mask{0};                                                                       \
+        const uint64_t dev_bit = 1ull << (unsigned)(current_device() & 63);                                              \
+        if (!(attr_mask.load(std::memory_order_acquire) & dev_bit)) {                                                    \
             SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C, N, RING>),                  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                    \
-            attr_set = true;                                                                                             \
+            attr_mask.fetch_or(dev_bit, std::memory_order_release);                                                      \
         }                                                                                                                \
         hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N, RING>), grid, block, lds_bytes, s, off, col, col16, val, x, y,      \
                            (uint32_t)nnz_lim, last_chunk, phase_ptr, phases, bands);                                     \

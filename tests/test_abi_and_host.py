@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libsparsemat_hip.so lacks %s" % name
         assert name in _lib.SIGNATURES, "python binding lacks %s" % name
     assert sorted(_lib.SIGNATURES) == names, "binding declares symbols the header does not"
-    assert L.smh_abi_version() == 1
+    assert L.smh_abi_version() == 2
     out = subprocess.run(["nm", "-D", "--defined-only", sm.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (smh_[a-z0-9_]+)", out))
     assert exported == set(names), exported ^ set(names)
@@ -219,6 +219,33 @@ def test_sparsemat_par_gloo(tmp_path, world):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o
+
+
+def test_library_plan_matches_the_python_plan():
+    """smh_par_plan (the plan arithmetic csrc/par.hip exchanges by: pure host code, no device needed) against the Python
+    restatement the gloo tests run on, over random partitions incl. ragged last blocks, blocks without entries and
+    intervals that reach across several neighbours."""
+    from sparsemat_amd import sparsemat_par_local
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        n_blocks = int(rng.integers(1, 9))
+        n_rows = int(rng.integers(n_blocks, 400))
+        needs = rng.integers(0, 4, n_blocks) > 0
+        lo = rng.integers(0, n_rows, n_blocks)
+        hi = np.minimum(n_rows - 1, lo + rng.integers(0, n_rows, n_blocks))  # inclusive
+        py_needs = [(int(lo[q]), int(hi[q]) + 1) if needs[q] else (0, 0) for q in range(n_blocks)]
+        worst = 0
+        for block in range(n_blocks):
+            recv, send, mode, max_recv = sparsemat_par_local.plan(n_blocks, n_rows, needs, lo, hi, block)
+            py_send, py_recv = sparsemat_par.exchange_plan(n_blocks, n_rows, py_needs, block)
+            assert recv == py_recv and send == py_send, (n_blocks, n_rows, block)
+            worst = max(worst, sum(b - a for a, b in py_recv))
+            for q in range(n_blocks):  # what I send to q is what q expects from me
+                assert send[q] == sparsemat_par_local.plan(n_blocks, n_rows, needs, lo, hi, q)[0][block]
+        assert max_recv == worst
+        assert mode == ("none" if n_blocks == 1 else ("window" if worst * 2 < n_rows else "allgather"))
+    with pytest.raises(sm.SparseMatPanic):  # R == 0 (sparsemat_par.rs:21,32)
+        sparsemat_par_local.plan(5, 4, [1] * 5, [0] * 5, [3] * 5, 0)
 
 
 def test_exchange_plan_arithmetic():
