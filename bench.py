@@ -463,7 +463,11 @@ def main():
     }
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
-            one, allc = cpu_baseline(rows, xbuf.download(np.float32, n), ybuf.download(np.float32, n))
+            if par is None:
+                x_host, y_host = xbuf.download(np.float32, n), ybuf.download(np.float32, n)
+            else:  # (SMH_BENCH_FORCE_PAR: the partitioned path with one block)
+                x_host, y_host = x.download_block(0), y.download()
+            one, allc = cpu_baseline(rows, x_host, y_host)
             result["cpu_baseline"], result["cpu_baseline_all_cores"] = one, allc
         else:
             result["cpu_baseline"] = None

@@ -1,16 +1,23 @@
-//! Raw declarations of include/sparsemat_hip.h (ABI version 1) -- the subset the shim uses.
+//! Raw declarations of include/sparsemat_hip.h (ABI version 2) -- the subset the shim uses.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 
 #[repr(C)] pub struct smh_crs { _private: [u8; 0] }
 #[repr(C)] pub struct smh_vec { _private: [u8; 0] }
 #[repr(C)] pub struct smh_par { _private: [u8; 0] }
+#[repr(C)] pub struct smh_par_vec { _private: [u8; 0] }
+#[repr(C)] pub struct smh_comm { _private: [u8; 0] }
 
 pub const SMH_OK: c_int = 0;
 pub const SMH_ERR_DIM_MISMATCH: c_int = 1;
 pub const SMH_F32: c_int = 0;
 pub const SMH_F64: c_int = 1;
 pub const SMH_SPMV_AUTO: c_int = 0;
+pub const SMH_EXCHANGE_NONE: c_int = 0;
+pub const SMH_EXCHANGE_ALLGATHER: c_int = 1;
+pub const SMH_EXCHANGE_WINDOW: c_int = 2;
+pub const SMH_EXCHANGE_AUTO: c_int = 3;
+pub const SMH_COMM_ID_BYTES: usize = 128;
 
 extern "C" {
     pub fn smh_abi_version() -> c_int;
@@ -53,6 +60,22 @@ extern "C" {
     pub fn smh_par_cg_solve(p: *mut smh_par, b_host: *const c_void, b_len: usize, x_host_inout: *mut c_void, x_len: usize,
                             tol: c_double, iter_max: usize, variant: c_int, iters_out: *mut usize,
                             rr_out: *mut c_double) -> c_int;
+    // device-resident form: distributed vectors (one full-length buffer per local block), y = A x + ONE exchange of y
+    // inside the library (in-place ncclAllGather / grouped ncclSend+ncclRecv of the referenced window / peer reads)
+    pub fn smh_par_vec_create(p: *mut smh_par, n: usize, out: *mut *mut smh_par_vec) -> c_int;
+    pub fn smh_par_vec_destroy(v: *mut smh_par_vec) -> c_int;
+    pub fn smh_par_vec_upload(v: *mut smh_par_vec, host: *const c_void) -> c_int;
+    pub fn smh_par_vec_download(v: *const smh_par_vec, host: *mut c_void) -> c_int;
+    pub fn smh_par_spmv_dev(p: *mut smh_par, x: *const smh_par_vec, y: *mut smh_par_vec, variant: c_int, exchange: c_int) -> c_int;
+    pub fn smh_par_exchange(p: *mut smh_par, v: *mut smh_par_vec, mode: c_int) -> c_int;
+    pub fn smh_par_synchronize(p: *mut smh_par) -> c_int;
+    pub fn smh_par_cg_solve_vec(p: *mut smh_par, b: *const smh_par_vec, x: *mut smh_par_vec, tol: c_double, iter_max: usize,
+                                variant: c_int, check_every: usize, iters_out: *mut usize, rr_out: *mut c_double) -> c_int;
+    // one process per GPU: ncclGetUniqueId on one rank, ncclCommInitRank on all, the rank's own block
+    pub fn smh_comm_unique_id(id_out: *mut c_void) -> c_int;
+    pub fn smh_comm_create(id: *const c_void, n_ranks: c_int, rank: c_int, out: *mut *mut smh_comm) -> c_int;
+    pub fn smh_comm_destroy(c: *mut smh_comm) -> c_int;
+    pub fn smh_par_create_rank(comm: *mut smh_comm, n_rows: usize, block: *mut smh_crs, out: *mut *mut smh_par) -> c_int;
     pub fn smh_crs_n_rows(m: *const smh_crs) -> usize;
     pub fn smh_crs_n_cols(m: *const smh_crs) -> usize;
     pub fn smh_crs_nnz(m: *const smh_crs) -> usize;

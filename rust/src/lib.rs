@@ -202,13 +202,64 @@ impl DevicePar {
         y
     }
 
-    /// `ConjugateGradient::solve` with `M = SparseMatPar<..>`: halos of `p` travel device to device.
+    /// `ConjugateGradient::solve` with `M = SparseMatPar<..>`: halos of `p` travel device to device, the two dot products are
+    /// folded across the blocks on the devices (host vectors in and out).
     pub fn cg_solve<T: HipValue>(&self, b: &[T], x: &mut [T], tol: f64, iter_max: usize) -> (usize, f64) {
         let (mut iters, mut rr) = (0usize, 0f64);
         check(unsafe {
             ffi::smh_par_cg_solve(self.handle, b.as_ptr() as *const c_void, b.len(), x.as_mut_ptr() as *mut c_void, x.len(),
                                   tol, iter_max, ffi::SMH_SPMV_AUTO, &mut iters, &mut rr)
         });
+        (iters, rr)
+    }
+}
+
+/// A `DenseVec` distributed over the blocks of a `DevicePar`: block `b` owns entries `[b R, (b+1) R)`; every block keeps a
+/// full-length device buffer, valid as far as the last upload / exchange made it.
+pub struct DeviceParVec<'a> {
+    handle: *mut ffi::smh_par_vec,
+    par: &'a DevicePar,
+}
+
+impl<'a> DeviceParVec<'a> {
+    pub fn from_slice<T: HipValue>(par: &'a DevicePar, host: &[T]) -> Self {
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ffi::smh_par_vec_create(par.handle, host.len(), &mut handle) });
+        check(unsafe { ffi::smh_par_vec_upload(handle, host.as_ptr() as *const c_void) });
+        DeviceParVec { handle, par }
+    }
+    pub fn zeros(par: &'a DevicePar) -> Self {
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ffi::smh_par_vec_create(par.handle, par.n_rows, &mut handle) });
+        DeviceParVec { handle, par }
+    }
+    pub fn to_vec<T: HipValue + Default>(&self) -> Vec<T> {
+        let mut out = vec![T::default(); self.par.n_rows];
+        check(unsafe { ffi::smh_par_vec_download(self.handle, out.as_mut_ptr() as *mut c_void) });
+        out
+    }
+}
+
+impl<'a> Drop for DeviceParVec<'a> {
+    fn drop(&mut self) {
+        unsafe { ffi::smh_par_vec_destroy(self.handle) };
+    }
+}
+
+impl DevicePar {
+    /// The reference's intended `mvp_par` (src/sparsemat_par.rs:37-68), device resident: every block multiplies against the
+    /// shared `x`, writes its slice of `y` at `b * R`, then ONE exchange inside the library (RCCL all-gather, or only the
+    /// entries each block references) makes `y` usable as the next `x`.  Asynchronous; `synchronize` waits.
+    pub fn mvp_dev(&self, x: &DeviceParVec, y: &mut DeviceParVec) {
+        check(unsafe { ffi::smh_par_spmv_dev(self.handle, x.handle, y.handle, ffi::SMH_SPMV_AUTO, ffi::SMH_EXCHANGE_AUTO) });
+    }
+    pub fn synchronize(&self) {
+        check(unsafe { ffi::smh_par_synchronize(self.handle) });
+    }
+    /// `ConjugateGradient::solve` on distributed vectors: scalars stay on the devices, folded across blocks in a fixed order.
+    pub fn cg_solve_dev(&self, b: &DeviceParVec, x: &mut DeviceParVec, tol: f64, iter_max: usize) -> (usize, f64) {
+        let (mut iters, mut rr) = (0usize, 0f64);
+        check(unsafe { ffi::smh_par_cg_solve_vec(self.handle, b.handle, x.handle, tol, iter_max, ffi::SMH_SPMV_AUTO, 0, &mut iters, &mut rr) });
         (iters, rr)
     }
 }
