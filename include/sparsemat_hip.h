@@ -61,8 +61,12 @@ typedef enum {
     SMH_SPMV_STREAM = 4, /* K1s: short rows; dense entry stream, rounded products in LDS,   */
                          /* one thread folds a row in storage order: fast AND bit-exact     */
                          /* (stencil-like matrices stream 16-bit column codes, built once)  */
-    SMH_SPMV_COLBLOCK = 5 /* K2c: columns without locality and x larger than an L2: the      */
+    SMH_SPMV_COLBLOCK = 5, /* K2c: columns without locality and x larger than an L2: the     */
                          /* device copy is split into blocks of 2^19 columns, y += A_b x    */
+    SMH_SPMV_COLFUSED = 6 /* K2f: the same blocking in ONE sweep over y: a wave keeps the    */
+                         /* sums of its rows in registers while all waves walk the column   */
+                         /* blocks together (AUTO's choice when the rows are of similar     */
+                         /* length; runs K2c when a (row, block) pair exceeds 255 entries)  */
 } smh_spmv_variant;
 
 typedef struct smh_crs smh_crs; /* device-resident SparseMatCRS<T,u32>  (sparsemat_crs.rs:9-17) */
@@ -213,6 +217,20 @@ int smh_crs_set_colblock_shift(smh_crs *m, uint32_t shift); /* block = 2^shift c
 int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int *rows_per_thread_out,
                      double *span_fraction_out, uint32_t *offsets_out, uint32_t *columns_out,
                      void *values_out);
+
+/* K2f, the fused column-blocked copy (built on first use; integer structure, checked bit-exact in tests): rows are
+ * grouped into tiles -- tile t = rows [tile_rows[t], tile_rows[t+1]) = 64 lanes x h consecutive rows each, h <=
+ * rows_per_lane chosen greedily in row order so that a tile holds at most 1.25x the entries of a mean full-height tile
+ * (h = 1 when even 64 rows exceed that) -- and columns into blocks of 2^shift; the entries are sorted by (tile, block,
+ * row, storage order).  segments_out[t * n_blocks + b] = position of the first entry of (tile t, block b)
+ * (n_tiles * n_blocks + 1 values), counts_out[((t * n_blocks + b) * 64 + lane) * rows_per_lane + j] = entries of row
+ * tile_rows[t] + lane * h + j in block b (one byte each; zero for j >= h), columns_out / values_out [nnz] the permuted
+ * entries.  Call with NULL arrays for the sizes.  *fits_out == 0: a (row, block) pair holds more than 255 entries,
+ * there is no such copy (SMH_SPMV_COLFUSED then runs K2c).  Block width: smh_crs_set_colblock_shift, default 2^18
+ * columns; more than 255 blocks is SMH_ERR_INVALID. */
+int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_blocks_out, uint32_t *rows_per_lane_out,
+                     size_t *n_tiles_out, uint32_t *tile_rows_out, uint32_t *segments_out, uint8_t *counts_out,
+                     uint32_t *columns_out, void *values_out);
 
 /* SparseMatrix::mvp (sparsematrix.rs:146-158) == `A * v` (Mul, sparsematrix.rs:435-443):
  * y[0..n_rows) = A.x.  x_len is x.dim(); a column index >= x_len is SMH_ERR_INDEX_RANGE

@@ -147,6 +147,21 @@ static void drop_colblock(smh_crs *m) {
     m->d_cb_off = m->d_cb_col = nullptr;
     m->d_cb_val = nullptr;
     m->cb_built = false;
+    (void)hipFree(m->d_cf_seg); (void)hipFree(m->d_cf_cnt); (void)hipFree(m->d_cf_col); (void)hipFree(m->d_cf_val);
+    (void)hipFree(m->d_cf_tile_row); (void)hipFree(m->d_cf_progress);
+    m->d_cf_seg = m->d_cf_col = m->d_cf_tile_row = m->d_cf_progress = nullptr;
+    m->d_cf_cnt = nullptr;
+    m->d_cf_val = nullptr;
+    m->cf_built = m->cf_ok = false;
+}
+// K2f geometry: blocks of 2^18 columns (1 MiB of f32 x, 2 MiB of f64 x): its waves walk the blocks without a barrier and
+// spread over a few of them, so the L2 has to hold more than one (measured on C2-uniform, f32: 2^18 2.05 ms, 2^19 2.40 ms);
+// a forced width applies to both blocked variants
+static uint32_t cf_shift_for(const smh_crs *m) { return m->cb_forced_shift ? m->cb_forced_shift : 18u; }
+static size_t cf_blocks_for(const smh_crs *m) {
+    const uint64_t w = 1ull << cf_shift_for(m);
+    const uint64_t b = ((uint64_t)m->n_cols + w - 1) / w;
+    return (size_t)(b ? b : 1);
 }
 // x too large for the L2s AND rows whose columns span a large part of it (statistic taken at create time for
 // matrices with more than 8 MiB of x): gathers would miss L1 and L2 -> column-blocked execution
@@ -160,7 +175,18 @@ static bool wants_colblock(const smh_crs *m) {
 
 static int resolve_variant(const smh_crs *m, int variant) {
     if (variant != SMH_SPMV_AUTO) return variant;
-    if (wants_colblock(m)) return SMH_SPMV_COLBLOCK;
+    if (wants_colblock(m)) {
+        // one sweep over y (K2f) unless its byte table cannot describe the matrix / it was switched off
+        static const bool fused_off = getenv("SMH_COLBLOCK_FUSED") && atoi(getenv("SMH_COLBLOCK_FUSED")) == 0;  // tuning knob
+        if (fused_off || (m->cf_built && !m->cf_ok) || cf_blocks_for(m) > 255) return SMH_SPMV_COLBLOCK;
+        // K2f's waves keep their tiles for the whole sweep: that only works while they stay together, i.e. for rows of
+        // similar length.  Skewed rows (BASELINE C3, power law 1..2048) let them drift over all column blocks at once
+        // -- 5.2-5.6 ms against K2c's 3.25 ms, and a lock step costs more than it recovers (profiles/r02_k2f_sweep.log) --
+        // so those stay with the per-block launches, whose tiles the dispatcher hands out dynamically.
+        const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
+        if ((double)m->max_row_len > 2.0 * mean + 8.0) return SMH_SPMV_COLBLOCK;
+        return SMH_SPMV_COLFUSED;
+    }
     const int lanes = mean_lanes(m);
     // short rows (stencils, FEM): the dense CSR-stream kernel (a tile denser than its LDS stage takes several passes)
     const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
@@ -382,6 +408,27 @@ static int ensure_colblock(smh_crs *m) {
     return SMH_OK;
 }
 
+// K2f: build the fused column-blocked copy, once per matrix (cf_ok == false afterwards: not describable -> K2c)
+static int ensure_colfused(smh_crs *m) {
+    if (m->cf_built) return SMH_OK;
+    const size_t blocks = cf_blocks_for(m);
+    if (blocks > 255) return fail(SMH_ERR_INVALID, "fused column-blocked variant: %zu column blocks (supported: 1..255)", blocks);
+    uint32_t rt = 16;
+    if (const char *e = getenv("SMH_COLFUSED_RT")) {  // tuning knob: rows per lane, 8 or 16
+        if (atoi(e) == 8) rt = 8;
+    }
+    bool fits = false;
+    SMH_TRY(build_colfused(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, cf_shift_for(m), blocks, rt, &m->cf_tiles,
+                           &m->d_cf_tile_row, &m->d_cf_seg, &m->d_cf_cnt, &m->d_cf_col, &m->d_cf_val, &fits, m->stream));
+    if (fits) SMH_HIP(hipMalloc((void **)&m->d_cf_progress, 8 * blocks * 16 * sizeof(uint32_t)));  // per (XCD, block) lock-step counters, 16 slots each
+    m->cf_shift = cf_shift_for(m);
+    m->cf_blocks = blocks;
+    m->cf_rt = rt;
+    m->cf_ok = fits;
+    m->cf_built = true;
+    return SMH_OK;
+}
+
 // K1s: 16-bit column codes, once per matrix.  Kept only when EVERY tile has a description (stencils, bands): the kernel
 // variant then has no per-tile branch; any other matrix streams its u32 columns as before and nothing stays allocated.
 static int ensure_stream_codes(smh_crs *m) {
@@ -514,6 +561,13 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt,
                                       single_pass, dot_partials, code, cwin, s);
         }
+        case SMH_SPMV_COLFUSED: {
+            SMH_TRY(ensure_colfused(m));
+            if (m->cf_ok)
+                return launch_spmv_colfused(m->dtype, m->cf_rt, m->d_cf_tile_row, m->cf_tiles, m->d_cf_seg, m->d_cf_cnt, m->d_cf_col, m->d_cf_val,
+                                            x, y, m->n_rows, m->nnz, (uint32_t)m->cf_blocks, m->d_cf_progress, m->device, s);
+        }
+        [[fallthrough]];  // a (row, block) pair with more than 255 entries: the per-block launches
         case SMH_SPMV_COLBLOCK: {
             SMH_TRY(ensure_colblock(m));
             for (size_t b = 0; b < m->cb_blocks; ++b)
@@ -911,7 +965,10 @@ int smh_crs_destroy(smh_crs *m) {
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
     (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16); (void)hipFree(m->d_ring_win);
     (void)hipFree(m->d_stream_win); (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
-    (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
+    (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);
+    (void)hipFree(m->d_cf_seg); (void)hipFree(m->d_cf_cnt); (void)hipFree(m->d_cf_col); (void)hipFree(m->d_cf_val);
+    (void)hipFree(m->d_cf_tile_row); (void)hipFree(m->d_cf_progress);
+    (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
     return SMH_OK;
@@ -955,6 +1012,7 @@ int smh_crs_scale(smh_crs *m, double a) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(launch_scale_values(m->dtype, m->d_val, m->nnz, a, m->stream));
     if (m->cb_built) SMH_TRY(launch_scale_values(m->dtype, m->d_cb_val, m->nnz, a, m->stream));
+    if (m->cf_built && m->cf_ok) SMH_TRY(launch_scale_values(m->dtype, m->d_cf_val, m->nnz, a, m->stream));
     SMH_HIP(hipStreamSynchronize(m->stream));
     return SMH_OK;
 }
@@ -980,6 +1038,27 @@ int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int 
         SMH_HIP(hipMemcpy(offsets_out, m->d_cb_off, m->cb_blocks * (m->n_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (columns_out && m->nnz) SMH_HIP(hipMemcpy(columns_out, m->d_cb_col, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (values_out && m->nnz) SMH_HIP(hipMemcpy(values_out, m->d_cb_val, m->nnz * dtype_size(m->dtype), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_blocks_out, uint32_t *rows_per_lane_out,
+                     size_t *n_tiles_out, uint32_t *tile_rows_out, uint32_t *segments_out, uint8_t *counts_out, uint32_t *columns_out,
+                     void *values_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(ensure_colfused(m));
+    const size_t tile_rows = (size_t)64 * m->cf_rt, n_tiles = m->cf_ok ? m->cf_tiles : 0;
+    if (fits_out) *fits_out = m->cf_ok ? 1 : 0;
+    if (shift_out) *shift_out = m->cf_shift;
+    if (n_blocks_out) *n_blocks_out = m->cf_blocks;
+    if (rows_per_lane_out) *rows_per_lane_out = m->cf_rt;
+    if (n_tiles_out) *n_tiles_out = n_tiles;
+    if (!m->cf_ok) return SMH_OK;
+    SMH_HIP(hipStreamSynchronize(m->stream));
+    if (tile_rows_out) SMH_HIP(hipMemcpy(tile_rows_out, m->d_cf_tile_row, (n_tiles + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (segments_out) SMH_HIP(hipMemcpy(segments_out, m->d_cf_seg, (n_tiles * m->cf_blocks + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (counts_out && n_tiles) SMH_HIP(hipMemcpy(counts_out, m->d_cf_cnt, n_tiles * m->cf_blocks * tile_rows, hipMemcpyDeviceToHost));
+    if (columns_out && m->nnz) SMH_HIP(hipMemcpy(columns_out, m->d_cf_col, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (values_out && m->nnz) SMH_HIP(hipMemcpy(values_out, m->d_cf_val, m->nnz * dtype_size(m->dtype), hipMemcpyDeviceToHost));
     return SMH_OK;
 }
 
@@ -1071,6 +1150,9 @@ int smh_crs_prepare(smh_crs *m, int variant) {
         }
         case SMH_SPMV_MERGE: return ensure_merge_ws(m);
         case SMH_SPMV_COLBLOCK: return ensure_colblock(m);
+        case SMH_SPMV_COLFUSED:
+            SMH_TRY(ensure_colfused(m));
+            return m->cf_ok ? SMH_OK : ensure_colblock(m);
         case SMH_SPMV_STREAM: return m->use_stream_win == 1 ? ensure_stream_windows(m) : ensure_stream_codes(m);
         case SMH_SPMV_SEQ: return SMH_OK;
         default: return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);

@@ -77,6 +77,13 @@ int launch_spmv_stream_block(int dtype, const uint32_t *off, const uint32_t *col
 int build_colblock(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz,
                    uint32_t shift, size_t n_blocks, uint32_t **off2_out, uint32_t **col2_out, void **val2_out,
                    hipStream_t s);
+// K2f (column-blocked, one sweep over y; spmv_colfused.hip)
+int build_colfused(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t shift,
+                   size_t n_blocks, uint32_t rt, size_t *n_tiles_out, uint32_t **tile_row_out, uint32_t **seg_out, uint8_t **cnt_out,
+                   uint32_t **col2_out, void **val2_out, bool *fits_out, hipStream_t s);
+int launch_spmv_colfused(int dtype, uint32_t rt, const uint32_t *tile_row, size_t n_tiles, const uint32_t *seg, const uint8_t *cnt,
+                         const uint32_t *col, const void *val, const void *x, void *y, size_t n_rows, size_t nnz, uint32_t n_blocks,
+                         uint32_t *progress, int device, hipStream_t s);
 // on-device assembly (assemble.hip): add_to/set stream -> CRS; sort_row for all rows.  Device pointers.
 int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t *cols, const void *vals, const uint8_t *ops,
                       bool reverse_rows, bool all_set, bool repeats_adjacent, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
@@ -177,6 +184,14 @@ struct smh_crs {
     uint32_t *d_cb_off = nullptr, *d_cb_col = nullptr;
     void *d_cb_val = nullptr;
     double span_fraction = 0.0;  // mean column span of a 64-row tile / n_cols (1: no locality at all)
+    // K2f fused column-blocked copy (lazy)
+    bool cf_built = false;       // the build was attempted (cf_ok: and the byte table could describe the matrix)
+    bool cf_ok = false;
+    uint32_t cf_shift = 0, cf_rt = 0;
+    size_t cf_blocks = 0, cf_tiles = 0;
+    uint32_t *d_cf_seg = nullptr, *d_cf_col = nullptr, *d_cf_tile_row = nullptr, *d_cf_progress = nullptr;
+    uint8_t *d_cf_cnt = nullptr;
+    void *d_cf_val = nullptr;
     // K1r plan (lazy)
     bool ring_planned = false;
     unsigned ring_blocks = 0;

@@ -189,11 +189,30 @@ class SparseMatCRS:
     def resolved_variant(self):
         v, lanes = C.c_int(), C.c_int()
         check(lib().smh_crs_resolved_variant(self._h, C.byref(v), C.byref(lanes)))
-        return {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock"}[v.value], lanes.value
+        return {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused"}[v.value], lanes.value
 
     def set_colblock_shift(self, shift):
         """K2c: column blocks of 2**shift columns (0: automatic, 2 MiB of x)."""
         check(lib().smh_crs_set_colblock_shift(self._h, shift))
+
+    def colfused(self, arrays=True):
+        """The K2f copy (``smh_crs_colfused``): dict with fits, shift, n_blocks, rows_per_lane, n_tiles and -- with
+        ``arrays`` -- tile_rows, segments, counts, columns, values (entries sorted by (tile, block, row, storage order))."""
+        fits, sh, nb, rt, nt = C.c_int(), C.c_uint32(), C.c_size_t(), C.c_uint32(), C.c_size_t()
+        check(lib().smh_crs_colfused(self._h, C.byref(fits), C.byref(sh), C.byref(nb), C.byref(rt), C.byref(nt), None, None, None, None, None))
+        out = {"fits": bool(fits.value), "shift": sh.value, "n_blocks": nb.value, "rows_per_lane": rt.value, "n_tiles": nt.value}
+        if arrays and out["fits"]:
+            nnz = self.n_non_zero_entries()
+            tiles = np.zeros(nt.value + 1, np.uint32)
+            seg = np.zeros(nt.value * nb.value + 1, np.uint32)
+            cnt = np.zeros(nt.value * nb.value * 64 * rt.value, np.uint8)
+            col = np.zeros(nnz, np.uint32)
+            val = np.zeros(nnz, self._dtype)
+            check(lib().smh_crs_colfused(self._h, None, None, None, None, None, tiles.ctypes.data, seg.ctypes.data,
+                                         cnt.ctypes.data if len(cnt) else None, col.ctypes.data if nnz else None,
+                                         val.ctypes.data if nnz else None))
+            out.update(tile_rows=tiles, segments=seg, counts=cnt, columns=col, values=val)
+        return out
 
     def colblock(self, arrays=True):
         """K2c column-blocked copy: dict(shift, n_blocks, rows_per_thread, span_fraction[, offsets[B, n_rows+1],

@@ -112,12 +112,12 @@ def test_colblock_follows_value_updates_and_edge_shapes(gpu):
 
 
 def test_auto_picks_colblock_only_without_column_locality(gpu):
-    """x of 12 MB (f32): uniform columns -> K2c; banded columns -> K1r as before.  Parity on both."""
+    """x of 12 MB (f32): uniform columns -> column-blocked (K2f); banded columns -> K1r as before.  Parity on both."""
     rows, n, k = 200_000, 3_000_000, 16
     m_u = synth.crs_fixed(synth.SEED_MATRIX, 1, n, k, np.float32, 0, rows)
-    assert m_u.resolved_variant()[0] == "colblock"
+    assert m_u.resolved_variant()[0] == "colfused"  # the one-sweep form of the blocking (K2f)
     cb = m_u.colblock(arrays=False)
-    assert cb["n_blocks"] == 6 and cb["span_fraction"] > 0.9
+    assert cb["n_blocks"] == 6 and cb["span_fraction"] > 0.9 and m_u.colfused(arrays=False)["n_blocks"] == 12
     off, col, val = m_u.raw_parts()
     x = oracle.gen_x(synth.SEED_X, n, np.float32)
     y = m_u.mvp(x)
@@ -145,7 +145,7 @@ def test_cg_on_a_matrix_without_locality_runs_colblock(gpu):
     gather = np.repeat(src - off_p[:-1].astype(np.int64), lens_p) + np.arange(int(off_p[-1]))
     col_p, val_p = perm[col[gather]], val[gather]
     m = sm.SparseMatCRS.from_raw_parts(n, n, off_p, col_p, val_p)
-    assert m.resolved_variant()[0] == "colblock" and m.colblock(arrays=False)["n_blocks"] == 3
+    assert m.resolved_variant()[0] == "colfused" and m.colfused(arrays=False)["n_blocks"] == 6  # 2^18 columns of f64 each
     b = oracle.spmv(off_p, col_p, val_p, np.ones(n, dtype))
     iters = 40
     x_ref, it_ref, rr_ref = oracle.cg(n, n, off_p, col_p, val_p, b, np.zeros(n, dtype), tol=1e-30, iter_max=iters)
@@ -155,3 +155,130 @@ def test_cg_on_a_matrix_without_locality_runs_colblock(gpu):
     assert cg.iterations == it_ref == iters
     assert abs(cg.r_norm_squared - rr_ref) <= 1e-9 * rr_ref
     np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=1e-10)
+
+
+# ---- K2f: the same blocking in one sweep over y (spmv_colfused.hip) ---------------------------------------------------
+def fused_tiles(off, rt):
+    """The greedy tiling: in row order, a tile takes 64 * h rows with the largest h <= rt that keeps it within 1.25x the
+    entries of a mean full-height tile (h = 1 if even 64 rows exceed that); the last tile takes what is left."""
+    n_rows, nnz = len(off) - 1, int(off[-1])
+    target = int(1.25 * (nnz * 64.0 * rt / n_rows)) + 1 if n_rows else 0
+    o = off.astype(np.int64)
+    tiles, r = [], 0
+    while r < n_rows:
+        tiles.append(r)
+        h = 1
+        for cand in range(rt, 0, -1):
+            if o[min(n_rows, r + 64 * cand)] - o[r] <= target:
+                h = cand
+                break
+        r = min(n_rows, r + 64 * h)
+    return np.array(tiles + [n_rows], np.int64)
+
+
+def fused_reference(off, col, val, n_cols, shift, rt):
+    """The K2f copy restated in numpy: entries sorted by (tile, column block, row, storage order); one u32 per
+    (tile, block) -- where its entries start -- and one byte per (row, block)."""
+    n_rows = len(off) - 1
+    lens = np.diff(off.astype(np.int64))
+    n_blocks = max(1, -(-n_cols // (1 << shift)))
+    tile_rows = 64 * rt
+    tiles = fused_tiles(off, rt)
+    n_tiles = len(tiles) - 1
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), lens)
+    blk = (col >> np.uint32(shift)).astype(np.int64)
+    tile_of_row = np.searchsorted(tiles, np.arange(n_rows), side="right") - 1
+    h_of_tile = (np.diff(tiles) + 63) // 64
+    tile = tile_of_row[rows]
+    order = np.lexsort((rows, blk, tile))  # stable: ties keep the storage order
+    cnt = np.zeros(n_tiles * n_blocks * tile_rows, np.int64)
+    inside = rows - tiles[tile]
+    h = h_of_tile[tile]
+    np.add.at(cnt, ((tile * n_blocks + blk) * 64 + inside // h) * rt + inside % h, 1)
+    per_seg = cnt.reshape(n_tiles * n_blocks, tile_rows).sum(axis=1) if n_tiles else np.zeros(0, np.int64)
+    seg = np.concatenate(([0], np.cumsum(per_seg))).astype(np.uint32)
+    return n_blocks, tiles.astype(np.uint32), seg, cnt, col[order], val[order]
+
+
+def block_ordered_reference(off, col, val, x, shift):
+    """A row's entries taken column block by column block (storage order inside a block), folded sequentially like the
+    reference folds a row: the order in which K2f adds."""
+    lens = np.diff(off.astype(np.int64))
+    rows = np.repeat(np.arange(len(off) - 1, dtype=np.int64), lens)
+    order = np.lexsort(((col >> np.uint32(shift)).astype(np.int64), rows))
+    return oracle.spmv(off, col[order], val[order], x)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("kind", ["uniform32", "ragged", "long_rows", "empty_heavy", "one_tile"])
+def test_colfused_split_and_product(gpu, dtype, kind):
+    rng = np.random.default_rng({"uniform32": 21, "ragged": 22, "long_rows": 23, "empty_heavy": 24, "one_tile": 25}[kind])
+    n_rows, n_cols, shift = 6007, 5001, 8  # 20 column blocks of 256 columns; 6 tiles of 1024 rows, the last one ragged
+    if kind == "uniform32":
+        lens = np.full(n_rows, 32)
+    elif kind == "ragged":
+        lens = rng.integers(0, 70, n_rows)
+    elif kind == "long_rows":
+        lens = rng.integers(0, 6, n_rows)
+        lens[17] = 3000      # 150 per block: several passes of its wave's LDS stage in every block
+        lens[4000:4100] = 300
+    elif kind == "one_tile":
+        n_rows = 700
+        lens = rng.integers(0, 40, n_rows)
+    else:
+        lens = rng.integers(0, 5, n_rows)
+        lens[rng.random(n_rows) < 0.8] = 0
+    off, col, val = random_crs(rng, n_rows, n_cols, lens, dtype, dup=True)
+    x = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    m.set_colblock_shift(shift)
+    cf = m.colfused()
+    assert cf["fits"] and cf["shift"] == shift and cf["rows_per_lane"] == 16
+    n_blocks, tiles, seg, cnt, col2, val2 = fused_reference(off, col, val, n_cols, shift, cf["rows_per_lane"])
+    assert (cf["n_blocks"], cf["n_tiles"]) == (n_blocks, len(tiles) - 1) and np.array_equal(cf["tile_rows"], tiles)
+    if kind == "long_rows":
+        assert np.diff(tiles.astype(np.int64)).min() < 64 * cf["rows_per_lane"]  # the stretch of long rows got shorter tiles
+    assert np.array_equal(cf["segments"], seg) and np.array_equal(cf["counts"], cnt.astype(np.uint8))
+    assert np.array_equal(cf["columns"], col2) and np.array_equal(bits(cf["values"]), bits(val2))
+    y = m.mvp(x, variant="colfused")
+    assert_spmv_close(y, off, col, val, x, "colfused " + kind)
+    assert np.array_equal(bits(y), bits(block_ordered_reference(off, col, val, x, shift)))  # bit-exact in ITS order of additions
+    assert np.array_equal(bits(y), bits(m.mvp(x, variant="colfused")))                      # run-to-run reproducible
+    m.scale(-0.5)   # the copy follows value changes
+    assert np.array_equal(bits(m.mvp(x, variant="colfused")), bits(block_ordered_reference(off, col, (val * dtype(-0.5)).astype(dtype), x, shift)))
+    val3 = rng.uniform(-1, 1, len(val)).astype(dtype)
+    m.update_values(val3)
+    assert np.array_equal(bits(m.mvp(x, variant="colfused")), bits(block_ordered_reference(off, col, val3, x, shift)))
+
+
+def test_colfused_falls_back_when_a_row_block_pair_overflows_the_byte_table(gpu):
+    """More than 255 entries of one row in one column block: no K2f copy; the variant then runs K2c, bit for bit."""
+    rng = np.random.default_rng(31)
+    n_rows, n_cols, shift = 3000, 2000, 8
+    lens = rng.integers(0, 10, n_rows)
+    lens[5] = 4000  # 500 per block
+    off, col, val = random_crs(rng, n_rows, n_cols, lens, np.float32)
+    x = rng.uniform(-1, 1, n_cols).astype(np.float32)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    m.set_colblock_shift(shift)
+    assert not m.colfused(arrays=False)["fits"]
+    y = m.mvp(x, variant="colfused")
+    assert np.array_equal(bits(y), bits(m.mvp(x, variant="colblock")))
+    assert_spmv_close(y, off, col, val, x, "colfused -> colblock")
+
+
+def test_colfused_edge_shapes(gpu):
+    f = np.float64
+    m = sm.SparseMatCRS.from_raw_parts(5, 300, np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.zeros(0, f))
+    m.set_colblock_shift(6)
+    assert np.array_equal(m.mvp(np.ones(300, f), variant="colfused"), np.zeros(5, f))
+    m = sm.SparseMatCRS.from_raw_parts(2, 300, [0, 0, 2], [299, 299], np.array([1.0, 1.0], f))
+    m.set_colblock_shift(6)
+    assert np.array_equal(m.mvp(np.arange(300, dtype=f), variant="colfused"), np.array([0.0, 598.0], f))
+    # one block only: the order of additions is the storage order -> bit-exact against the reference loop itself
+    rng = np.random.default_rng(2)
+    off, col, val = random_crs(rng, 2500, 900, rng.integers(0, 50, 2500), np.float32)
+    x = rng.uniform(-1, 1, 900).astype(np.float32)
+    m = sm.SparseMatCRS.from_raw_parts(2500, 900, off, col, val)
+    assert m.colfused(arrays=False)["n_blocks"] == 1
+    assert np.array_equal(bits(m.mvp(x, variant="colfused")), bits(oracle.spmv(off, col, val, x)))

@@ -161,9 +161,9 @@ def test_full_size_c2_uniform_colblock_properties(gpu):
     samples bit for bit, K2c agrees with K1s on every row within the parity bound, linearity under x -> 2x."""
     n, k = 10_000_000, 32
     m = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_UNIFORM, n, k, np.float32)
-    assert m.resolved_variant()[0] == "colblock"
-    cb = m.colblock(arrays=False)
-    assert cb["n_blocks"] == 20 and cb["shift"] == 19 and cb["span_fraction"] > 0.9
+    assert m.resolved_variant()[0] == "colfused"  # column-blocked, one sweep over y (K2f)
+    cf = m.colfused(arrays=False)
+    assert cf["fits"] and cf["n_blocks"] == 39 and cf["shift"] == 18
     xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
     x = xbuf.download(np.float32, n)
     y_cb = _run(m, xptr, n, "auto", np.float32)
@@ -185,12 +185,14 @@ def test_full_size_c3_powerlaw_properties(gpu):
     and the bit-exact K1s agree on every row to 1e-12 of the row's scale; sampled rows against the oracle."""
     n = 10_000_000
     m = synth.crs_powerlaw(synth.SEED_MATRIX, n, n, np.float64)
-    assert m.resolved_variant()[0] == "colblock" and m.max_row_len() == 2048
+    assert m.resolved_variant()[0] == "colblock" and m.max_row_len() == 2048  # skewed rows: the per-block launches (K2c)
     xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float64)
     x = xbuf.download(np.float64, n)
     y_cb = _run(m, xptr, n, "auto", np.float64)
     y_mg = _run(m, xptr, n, "merge", np.float64)
     y_st = _run(m, xptr, n, "stream", np.float64)
+    y_k2f = _run(m, xptr, n, "colfused", np.float64)  # the one-sweep form must agree too (AUTO does not take it here)
+    assert np.abs(y_k2f - y_st).max() < 2.1e-9
     # |row| <= 2048 entries of magnitude < 1: sum|a x| <= 2048; bound 1e-12 * 2048 covers every row
     assert np.abs(y_cb - y_st).max() < 2.1e-9 and np.abs(y_mg - y_st).max() < 2.1e-9
     off_all = synth.powerlaw_offsets(synth.SEED_MATRIX, n)

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--k", type=int, default=32, help="entries per row of the fixed-length cases")
     ap.add_argument("--cases", default="banded,diag,uniform,powerlaw")
     ap.add_argument("--lanes", default="4,8,16")
+    ap.add_argument("--only-blocked", action="store_true", help="time only the column-blocked variants (K2c / K2f) and AUTO")
     ap.add_argument("--cb-shifts", default="", help="K2c column-block widths to time (log2 columns), e.g. 18,19,20")
     args = ap.parse_args()
     torch.cuda.init()
@@ -71,7 +72,7 @@ def main():
         print("== %s: rows %d nnz %d dtype %s auto=%s max_row %d bytes %.3f GB | ring: blocks %d phases %d fraction %.3f active %s" % (
             case, nr, m.n_non_zero_entries(), np.dtype(dtype).name, m.resolved_variant(), m.max_row_len(), B / 1e9,
             nb, len(ph), frac, act), flush=True)
-        for spec in args.lanes.split(","):  # "lanes" or "lanes:chunks"
+        for spec in ([] if args.only_blocked else args.lanes.split(",")):  # "lanes" or "lanes:chunks"
             lanes, chunks = (int(v) for v in (spec + ":0").split(":")[:2])
             m.set_vector_lanes(lanes)
             m.set_vector_chunks(chunks)
@@ -82,9 +83,10 @@ def main():
         m.set_vector_lanes(0)
         m.set_vector_chunks(0)
         m.set_ring(-1)
-        med, mn = time_variant(m, xptr, nr, ybuf.ptr, "merge")
-        report("merge", B, med, mn)
-        for mode, tag in ((0, "stream (K1s)"), (1, "stream (K1s-w)")):
+        if not args.only_blocked:
+            med, mn = time_variant(m, xptr, nr, ybuf.ptr, "merge")
+            report("merge", B, med, mn)
+        for mode, tag in (() if args.only_blocked else ((0, "stream (K1s)"), (1, "stream (K1s-w)"))):
             m.set_stream_windows(mode)
             med, mn = time_variant(m, xptr, nr, ybuf.ptr, "stream", reps=8 if case != "lap512" and not case.startswith("lap") else 20)
             report(tag + " win=%.2f" % m.stream_windows()[0] if mode else tag, B, med, mn)
@@ -98,6 +100,10 @@ def main():
                 continue
             med, mn = time_variant(m, xptr, nr, ybuf.ptr, "colblock", reps=8)
             report("colblock 2^%d x%d rpt%d" % (cb["shift"], cb["n_blocks"], cb["rows_per_thread"]), B, med, mn)
+            cf = m.colfused(arrays=False)
+            if cf["fits"]:
+                med, mn = time_variant(m, xptr, nr, ybuf.ptr, "colfused", reps=8)
+                report("colfused 2^%d x%d rt%d" % (cf["shift"], cf["n_blocks"], cf["rows_per_lane"]), B, med, mn)
         m.set_colblock_shift(0)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "auto")
         report("auto", B, med, mn)
