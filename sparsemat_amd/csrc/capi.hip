@@ -455,14 +455,22 @@ static int ensure_stream_codes(smh_crs *m) {
     SMH_HIP(hipMalloc((void **)&m->d_stream_code, n_out * sizeof(uint16_t)));
     SMH_HIP(hipMemsetAsync(m->d_stream_code, 0, n_out * sizeof(uint16_t), m->stream));
     SMH_TRY(launch_stream_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, m->d_stream_code, m->stream));
+    // ... and with rows of at most 255 entries the row boundaries shrink from a u32 offset to a byte per row
+    if (m->max_row_len <= 255u) {
+        SMH_HIP(hipMalloc((void **)&m->d_stream_len8, n_tiles * kStreamRows));
+        SMH_HIP(hipMalloc((void **)&m->d_stream_tbase, (n_tiles + 1) * sizeof(uint32_t)));
+        SMH_TRY(launch_stream_len8(m->d_off, m->n_rows, m->d_stream_len8, m->d_stream_tbase, m->stream));
+    }
     SMH_HIP(hipStreamSynchronize(m->stream));
     return SMH_OK;
 }
 
 static void drop_stream_codes(smh_crs *m) {
-    (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
+    (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code); (void)hipFree(m->d_stream_len8); (void)hipFree(m->d_stream_tbase);
     m->d_stream_cwin = nullptr;
     m->d_stream_code = nullptr;
+    m->d_stream_len8 = nullptr;
+    m->d_stream_tbase = nullptr;
     m->stream_coded = false;
 }
 
@@ -550,6 +558,8 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
             // 16-bit column codes when every tile's columns fall into <= 4 intervals of <= 16384 (stencils, bands)
             const uint16_t *code = nullptr;
             const uint32_t *cwin = nullptr;
+            const uint8_t *len8 = nullptr;
+            const uint32_t *tbase = nullptr;
             const char *c16_env = getenv("SMH_STREAM_C16");  // tuning knob: 0 = always the u32 columns
             // (single-pass tiles only: on dense multi-pass tiles -- banded C2 through K1s -- the decode costs more than
             // the bytes save, 0.83 vs 0.80 ms)
@@ -557,9 +567,11 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
                 SMH_TRY(ensure_stream_codes(m));
                 code = m->d_stream_code;
                 cwin = m->d_stream_code ? m->d_stream_cwin : nullptr;
+                static const bool l8_off = getenv("SMH_STREAM_L8") && atoi(getenv("SMH_STREAM_L8")) == 0;  // tuning knob
+                if (cwin && !l8_off) { len8 = m->d_stream_len8; tbase = m->d_stream_tbase; }
             }
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt,
-                                      single_pass, dot_partials, code, cwin, s);
+                                      single_pass, dot_partials, code, cwin, len8, tbase, s);
         }
         case SMH_SPMV_COLFUSED: {
             SMH_TRY(ensure_colfused(m));
@@ -965,6 +977,7 @@ int smh_crs_destroy(smh_crs *m) {
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
     (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16); (void)hipFree(m->d_ring_win);
     (void)hipFree(m->d_stream_win); (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
+    (void)hipFree(m->d_stream_len8); (void)hipFree(m->d_stream_tbase);
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);
     (void)hipFree(m->d_cf_seg); (void)hipFree(m->d_cf_cnt); (void)hipFree(m->d_cf_col); (void)hipFree(m->d_cf_val);
     (void)hipFree(m->d_cf_tile_row); (void)hipFree(m->d_cf_progress);

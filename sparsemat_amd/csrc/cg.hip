@@ -6,9 +6,15 @@
 //   per iteration   SpMV  Ap = A p                      (K1 / K2, launched by the caller)   :43
 //                   k_dot_stage1(p, Ap) -> partials                                          :45
 //                   k_cg_alpha   : fold partials, alpha = rr / pAp, decide "active"          :45
-//                   k_cg_update  : x += round(p*alpha); r -= round(Ap*alpha); partials r.r   :47-51
+//                   k_cg_update  : r -= round(Ap*alpha); partials r.r                        :49-51
 //                   k_cg_beta    : fold, rr_prev/rr, stop if sqrt(f64(rr)) < tol, else beta  :50-56
-//                   k_cg_p       : p = round(p*beta) + r                                     :58-59
+//                   k_cg_p       : x += round(p*alpha) (:47), then p = round(p*beta) + r     :58-59
+//
+// `*x += p * alpha` (:47) is carried out by the sweep that rebuilds p: it reads the old p anyway, so x costs one read and
+// one write there instead of p AND x in the update sweep -- 8 n instead of 9 n values of vector traffic per iteration,
+// the same operations on the same operands (x does not feed anything else inside an iteration), bit-identical results.
+// That sweep therefore runs whenever the body was ENTERED ("entered"), and only its p part is gated by "active": the
+// iteration that converges still delivers its x.
 //
 // "active" = not converged and fewer than iter_max bodies entered; once it drops, the gated
 // kernels are no-ops, so the host may enqueue iterations in batches and poll the flag lazily:
@@ -24,6 +30,8 @@ struct CgScalars {
     T rr, rr_prev, pap, alpha, beta;
     uint32_t converged;
     uint32_t active;
+    uint32_t entered;  // the current loop body was entered: its x update is due (set by k_cg_alpha)
+    uint32_t pad_;
     uint64_t iters;
     uint64_t iter_max;
     double tol;
@@ -71,6 +79,8 @@ __global__ void k_cg_init(CgScalars<T> *sc, double tol, uint64_t iter_max) {
     sc->rr = sc->rr_prev = sc->pap = sc->alpha = sc->beta = T(0);
     sc->converged = 0;
     sc->active = 0;
+    sc->entered = 0;
+    sc->pad_ = 0;
     sc->iters = 0;
     sc->iter_max = iter_max;
     sc->tol = tol;
@@ -95,6 +105,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_alpha(CgScalars<T> *sc, const T *
     if (threadIdx.x == 0) {
         const bool active = !sc->converged && sc->iters < sc->iter_max;
         sc->active = active ? 1u : 0u;
+        sc->entered = active ? 1u : 0u;
         if (active) {
             sc->iters += 1;  // a loop body is entered (for _k in 0..iter_max, :41)
             sc->pap = pap;
@@ -105,8 +116,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_alpha(CgScalars<T> *sc, const T *
 
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(kBlock)
-k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ x, T *__restrict__ r, const T *__restrict__ p,
-            const T *__restrict__ ap, uint64_t n, T *__restrict__ partials) {
+k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ r, const T *__restrict__ ap, uint64_t n, T *__restrict__ partials) {
     __shared__ T s_w[kBlock / kWave];
     if (!sc->active) return;  // block-uniform
     const T alpha = sc->alpha;
@@ -117,31 +127,25 @@ k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ x, T *__restric
         typedef typename CgVec<T>::type V;
         constexpr int N = CgVec<T>::N;
         const uint64_t nv = n / N;
-        V *xv = reinterpret_cast<V *>(x);
         V *rv = reinterpret_cast<V *>(r);
-        const V *pv = reinterpret_cast<const V *>(p);
         const V *apv = reinterpret_cast<const V *>(ap);
         for (uint64_t i = tid; i < nv; i += nthreads) {
-            V xx = xv[i], rr = rv[i];
-            const V pp = pv[i], aa = apv[i];
+            V rr = rv[i];
+            const V aa = apv[i];
 #pragma unroll
             for (int e = 0; e < N; ++e) {
-                xx[e] = cg_add(xx[e], cg_mul(pp[e], alpha));  // *x += p.clone() * alpha   :47
                 rr[e] = cg_sub(rr[e], cg_mul(aa[e], alpha));  // r -= mat_p * alpha        :49
                 acc += rr[e] * rr[e];                         // r.norm_squared()          :51
             }
-            xv[i] = xx;
             rv[i] = rr;
         }
         for (uint64_t i = nv * N + tid; i < n; i += nthreads) {
-            x[i] = cg_add(x[i], cg_mul(p[i], alpha));
             const T t = cg_sub(r[i], cg_mul(ap[i], alpha));
             r[i] = t;
             acc += t * t;
         }
     } else {
         for (uint64_t i = tid; i < n; i += nthreads) {
-            x[i] = cg_add(x[i], cg_mul(p[i], alpha));
             const T t = cg_sub(r[i], cg_mul(ap[i], alpha));
             r[i] = t;
             acc += t * t;
@@ -172,9 +176,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_beta(CgScalars<T> *sc, const T *_
 
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(kBlock)
-k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restrict__ r, uint64_t n) {
-    if (!sc->active) return;
-    const T beta = sc->beta;
+k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restrict__ r, T *__restrict__ x, uint64_t n) {
+    if (!sc->entered) return;
+    const bool rebuild = sc->active != 0;  // (false: this body broke out at the stop test -- x is still due, p stays)
+    const T alpha = sc->alpha, beta = sc->beta;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     if constexpr (VEC) {
@@ -182,17 +187,38 @@ k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restri
         constexpr int N = CgVec<T>::N;
         const uint64_t nv = n / N;
         V *pv = reinterpret_cast<V *>(p);
+        V *xv = reinterpret_cast<V *>(x);
         const V *rv = reinterpret_cast<const V *>(r);
-        for (uint64_t i = tid; i < nv; i += nthreads) {
-            V pp = pv[i];
-            const V rr = rv[i];
+        if (rebuild) {
+            for (uint64_t i = tid; i < nv; i += nthreads) {
+                V pp = pv[i], xx = xv[i];
+                const V rr = rv[i];
 #pragma unroll
-            for (int e = 0; e < N; ++e) pp[e] = cg_add(cg_mul(pp[e], beta), rr[e]);  // p.scale(beta); p.add(&r) :58-59
-            pv[i] = pp;
+                for (int e = 0; e < N; ++e) {
+                    xx[e] = cg_add(xx[e], cg_mul(pp[e], alpha));  // *x += p.clone() * alpha        :47
+                    pp[e] = cg_add(cg_mul(pp[e], beta), rr[e]);   // p.scale(beta); p.add(&r)       :58-59
+                }
+                xv[i] = xx;
+                pv[i] = pp;
+            }
+        } else {
+            for (uint64_t i = tid; i < nv; i += nthreads) {
+                V xx = xv[i];
+                const V pp = pv[i];
+#pragma unroll
+                for (int e = 0; e < N; ++e) xx[e] = cg_add(xx[e], cg_mul(pp[e], alpha));
+                xv[i] = xx;
+            }
         }
-        for (uint64_t i = nv * N + tid; i < n; i += nthreads) p[i] = cg_add(cg_mul(p[i], beta), r[i]);
+        for (uint64_t i = nv * N + tid; i < n; i += nthreads) {
+            x[i] = cg_add(x[i], cg_mul(p[i], alpha));
+            if (rebuild) p[i] = cg_add(cg_mul(p[i], beta), r[i]);
+        }
     } else {
-        for (uint64_t i = tid; i < n; i += nthreads) p[i] = cg_add(cg_mul(p[i], beta), r[i]);
+        for (uint64_t i = tid; i < n; i += nthreads) {
+            x[i] = cg_add(x[i], cg_mul(p[i], alpha));
+            if (rebuild) p[i] = cg_add(cg_mul(p[i], beta), r[i]);
+        }
     }
 }
 
@@ -245,9 +271,9 @@ static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T 
     }
     SMH_HIP(hipGetLastError());
     if (vec)
-        hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, sc, x, r, p, ap, (uint64_t)n, partials);
+        hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, sc, r, ap, (uint64_t)n, partials);
     else
-        hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, sc, x, r, p, ap, (uint64_t)n, partials);
+        hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, sc, r, ap, (uint64_t)n, partials);
     SMH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cg_beta<T>, dim3(1), dim3(kBlock), 0, s, sc, partials, rb);
     SMH_HIP(hipGetLastError());
@@ -255,9 +281,9 @@ static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T 
     static const uint64_t p_cap = getenv("SMH_CG_P_BLOCKS") ? (uint64_t)atoll(getenv("SMH_CG_P_BLOCKS")) : 512;  // tuning knob
     if (pb > p_cap) pb = p_cap;
     if (vec)
-        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, (uint64_t)n);
+        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, x, (uint64_t)n);
     else
-        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, (uint64_t)n);
+        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, x, (uint64_t)n);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
@@ -324,42 +350,41 @@ int cg_par_init(int dtype, void *sc, double tol, size_t iter_max, hipStream_t s)
     return SMH_OK;
 }
 
-// x += round(p*alpha); r -= round(Ap*alpha) on this block's rows; partials[0..*count_out) of r.r   (:47-51)
+// r -= round(Ap*alpha) on this block's rows; partials[0..*count_out) of r.r   (:49-51)
 template <typename T>
-static int cg_par_update_t(void *sc, T *x, T *r, const T *p, const T *ap, size_t n, T *partials, uint32_t *count_out, hipStream_t s) {
+static int cg_par_update_t(void *sc, T *r, const T *ap, size_t n, T *partials, uint32_t *count_out, hipStream_t s) {
     unsigned rb = reduce_blocks(n);
     if (rb > 512u) rb = 512u;
-    const bool vec = cg_aligned16(x) && cg_aligned16(r) && cg_aligned16(p) && cg_aligned16(ap);
-    if (vec) hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, x, r, p, ap, (uint64_t)n, partials);
-    else hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, x, r, p, ap, (uint64_t)n, partials);
+    if (cg_aligned16(r) && cg_aligned16(ap))
+        hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, r, ap, (uint64_t)n, partials);
+    else
+        hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, r, ap, (uint64_t)n, partials);
     SMH_HIP(hipGetLastError());
     *count_out = rb;
     return SMH_OK;
 }
 
-int cg_par_update(int dtype, void *sc, void *x, void *r, const void *p, const void *ap, size_t n, void *partials, uint32_t *count_out,
-                  hipStream_t s) {
-    if (dtype == SMH_F64)
-        return cg_par_update_t<double>(sc, (double *)x, (double *)r, (const double *)p, (const double *)ap, n, (double *)partials, count_out, s);
-    return cg_par_update_t<float>(sc, (float *)x, (float *)r, (const float *)p, (const float *)ap, n, (float *)partials, count_out, s);
+int cg_par_update(int dtype, void *sc, void *r, const void *ap, size_t n, void *partials, uint32_t *count_out, hipStream_t s) {
+    if (dtype == SMH_F64) return cg_par_update_t<double>(sc, (double *)r, (const double *)ap, n, (double *)partials, count_out, s);
+    return cg_par_update_t<float>(sc, (float *)r, (const float *)ap, n, (float *)partials, count_out, s);
 }
 
-// p = round(p*beta) + r on this block's rows   (:58-59)
+// x += round(p*alpha) (:47), then p = round(p*beta) + r (:58-59), on this block's rows
 template <typename T>
-static int cg_par_p_t(void *sc, T *p, const T *r, size_t n, hipStream_t s) {
+static int cg_par_p_t(void *sc, T *p, const T *r, T *x, size_t n, hipStream_t s) {
     uint64_t pb = (n / CgVec<T>::N + kBlock) / kBlock;
     if (pb > 512) pb = 512;
-    if (cg_aligned16(p) && cg_aligned16(r))
-        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, (uint64_t)n);
+    if (cg_aligned16(p) && cg_aligned16(r) && cg_aligned16(x))
+        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, x, (uint64_t)n);
     else
-        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, (uint64_t)n);
+        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, x, (uint64_t)n);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
 
-int cg_par_p(int dtype, void *sc, void *p, const void *r, size_t n, hipStream_t s) {
-    if (dtype == SMH_F64) return cg_par_p_t<double>(sc, (double *)p, (const double *)r, n, s);
-    return cg_par_p_t<float>(sc, (float *)p, (const float *)r, n, s);
+int cg_par_p(int dtype, void *sc, void *p, const void *r, void *x, size_t n, hipStream_t s) {
+    if (dtype == SMH_F64) return cg_par_p_t<double>(sc, (double *)p, (const double *)r, (double *)x, n, s);
+    return cg_par_p_t<float>(sc, (float *)p, (const float *)r, (float *)x, n, s);
 }
 
 }  // namespace smh

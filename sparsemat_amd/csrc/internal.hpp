@@ -63,7 +63,9 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
                        bool single_pass /* no tile holds more than kStreamCap entries */,
                        void *dot_partials /* optional: x.y per tile, stream_tiles() entries */,
                        const uint16_t *code, const uint32_t *cwin /* optional: 16-bit column codes + their interval table */,
+                       const uint8_t *len8, const uint32_t *tbase /* optional (with codes): byte row lengths + tile starts */,
                        hipStream_t s);
+int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
 size_t stream_tiles(size_t n_rows, int rows_per_thread);
 int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, bool for_codes, uint32_t *win,
                           uint32_t *d_count, hipStream_t s);
@@ -174,6 +176,8 @@ struct smh_crs {
     bool stream_coded = false;         // inspected
     uint32_t *d_stream_cwin = nullptr; // 8 u32 per 256-row tile
     uint16_t *d_stream_code = nullptr; // one u16 per entry
+    uint8_t *d_stream_len8 = nullptr;  // with codes and max_row_len <= 255: one byte per row (its length) ...
+    uint32_t *d_stream_tbase = nullptr; // ... and one u32 per 256-row tile (its first entry)
     // K2c column-blocked copy (lazy)
     bool cb_built = false;
     uint32_t cb_forced_shift = 0;  // 0 automatic (2 MiB of x per block)

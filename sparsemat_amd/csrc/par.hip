@@ -45,9 +45,8 @@ int cg_par_init(int dtype, void *sc, double tol, size_t iter_max, hipStream_t s)
 int cg_par_set_rr(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
 int cg_par_alpha(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
 int cg_par_beta(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
-int cg_par_update(int dtype, void *sc, void *x, void *r, const void *p, const void *ap, size_t n, void *partials,
-                  uint32_t *count_out, hipStream_t s);
-int cg_par_p(int dtype, void *sc, void *p, const void *r, size_t n, hipStream_t s);
+int cg_par_update(int dtype, void *sc, void *r, const void *ap, size_t n, void *partials, uint32_t *count_out, hipStream_t s);
+int cg_par_p(int dtype, void *sc, void *p, const void *r, void *x, size_t n, hipStream_t s);
 }  // namespace smh
 
 #define SMH_NCCL(call)                                                                                    \
@@ -1042,8 +1041,7 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
                     SMH_TRY(use(blk));
                     uint32_t cnt = 0;
                     SMH_TRY(cg_par_alpha(dt, blk.d_sc, red_all(p, blk, 0), nb, blk.s));
-                    SMH_TRY(cg_par_update(dt, blk.d_sc, (char *)x->d[k] + blk.r0 * vs, blk.d_r, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap,
-                                          blk.r1 - blk.r0, blk.d_partials, &cnt, blk.s));                                        // :47-51
+                    SMH_TRY(cg_par_update(dt, blk.d_sc, blk.d_r, blk.d_ap, blk.r1 - blk.r0, blk.d_partials, &cnt, blk.s));           // :49-51
                     SMH_TRY(cg_fold(dt, blk.d_partials, cnt, red_mine(p, blk, 1), blk.s));
                 }
                 SMH_TRY(combine(p, 1));
@@ -1051,7 +1049,8 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
                     ParBlock &blk = p->b[k];
                     SMH_TRY(use(blk));
                     SMH_TRY(cg_par_beta(dt, blk.d_sc, red_all(p, blk, 1), nb, blk.s));                                          // :52-56
-                    SMH_TRY(cg_par_p(dt, blk.d_sc, (char *)pv->d[k] + blk.r0 * vs, blk.d_r, blk.r1 - blk.r0, blk.s));           // :58-59
+                    SMH_TRY(cg_par_p(dt, blk.d_sc, (char *)pv->d[k] + blk.r0 * vs, blk.d_r, (char *)x->d[k] + blk.r0 * vs, blk.r1 - blk.r0,
+                                     blk.s));                                                                                   // :47, :58-59
                 }
             }
             launched += batch;

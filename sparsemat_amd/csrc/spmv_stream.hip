@@ -186,13 +186,20 @@ __device__ __forceinline__ uint32_t decode_col(uint32_t cd, uint32_t b0, uint32_
     return (q == 0u ? b0 : q == 1u ? b1 : q == 2u ? b2 : b3) + (cd & 16383u);
 }
 
-template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false>
+// L8 (with C16, when no row holds more than 255 entries): the row boundaries come from one BYTE per row (its length) and
+// one u32 per tile (where its entries start) instead of the u32 offset_rows stream -- 1 instead of 4 bytes per row from HBM
+// (512^3 Laplacian: 537 -> 136 MB of the 7.2 GB a product moves).  The in-tile prefix sum of the lengths is a wave scan
+// whose cross-wave part rides on the barrier the kernel has anyway.
+template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false, bool L8 = false>
 __global__ void SMH_STREAM_BOUNDS
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
               uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials,
-              const uint16_t *__restrict__ code, const uint32_t *__restrict__ cwin) {
+              const uint16_t *__restrict__ code, const uint32_t *__restrict__ cwin, const uint8_t *__restrict__ len8,
+              const uint32_t *__restrict__ tbase) {
     static_assert(!C16 || (RPT == 1 && !XWIN), "the code table describes 256-row tiles");
+    static_assert(!L8 || (C16 && !MULTI), "row lengths as bytes: single-pass 256-row tiles with column codes");
+    __shared__ uint32_t s_wtot[L8 ? kBlock / kWave : 1];
     __shared__ T s_prod[CAP + CAP / 32 + 8];
     __shared__ T s_x[XWIN ? kStreamXWin : 1];
     // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of tiles
@@ -203,13 +210,30 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     const uint64_t r1 = r0 + TILE_ROWS < n_rows ? r0 + TILE_ROWS : n_rows;
     const uint32_t tid = threadIdx.x;
     uint32_t o0[RPT], o1[RPT];
+    uint32_t k0, k1, my_len = 0, my_excl = 0;
+    if constexpr (L8) {
+        k0 = tbase[tile];      // tile-uniform: scalar loads
+        k1 = tbase[tile + 1];
+        my_len = len8[r0 + tid];  // (the byte array is padded to whole tiles with zeros)
+        uint32_t incl = my_len;
 #pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) {
-        const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
-        o0[rr] = off[r < r1 ? r : r1];  // (non-temporal loads here: no measurable difference)
-        o1[rr] = off[r + 1 < r1 ? r + 1 : r1];
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, kWave);
+            if ((int)(tid & (kWave - 1)) >= o) incl += up;
+        }
+        if ((tid & (kWave - 1)) == kWave - 1) s_wtot[tid / kWave] = incl;  // read after the barrier below
+        my_excl = incl - my_len;
+        o0[0] = o1[0] = 0;
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
+            o0[rr] = off[r < r1 ? r : r1];  // (non-temporal loads here: no measurable difference)
+            o1[rr] = off[r + 1 < r1 ? r + 1 : r1];
+        }
+        k0 = off[r0];  // tile-uniform: scalar loads
+        k1 = off[r1];
     }
-    const uint32_t k0 = off[r0], k1 = off[r1];  // tile-uniform: scalar loads
     T sum[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) sum[rr] = T(0);
@@ -327,6 +351,12 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             }
         }
         __syncthreads();
+        if constexpr (L8) {  // this row's entries: the tile's start + the lengths of the rows before it
+            uint32_t base = k0;
+            for (uint32_t w = 0; w < tid / kWave; ++w) base += s_wtot[w];
+            o0[0] = base + my_excl;
+            o1[0] = o0[0] + my_len;
+        }
         // each row: storage order, one rounded add per entry (reference: sum += product)
 #pragma unroll
         for (int rr = 0; rr < RPT; ++rr) {
@@ -383,7 +413,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
 template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
                            size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
-                           const uint16_t *code, const uint32_t *cwin, hipStream_t s) {
+                           const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, hipStream_t s) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
@@ -394,7 +424,8 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     static const unsigned lds_pad = getenv("SMH_STREAM_LDS_PAD") ? (unsigned)atoi(getenv("SMH_STREAM_LDS_PAD")) : 0u;
 #define SMH_ST_LAUNCH(XW, R, D, M, C)                                                                                    \
     hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M, kStreamCap, C>), grid, block, lds_pad, s, off, col, val, x, y, \
-                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin)
+                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin,                   \
+                       (const uint8_t *)nullptr, (const uint32_t *)nullptr)
 #define SMH_ST_PICK(XW, R, C)                                                     \
     do {                                                                          \
         if (single_pass) {                                                        \
@@ -405,6 +436,14 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     } while (0)
     if (win) SMH_ST_PICK(true, 1, false);  // the window table describes 256-row tiles
     else if (rpt == 2) SMH_ST_PICK(false, 2, false);
+    else if (code && cwin && len8 && tbase && single_pass) {  // column codes + byte row lengths
+        if (dot_partials)
+            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase);
+        else
+            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase);
+    }
     else if (code && cwin) SMH_ST_PICK(false, 1, true);  // 16-bit column codes (every tile described)
     else SMH_ST_PICK(false, 1, false);
 #undef SMH_ST_PICK
@@ -425,7 +464,7 @@ static int launch_stream_block_t(const uint32_t *off, const uint32_t *col, const
 #define SMH_SB_LAUNCH(R, A, M)                                                                                          \
     hipLaunchKernelGGL((k_spmv_stream<T, false, R, false, A, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
                        (uint64_t)nnz_total, readable, n_tiles, (const uint32_t *)nullptr, (T *)nullptr,         \
-                       (const uint16_t *)nullptr, (const uint32_t *)nullptr)
+                       (const uint16_t *)nullptr, (const uint32_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr)
 #define SMH_SB_PICK(R)                                                                      \
     do {                                                                                     \
         if (single_pass) { if (acc) SMH_SB_LAUNCH(R, true, false); else SMH_SB_LAUNCH(R, false, false); } \
@@ -462,13 +501,38 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
-                       void *dot_partials, const uint16_t *code, const uint32_t *cwin, hipStream_t s) {
+                       void *dot_partials, const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase,
+                       hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
     if (dtype == SMH_F64)
         return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
-                                       rpt, single_pass, (double *)dot_partials, code, cwin, s);
+                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, s);
     return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
-                                  single_pass, (float *)dot_partials, code, cwin, s);
+                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, s);
+}
+
+// row lengths as bytes (rows padded to whole 256-row tiles with zeros) and the tiles' first entries (n_tiles + 1 values);
+// the caller guarantees max_row_len <= 255
+__global__ void __launch_bounds__(kBlock)
+k_stream_len8(const uint32_t *__restrict__ off, uint64_t n_rows, uint64_t n_padded, uint64_t n_tiles, uint8_t *__restrict__ len8,
+              uint32_t *__restrict__ tbase) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = tid; r < n_padded; r += nthreads) len8[r] = r < n_rows ? (uint8_t)(off[r + 1] - off[r]) : (uint8_t)0;
+    for (uint64_t t = tid; t <= n_tiles; t += nthreads) {
+        const uint64_t r = t * kStreamRows;
+        tbase[t] = off[r < n_rows ? r : n_rows];
+    }
+}
+
+int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s) {
+    const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
+    if (n_tiles == 0) return SMH_OK;
+    const uint64_t n_padded = n_tiles * kStreamRows;
+    uint64_t blocks = (n_padded + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_stream_len8, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, (uint64_t)n_rows, n_padded, n_tiles, len8, tbase);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
 }
 
 // for_codes: intervals for the 16-bit column codes (any tile size, <= 16384 columns per interval; tiles without

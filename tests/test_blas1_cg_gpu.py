@@ -110,16 +110,18 @@ def test_cg_laplace3d_matches_oracle(gpu, dtype, tol):
             xd, bd = sm.DenseVec.from_vec(x), sm.DenseVec.from_vec(b)
             cg = sm.ConjugateGradient(tol, 500, variant=variant, check_every=check_every)
             cg.solve(m, bd, xd)
-            assert abs(cg.iterations - it_ref) <= 2, (variant, cg.iterations, it_ref)
+            # measured (tools/dev/cg_probe.py, r02): every kernel family stops in the oracle's iteration, |x - x_ref| <= 0.03 tol
+            assert abs(cg.iterations - it_ref) <= 1, (variant, cg.iterations, it_ref)
             assert np.sqrt(cg.r_norm_squared) < tol
-            np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=50 * tol)
-            np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=50 * tol)
+            np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=10 * tol)
+            np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=10 * tol)
 
 
 def test_cg_64_cubed_f64_convergence_parity(gpu):
     """the 64^3 f64 convergence-parity case with the reference stop rule (sqrt(r.r) < tol, absolute,
-    tested before the beta update): same iteration count as the oracle (+-2: the reductions are regrouped) and the
-    same solution, for the bit-exact SpMV kernel and for AUTO; b = A.1, x0 = 0."""
+    tested before the beta update): same iteration count as the oracle (+-1: the reductions are regrouped; measured 195
+    on both sides) and the same solution (measured |x - x_ref| < 0.01 tol), for the bit-exact SpMV kernel and for AUTO;
+    b = A.1, x0 = 0."""
     g, dtype, tol = 64, np.float64, 1e-9
     n = g ** 3
     off, col, val = oracle.laplace3d(g, g, g, dtype)
@@ -131,10 +133,10 @@ def test_cg_64_cubed_f64_convergence_parity(gpu):
         xd, bd = sm.DenseVec.from_vec(np.zeros(n, dtype)), sm.DenseVec.from_vec(b)
         cg = sm.ConjugateGradient(tol, 2000, variant=variant)
         cg.solve(m, bd, xd)
-        assert abs(cg.iterations - it_ref) <= 2, (variant, cg.iterations, it_ref)
+        assert abs(cg.iterations - it_ref) <= 1, (variant, cg.iterations, it_ref)
         assert np.sqrt(cg.r_norm_squared) < tol
-        np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=100 * tol)
-        np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=100 * tol)
+        np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=10 * tol)
+        np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=10 * tol)
 
 
 def test_cg_iter_max_and_exact_iteration_semantics(gpu):

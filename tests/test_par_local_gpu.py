@@ -101,15 +101,15 @@ def test_par_cg_matches_oracle(gpu, dtype, n_blocks):
     x = np.zeros(n, dtype)
     iters, rr = m.cg_solve(b, x, tol=tol, iter_max=500)
     o_x, o_iters, o_rr = oracle.cg(n, n, off, col, val, b, np.zeros(n, dtype), tol=tol, iter_max=500)
-    assert abs(iters - o_iters) <= 2 and np.sqrt(rr) < tol
+    assert abs(iters - o_iters) <= 1 and np.sqrt(rr) < tol   # measured: the oracle's count for 1..7 blocks
     err = np.max(np.abs(x.astype(np.float64) - o_x.astype(np.float64)))
-    assert err < (2e-4 if dtype == np.float32 else 1e-9), err
+    assert err < 10 * tol, err                                # measured <= 0.03 tol
     # the single-device solver on the same system
     a = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
     cg = sm.ConjugateGradient(tol, 500)
     x1 = sm.DenseVec.zeros(n, dtype)
     cg.solve(a, sm.DenseVec.from_vec(b), x1)
-    assert abs(cg.iterations - iters) <= 2
+    assert abs(cg.iterations - iters) <= 1
     # iter_max is honoured, x is the iterate reached
     x2 = np.zeros(n, dtype)
     it2, _ = m.cg_solve(b, x2, tol=tol, iter_max=3)

@@ -204,3 +204,67 @@ def test_full_size_c3_powerlaw_properties(gpu):
         assert np.array_equal(y_st[rb:re].view(np.uint64), y_ref.view(np.uint64))
         assert_spmv_close(y_cb[rb:re], off, col, val, x, "colblock rows %d.." % rb)
         assert_spmv_close(y_mg[rb:re], off, col, val, x, "merge rows %d.." % rb)
+
+
+def test_full_size_c4_laplacian_512_spmv_and_cg(gpu):
+    """BASELINE configs[3] at its size: the 7-point Laplacian on a 512^3 grid (134,217,728 rows, 937,951,232 entries, f32).
+    SpMV: AUTO = K1s with 16-bit column codes and byte row lengths; it must equal the SEQ kernel (one lane per row, the
+    reference's loop) on EVERY row bit for bit, and the oracle on sampled row blocks.  CG (linearsolver.rs:27-61): three
+    iterations from x0 = 0, b = A.1.  Iteration 1 is exact on both sides (b is integer valued and its sums stay below
+    2^24): bit-identical x.  From then on the reference's SEQUENTIAL f32 folds over 1.3e8 elements (vector.rs:50-58) are
+    themselves inaccurate at this size -- partial sums beyond 2^24 swallow the low bits of every further term -- so its
+    alpha / beta drift from the exact quotients by ~1e-3, while the device folds with a fixed tree.  As for the SpMV rows
+    (tests/util.py), the device is therefore measured against an (effectively) exact restatement -- the same recurrence, the
+    same f32 element-wise roundings, the two dot products per iteration accumulated in f64 -- and must be no further from
+    it than the oracle is: measured in r02, device 3e-7 of max|x| against the oracle's 2.9e-3."""
+    g = 512
+    n = g ** 3
+    m = synth.crs_laplace3d(g, g, g, np.float32)
+    assert (m.n_rows(), m.n_non_zero_entries()) == (n, 937_951_232) and m.resolved_variant()[0] == "stream"
+    xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
+    y_auto = _run(m, xptr, n, "auto", np.float32)
+    y_seq = _run(m, xptr, n, "seq", np.float32)
+    assert np.array_equal(y_auto.view(np.uint32), y_seq.view(np.uint32))  # all 134 M rows, bit for bit
+    del y_seq
+    off, col, val = oracle.laplace3d(g, g, g, np.float32)  # the oracle's own generator (host, ~8 GB)
+    x = xbuf.download(np.float32, n)
+    for rb in (0, g * g - 300, n // 2 + 12345, n - 70_000):
+        re = min(n, rb + 70_000)
+        y_ref = oracle.spmv(off, col, val, x, rows=(rb, re))
+        assert np.array_equal(y_auto[rb:re].view(np.uint32), y_ref[rb:re].view(np.uint32)), rb
+    del y_auto, x, xbuf
+    b = oracle.spmv(off, col, val, np.ones(n, np.float32))
+    x_ref, it_ref, rr_ref = oracle.cg(n, n, off, col, val, b, np.zeros(n, np.float32), tol=1e-12, iter_max=3)
+    xd = np.zeros(n, np.float32)
+    cg = sm.ConjugateGradient(1e-12, 3)
+    cg.solve(m, b, xd)
+    assert cg.iterations == it_ref == 3
+
+    def dot64(u, v):  # blockwise f64 accumulation (no 1 GB temporaries)
+        return float(sum(np.dot(u[i:i + (1 << 24)].astype(np.float64), v[i:i + (1 << 24)].astype(np.float64)) for i in range(0, n, 1 << 24)))
+
+    xe, r = np.zeros(n, np.float32), b.copy()   # r = b - A.0
+    p = r.copy()
+    rr = dot64(r, r)
+    for _ in range(3):
+        ap = oracle.spmv(off, col, val, p)       # storage-order f32 rows: what K1s computes bit for bit
+        alpha = np.float32(rr) / np.float32(dot64(p, ap))
+        xe += p * alpha                          # round(p * alpha), then add   (linearsolver.rs:47)
+        r -= ap * alpha                          #                               (:49)
+        rr_new = dot64(r, r)
+        beta = np.float32(rr_new) / np.float32(rr)
+        p *= beta                                # p.scale(beta); p.add(&r)      (:58-59)
+        p += r
+        rr = rr_new
+    scale = float(np.abs(xe).max())
+    d_dev = float(np.abs(xd.astype(np.float64) - xe).max()) / scale
+    d_orc = float(np.abs(x_ref.astype(np.float64) - xe).max()) / scale
+    print("C4 full size, 3 CG iterations: max |x - x_exactdots| / max|x|: device %.3g, oracle %.3g; rr device %.6g oracle %.6g exact %.6g"
+          % (d_dev, d_orc, cg.r_norm_squared, rr_ref, rr))
+    assert d_dev <= d_orc + 1e-5 and d_dev < 1e-4
+    assert abs(cg.r_norm_squared - rr) <= 1e-4 * rr
+    # one iteration is exact on both sides (see the docstring): bit-identical x
+    x1_ref, _, _ = oracle.cg(n, n, off, col, val, b, np.zeros(n, np.float32), tol=1e-12, iter_max=1)
+    x1 = np.zeros(n, np.float32)
+    sm.ConjugateGradient(1e-12, 1).solve(m, b, x1)
+    assert np.array_equal(x1.view(np.uint32), x1_ref.view(np.uint32))

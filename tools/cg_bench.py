@@ -36,7 +36,7 @@ def main():
     # SpMV alone
     sm.lib().smh_device_synchronize()
     y = sm.DenseVec.zeros(n, dtype)
-    for variant in ("vector", "merge"):
+    for variant in ("vector", "merge", "auto"):
         a.mvp_dev(ones.data_ptr(), n, y.data_ptr(), variant)
         sm.lib().smh_device_synchronize()
         t0 = time.perf_counter()
