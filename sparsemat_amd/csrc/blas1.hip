@@ -186,6 +186,37 @@ static int launch_dot_t(const T *x, const T *y, size_t n, T *partials, T *result
     return SMH_OK;
 }
 
+// *result = sum of in[0..count): the same two stages as a dot (fixed grid and tree: deterministic)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_sum_stage1_b(const T *__restrict__ in, uint64_t n, T *__restrict__ partials) {
+    __shared__ T s_w[kBlock / kWave];
+    T acc = T(0);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc += in[i];
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T r = T(0);
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) r += s_w[w];
+        partials[blockIdx.x] = r;
+    }
+}
+
+int launch_fold2(int dtype, const void *in, size_t count, void *partials, void *result_dev, hipStream_t s) {
+    const unsigned blocks = reduce_blocks(count);
+    if (dtype == SMH_F64) {
+        hipLaunchKernelGGL(k_sum_stage1_b<double>, dim3(blocks), dim3(kBlock), 0, s, (const double *)in, (uint64_t)count, (double *)partials);
+        hipLaunchKernelGGL(k_reduce_stage2<double>, dim3(1), dim3(kBlock), 0, s, (const double *)partials, blocks, (double *)result_dev);
+    } else {
+        hipLaunchKernelGGL(k_sum_stage1_b<float>, dim3(blocks), dim3(kBlock), 0, s, (const float *)in, (uint64_t)count, (float *)partials);
+        hipLaunchKernelGGL(k_reduce_stage2<float>, dim3(1), dim3(kBlock), 0, s, (const float *)partials, blocks, (float *)result_dev);
+    }
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
 int launch_dot(int dtype, const void *x, const void *y, size_t n, void *partials, void *result_dev, hipStream_t s) {
     if (dtype == SMH_F64)
         return launch_dot_t<double>((const double *)x, (const double *)y, n, (double *)partials, (double *)result_dev, s);

@@ -516,17 +516,19 @@ static int stream_rpt(const smh_crs *m) {
 
 // Can y = A x also leave the partial sums of x.y (CG's p.Ap) in its epilogue?  Only the K1s kernel does;
 // returns the number of partials it would write (0: not fused -- run a separate dot).
-static size_t spmv_fused_dot_partials(const smh_crs *m, size_t x_len, int variant) {
+// any_lhs: the dot is taken with a vector of its own (n_rows entries; SparseMatrix::inner_prod) instead of x itself, so
+// the matrix need not be square
+size_t spmv_fused_dot_partials(const smh_crs *m, size_t x_len, int variant, bool any_lhs) {
     if (const char *e = getenv("SMH_CG_FUSED_DOT")) {  // tuning knob: 0 = always the separate dot
         if (atoi(e) == 0) return 0;
     }
-    if (resolve_variant(m, variant) != SMH_SPMV_STREAM || m->n_rows != m->n_cols || x_len < m->n_rows) return 0;
+    if (resolve_variant(m, variant) != SMH_SPMV_STREAM) return 0;
+    if (!any_lhs && (m->n_rows != m->n_cols || x_len < m->n_rows)) return 0;
     return stream_tiles(m->n_rows, m->use_stream_win == 1 ? 1 : stream_rpt(m));
 }
 
 // enqueue y = A x on stream s (device pointers); dot_partials (optional, K1s only): see above
-static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s,
-                        void *dot_partials = nullptr) {
+int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, void *dot_partials, const void *dot_lhs) {
     if (m->nnz > 0 && (size_t)m->max_col >= x_len)
         return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, m->max_col);
     const int v = resolve_variant(m, variant);
@@ -571,7 +573,7 @@ static int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int va
                 if (cwin && !l8_off) { len8 = m->d_stream_len8; tbase = m->d_stream_tbase; }
             }
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt,
-                                      single_pass, dot_partials, code, cwin, len8, tbase, s);
+                                      single_pass, dot_partials, code, cwin, len8, tbase, dot_lhs, s);
         }
         case SMH_SPMV_COLFUSED: {
             SMH_TRY(ensure_colfused(m));
@@ -1329,12 +1331,32 @@ static int inner_prod_dev(smh_crs *m, const void *d_lhs, size_t lhs_len, const v
     if (lhs_len < m->n_rows)  // lhs.get(i) for every row: densevec.rs:41
         return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %zu", lhs_len, m->n_rows - 1);
     const size_t vs = dtype_size(m->dtype);
-    SMH_TRY(ensure_cap(&m->d_y, &m->d_y_cap, m->n_rows * vs));
-    SMH_TRY(spmv_enqueue(m, d_rhs, rhs_len, m->d_y, variant, m->stream));
     void *scratch = nullptr;
     SMH_TRY(reduce_scratch(&scratch));
     char *res = (char *)scratch + kReducePartials * sizeof(double);
-    SMH_TRY(launch_dot(m->dtype, d_lhs, m->d_y, m->n_rows, scratch, res, m->stream));
+    const size_t n_dot = spmv_fused_dot_partials(m, rhs_len, variant, true);
+    bool ring = false;
+    if (!n_dot && resolve_variant(m, variant) == SMH_SPMV_VECTOR) SMH_TRY(vector_uses_ring(m, &ring));
+    if (ring) {
+        // K1r: the lanes that would store a row's sum multiply it by lhs[row] instead and the blocks leave partial sums
+        if (m->nnz > 0 && (size_t)m->max_col >= rhs_len)
+            return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", rhs_len, m->max_col);
+        SMH_TRY(ensure_cap(&m->d_y, &m->d_y_cap, ((size_t)m->ring_blocks + 1) * vs));
+        SMH_TRY(launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_col16, m->d_val, d_rhs, const_cast<void *>(d_lhs),
+                                  m->n_rows, m->nnz, m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases, m->ring_entries,
+                                  m->ring_bands, m->stream, m->d_y));
+        SMH_TRY(launch_fold2(m->dtype, m->d_y, (size_t)m->ring_blocks + 1, scratch, res, m->stream));
+    } else if (n_dot) {
+        // K1s: lhs_i * (A rhs)_i summed per tile in the SpMV's epilogue -- no y vector, no second pass; the tile partials
+        // are folded by the two small reduction kernels
+        SMH_TRY(ensure_cap(&m->d_y, &m->d_y_cap, n_dot * vs));  // (the staging buffer holds the partials here)
+        SMH_TRY(spmv_enqueue(m, d_rhs, rhs_len, nullptr, variant, m->stream, m->d_y, d_lhs));
+        SMH_TRY(launch_fold2(m->dtype, m->d_y, n_dot, scratch, res, m->stream));
+    } else {
+        SMH_TRY(ensure_cap(&m->d_y, &m->d_y_cap, m->n_rows * vs));
+        SMH_TRY(spmv_enqueue(m, d_rhs, rhs_len, m->d_y, variant, m->stream));
+        SMH_TRY(launch_dot(m->dtype, d_lhs, m->d_y, m->n_rows, scratch, res, m->stream));
+    }
     double h64 = 0;
     float h32 = 0;
     if (m->dtype == SMH_F64) SMH_HIP(hipMemcpyAsync(&h64, res, sizeof h64, hipMemcpyDeviceToHost, m->stream));

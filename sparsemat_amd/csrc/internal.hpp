@@ -64,6 +64,7 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
                        void *dot_partials /* optional: x.y per tile, stream_tiles() entries */,
                        const uint16_t *code, const uint32_t *cwin /* optional: 16-bit column codes + their interval table */,
                        const uint8_t *len8, const uint32_t *tbase /* optional (with codes): byte row lengths + tile starts */,
+                       const void *dot_lhs /* with dot_partials: the vector dotted with y (NULL: x); y may then be NULL */,
                        hipStream_t s);
 int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
 size_t stream_tiles(size_t n_rows, int rows_per_thread);
@@ -118,7 +119,7 @@ int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
                       const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, unsigned bands,
-                      hipStream_t s);
+                      hipStream_t s, void *dot_partials = nullptr /* DOT form: y = lhs (read only), n_blocks + 1 partials of lhs . (A x) */);
 // banded ring (4 bands): per-tile column intervals (the K1s inspector over 64-row tiles) and the 16-bit ring slots
 int launch_tile_intervals(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t tile_rows, size_t max_width,
                           uint32_t *win, uint32_t *d_count, hipStream_t s);
@@ -134,11 +135,17 @@ struct CrsStats {
 };
 int launch_crs_stats(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t nnz, CrsStats *d_stats,
                      hipStream_t s);
+// y = A x on stream s with the handle's kernel (capi.hip).  dot_partials (optional): when spmv_fused_dot_partials() > 0 the
+// kernel also leaves that many partial sums of x.y there (K1s epilogue; square matrices) -- CG's / PCG's p.Ap for free
+size_t spmv_fused_dot_partials(const ::smh_crs *m, size_t x_len, int variant, bool any_lhs = false);
+int spmv_enqueue(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, void *dot_partials = nullptr,
+                 const void *dot_lhs = nullptr);
 // BLAS-1 (a_dev: scalar read from device memory when non-null, else `a`)
 enum class Ew { Add, Sub, Scale, Axpy, Xpby, RSubInto };
 int launch_ew(int dtype, Ew op, void *x, const void *y, size_t n, double a, const void *a_dev, hipStream_t s);
 int launch_dot(int dtype, const void *x, const void *y, size_t n, void *partials, void *result_dev,
                hipStream_t s);
+int launch_fold2(int dtype, const void *in, size_t count, void *partials, void *result_dev, hipStream_t s);  // *result = sum(in)
 int launch_scale_values(int dtype, void *v, size_t n, double a, hipStream_t s);
 
 }  // namespace smh

@@ -8,15 +8,23 @@
 //   loop: Ap = A p;  alpha = rz / (p.Ap);  x += p*alpha;  r -= Ap*alpha;  rr = r.r;  stop test;
 //         rz' = r.(r/d);  beta = rz' / rz;  p = p*beta + r/d
 // Kernels: the SpMV is the matrix's own (K1r/K1s/...); the tail is fused so that z is never stored: one sweep updates
-// x and r and leaves the block partials of r.r and r.(r/d) (6 vector streams + d), one sweep rebuilds p (r, d, p).  The
-// two scalars of an iteration pass through the host (p.Ap, then r.r / r.z): 2 synchronisations per iteration.
+// r and leaves the block partials of r.r and r.(r/d) (r, Ap, d in; r out), one sweep adds p*alpha to x and rebuilds p
+// (p, x, r, d in; p, x out): 10 n values per iteration beside the SpMV (the plain CG moves 8 n; the two reads of d are
+// what the preconditioner costs), p.Ap out of the SpMV epilogue when the kernel offers it.  All scalars (r.r, r.z, p.Ap,
+// alpha, beta, the stop flag, the iteration count) live in device memory as in cg.hip: the host replays a hipGraph of 8
+// bodies and polls one small block per batch -- no synchronisation inside an iteration.
 // Reductions: fixed grid, per-thread strided sums, wave butterfly, LDS across waves, one block folds the partials in
 // index order -- deterministic.
 #include "internal.hpp"
 
 #include <cmath>
+#include <cstring>
 
 using namespace smh;
+
+namespace smh {
+unsigned reduce_blocks(size_t n);  // blas1.hip
+}
 
 namespace {
 
@@ -58,28 +66,91 @@ __device__ __forceinline__ void block_sums(T a, T b, T *pa, T *pb) {
     }
 }
 
-// UPDATE: x += p*alpha, r -= ap*alpha first; always: partials of r.r and r.(r/d)
+// ---- device-resident scalars (like cg.hip): nothing of an iteration passes through the host ---------------------------
+template <typename T>
+struct PcgScalars {
+    T rr, rz, pap, alpha, beta;
+    uint32_t converged;
+    uint32_t active;   // this loop body runs (not converged, fewer than iter_max bodies entered)
+    uint32_t entered;  // ... was entered: its x update is due even if the stop test then ends the loop
+    uint32_t pad_;
+    uint64_t iters;
+    uint64_t iter_max;
+    double tol;
+};
+
+template <typename T>
+__global__ void k_pcg_init(PcgScalars<T> *sc, double tol, uint64_t iter_max) {
+    sc->rr = sc->rz = sc->pap = sc->alpha = sc->beta = T(0);
+    sc->converged = sc->active = sc->entered = sc->pad_ = 0;
+    sc->iters = 0;
+    sc->iter_max = iter_max;
+    sc->tol = tol;
+}
+
+template <typename T>
+__device__ __forceinline__ T block_sum1(T a) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) a = p_add(a, (T)__shfl_down(a, o, kWave));
+    __shared__ T sa1[kBlock / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) sa1[threadIdx.x / kWave] = a;
+    __syncthreads();
+    T t = T(0);
+    if (threadIdx.x == 0) {
+        t = sa1[0];
+        for (int w = 1; w < kBlock / kWave; ++w) t = p_add(t, sa1[w]);
+    }
+    return t;  // (thread 0)
+}
+
+// out[b] = sum of block b's strided share of in[0..n): first stage of folding the SpMV epilogue's per-tile partials
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_pcg_sum_stage1(const T *__restrict__ in, uint64_t n, T *__restrict__ out) {
+    T a = T(0);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a = p_add(a, in[i]);
+    const T t = block_sum1(a);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+// p.Ap = fold(partials); decide whether this body runs; alpha = r.z / p.Ap
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_pcg_alpha(PcgScalars<T> *sc, const T *__restrict__ partials, uint32_t count) {
+    T a = T(0);
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) a = p_add(a, partials[i]);
+    const T pap = block_sum1(a);
+    if (threadIdx.x == 0) {
+        const bool active = !sc->converged && sc->iters < sc->iter_max;
+        sc->active = sc->entered = active ? 1u : 0u;
+        if (active) {
+            sc->iters += 1;
+            sc->pap = pap;
+            sc->alpha = p_div(sc->rz, pap);
+        }
+    }
+}
+
+// UPDATE: r -= ap*alpha first (gated by "active"); always: partials of r.r and r.(r/d)
 template <typename T, bool UPDATE>
 __global__ void __launch_bounds__(kBlock)
-k_pcg_update(T *__restrict__ x, T *__restrict__ r, const T *__restrict__ p, const T *__restrict__ ap, const T *__restrict__ d,
-             uint64_t n, T alpha, T *__restrict__ part_rr, T *__restrict__ part_rz) {
+k_pcg_update(const PcgScalars<T> *__restrict__ sc, T *__restrict__ r, const T *__restrict__ ap, const T *__restrict__ d, uint64_t n,
+             T *__restrict__ part_rr, T *__restrict__ part_rz) {
     // 16 bytes per lane and array (the buffers are hipMalloc'ed: aligned); the last n % V elements one by one
     constexpr int V = 16 / sizeof(T);
     typedef T VT __attribute__((ext_vector_type(V)));
+    T alpha = T(0);
+    if (UPDATE) {
+        if (!sc->active) return;  // block-uniform
+        alpha = sc->alpha;
+    }
     T s_rr = T(0), s_rz = T(0);
     const uint64_t nv = n / V, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = tid; q < nv; q += nthreads) {
         VT rv = reinterpret_cast<const VT *>(r)[q];
         const VT dv = reinterpret_cast<const VT *>(d)[q];
         if (UPDATE) {
-            VT xv = reinterpret_cast<const VT *>(x)[q];
-            const VT pv = reinterpret_cast<const VT *>(p)[q], av = reinterpret_cast<const VT *>(ap)[q];
+            const VT av = reinterpret_cast<const VT *>(ap)[q];
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                xv[e] = p_add(xv[e], p_mul(pv[e], alpha));
-                rv[e] = p_add(rv[e], -p_mul(av[e], alpha));
-            }
-            reinterpret_cast<VT *>(x)[q] = xv;
+            for (int e = 0; e < V; ++e) rv[e] = p_add(rv[e], -p_mul(av[e], alpha));
             reinterpret_cast<VT *>(r)[q] = rv;
         }
 #pragma unroll
@@ -91,7 +162,6 @@ k_pcg_update(T *__restrict__ x, T *__restrict__ r, const T *__restrict__ p, cons
     for (uint64_t i = nv * V + tid; i < n; i += nthreads) {
         T ri = r[i];
         if (UPDATE) {
-            x[i] = p_add(x[i], p_mul(p[i], alpha));
             ri = p_add(ri, -p_mul(ap[i], alpha));
             r[i] = ri;
         }
@@ -101,35 +171,71 @@ k_pcg_update(T *__restrict__ x, T *__restrict__ r, const T *__restrict__ p, cons
     block_sums(s_rr, s_rz, part_rr, part_rz);
 }
 
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-k_pcg_fold(const T *__restrict__ part_a, const T *__restrict__ part_b, unsigned n_parts, T *__restrict__ out /* [2] */) {
-    T a = T(0), b = T(0);
-    for (unsigned k = threadIdx.x; k < n_parts; k += kBlock) { a = p_add(a, part_a[k]); b = p_add(b, part_b[k]); }
-    block_sums(a, b, out, out + 1);  // (one block: blockIdx.x == 0)
-}
-
-// p = p*beta + r/d   (FIRST: p = r/d)
+// FIRST: rr, rz of the initial residual.  Else: the stop test on r.r (before beta, linearsolver.rs:52-54), then beta = rz' / rz
 template <typename T, bool FIRST>
 __global__ void __launch_bounds__(kBlock)
-k_pcg_p(T *__restrict__ p, const T *__restrict__ r, const T *__restrict__ d, uint64_t n, T beta) {
+k_pcg_beta(PcgScalars<T> *sc, const T *__restrict__ part_a, const T *__restrict__ part_b, unsigned n_parts) {
+    if (!FIRST && !sc->active) return;
+    T a = T(0), b = T(0);
+    for (unsigned k = threadIdx.x; k < n_parts; k += kBlock) { a = p_add(a, part_a[k]); b = p_add(b, part_b[k]); }
+    __shared__ T out2[2];
+    block_sums(a, b, out2, out2 + 1);  // (one block: blockIdx.x == 0; thread 0 writes)
+    if (threadIdx.x == 0) {
+        const T rr = out2[0], rz = out2[1];
+        sc->rr = rr;
+        if (FIRST) {
+            sc->rz = rz;
+        } else if (sqrt((double)rr) < sc->tol) {
+            sc->converged = 1;
+            sc->active = 0;
+        } else {
+            sc->beta = p_div(rz, sc->rz);
+            sc->rz = rz;
+        }
+    }
+}
+
+// x += p*alpha (the entered body's update, linearsolver.rs:47 -- carried out here because this sweep reads p anyway), then
+// p = p*beta + r/d while the loop goes on.  FIRST: p = r/d.
+template <typename T, bool FIRST>
+__global__ void __launch_bounds__(kBlock)
+k_pcg_p(const PcgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restrict__ r, const T *__restrict__ d, T *__restrict__ x, uint64_t n) {
     constexpr int V = 16 / sizeof(T);
     typedef T VT __attribute__((ext_vector_type(V)));
+    T alpha = T(0), beta = T(0);
+    bool rebuild = true;
+    if (!FIRST) {
+        if (!sc->entered) return;
+        alpha = sc->alpha;
+        beta = sc->beta;
+        rebuild = sc->active != 0;
+    }
     const uint64_t nv = n / V, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = tid; q < nv; q += nthreads) {
-        const VT rv = reinterpret_cast<const VT *>(r)[q], dv = reinterpret_cast<const VT *>(d)[q];
         VT pv;
-        if (!FIRST) pv = reinterpret_cast<const VT *>(p)[q];
+        if (!FIRST) {
+            pv = reinterpret_cast<const VT *>(p)[q];
+            VT xv = reinterpret_cast<const VT *>(x)[q];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const T z = p_div(rv[e], dv[e]);
-            pv[e] = FIRST ? z : p_add(p_mul(pv[e], beta), z);
+            for (int e = 0; e < V; ++e) xv[e] = p_add(xv[e], p_mul(pv[e], alpha));
+            reinterpret_cast<VT *>(x)[q] = xv;
         }
-        reinterpret_cast<VT *>(p)[q] = pv;
+        if (rebuild) {
+            const VT rv = reinterpret_cast<const VT *>(r)[q], dv = reinterpret_cast<const VT *>(d)[q];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T z = p_div(rv[e], dv[e]);
+                pv[e] = FIRST ? z : p_add(p_mul(pv[e], beta), z);
+            }
+            reinterpret_cast<VT *>(p)[q] = pv;
+        }
     }
     for (uint64_t i = nv * V + tid; i < n; i += nthreads) {
-        const T z = p_div(r[i], d[i]);
-        p[i] = FIRST ? z : p_add(p_mul(p[i], beta), z);
+        if (!FIRST) x[i] = p_add(x[i], p_mul(p[i], alpha));
+        if (rebuild) {
+            const T z = p_div(r[i], d[i]);
+            p[i] = FIRST ? z : p_add(p_mul(p[i], beta), z);
+        }
     }
 }
 
@@ -143,8 +249,11 @@ template <typename T>
 int pcg_t(smh_crs *m, const T *b_host, T *x_host, size_t n, double tol, size_t iter_max, int variant, size_t *iters_out, double *rr_out) {
     const int dt = sizeof(T) == 8 ? SMH_F64 : SMH_F32;
     hipStream_t s = nullptr;
-    T *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_ap = nullptr, *d_d = nullptr, *d_part = nullptr, *d_out = nullptr, *h_out = nullptr;
+    T *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_ap = nullptr, *d_d = nullptr, *d_part = nullptr, *d_dot = nullptr;
+    PcgScalars<T> *d_sc = nullptr, *h_sc = nullptr;
     unsigned long long *d_bad = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
     size_t iters = 0;
     double rr = 0.0;
     const unsigned grid = pcg_grid(n);
@@ -153,11 +262,14 @@ int pcg_t(smh_crs *m, const T *b_host, T *x_host, size_t n, double tol, size_t i
         const size_t vb = (n ? n : 1) * sizeof(T);
         SMH_HIP(hipMalloc((void **)&d_x, vb)); SMH_HIP(hipMalloc((void **)&d_r, vb)); SMH_HIP(hipMalloc((void **)&d_p, vb));
         SMH_HIP(hipMalloc((void **)&d_ap, vb)); SMH_HIP(hipMalloc((void **)&d_d, vb));
-        SMH_HIP(hipMalloc((void **)&d_part, (2 * (size_t)kPcgBlocks + (size_t)kReducePartials + 8) * sizeof(T)));
-        SMH_HIP(hipMalloc((void **)&d_out, 4 * sizeof(T)));
+        SMH_HIP(hipMalloc((void **)&d_part, (2 * (size_t)kPcgBlocks + 2 * (size_t)kReducePartials + 8) * sizeof(T)));
+        SMH_HIP(hipMalloc((void **)&d_sc, sizeof(PcgScalars<T>)));
         SMH_HIP(hipMalloc((void **)&d_bad, sizeof(unsigned long long)));
-        SMH_HIP(hipHostMalloc((void **)&h_out, 4 * sizeof(T), hipHostMallocDefault));
-        T *part_rr = d_part, *part_rz = d_part + kPcgBlocks, *dot_scratch = d_part + 2 * kPcgBlocks;
+        SMH_HIP(hipHostMalloc((void **)&h_sc, sizeof(PcgScalars<T>), hipHostMallocDefault));
+        T *part_rr = d_part, *part_rz = d_part + kPcgBlocks, *dot_scratch = d_part + 2 * kPcgBlocks, *fold_scratch = dot_scratch + kReducePartials + 8;
+        // p.Ap: out of the SpMV epilogue when the kernel offers it (K1s), else a separate two-stage dot
+        const size_t n_dot = spmv_fused_dot_partials(m, n, variant);
+        if (n_dot) SMH_HIP(hipMalloc((void **)&d_dot, n_dot * sizeof(T)));
         const uint32_t *off = m->d_off, *col = m->d_col;
         const void *val = m->d_val;
         SMH_HIP(hipStreamSynchronize(m->stream));
@@ -174,46 +286,87 @@ int pcg_t(smh_crs *m, const T *b_host, T *x_host, size_t n, double tol, size_t i
         SMH_HIP(hipStreamSynchronize(s));
         if (bad != ~0ull) return fail(SMH_ERR_INVALID, "Jacobi preconditioner: zero or absent diagonal entry in row %llu", bad);
         // r = b - A x; p = r / d; rr, rz
-        SMH_TRY(smh_crs_spmv_dev(m, d_x, n, d_ap, variant, s));
+        hipLaunchKernelGGL((k_pcg_init<T>), dim3(1), dim3(1), 0, s, d_sc, tol, (uint64_t)iter_max);
+        SMH_TRY(spmv_enqueue(m, d_x, n, d_ap, variant, s));
         if (n) SMH_TRY(launch_ew(dt, Ew::Sub, d_r, d_ap, n, 0.0, nullptr, s));
-        hipLaunchKernelGGL((k_pcg_update<T, false>), dim3(grid), dim3(kBlock), 0, s, d_x, d_r, d_p, d_ap, d_d, (uint64_t)n, T(0), part_rr, part_rz);
-        hipLaunchKernelGGL((k_pcg_fold<T>), dim3(1), dim3(kBlock), 0, s, part_rr, part_rz, grid, d_out);
-        hipLaunchKernelGGL((k_pcg_p<T, true>), dim3(grid), dim3(kBlock), 0, s, d_p, d_r, d_d, (uint64_t)n, T(0));
+        hipLaunchKernelGGL((k_pcg_update<T, false>), dim3(grid), dim3(kBlock), 0, s, d_sc, d_r, d_ap, d_d, (uint64_t)n, part_rr, part_rz);
+        hipLaunchKernelGGL((k_pcg_beta<T, true>), dim3(1), dim3(kBlock), 0, s, d_sc, part_rr, part_rz, grid);
+        hipLaunchKernelGGL((k_pcg_p<T, true>), dim3(grid), dim3(kBlock), 0, s, d_sc, d_p, d_r, d_d, d_x, (uint64_t)n);
         SMH_HIP(hipGetLastError());
-        SMH_HIP(hipMemcpyAsync(h_out, d_out, 2 * sizeof(T), hipMemcpyDeviceToHost, s));
-        SMH_HIP(hipStreamSynchronize(s));
-        T rr_t = h_out[0], rz = h_out[1];
-        rr = (double)rr_t;
-        for (size_t k = 0; k < iter_max; ++k) {
-            SMH_TRY(smh_crs_spmv_dev(m, d_p, n, d_ap, variant, s));
-            if (n) SMH_TRY(launch_dot(dt, d_p, d_ap, n, dot_scratch, d_out + 2, s));
-            else SMH_HIP(hipMemsetAsync(d_out + 2, 0, sizeof(T), s));
-            SMH_HIP(hipMemcpyAsync(h_out + 2, d_out + 2, sizeof(T), hipMemcpyDeviceToHost, s));
-            SMH_HIP(hipStreamSynchronize(s));
-            const T alpha = rz / h_out[2];
-            hipLaunchKernelGGL((k_pcg_update<T, true>), dim3(grid), dim3(kBlock), 0, s, d_x, d_r, d_p, d_ap, d_d, (uint64_t)n, alpha, part_rr, part_rz);
-            hipLaunchKernelGGL((k_pcg_fold<T>), dim3(1), dim3(kBlock), 0, s, part_rr, part_rz, grid, d_out);
+        // one loop body: SpMV (+ p.Ap), alpha, update of r + partials, stop test / beta, x and p
+        auto body = [&]() -> int {
+            SMH_TRY(spmv_enqueue(m, d_p, n, d_ap, variant, s, d_dot));
+            if (d_dot && n_dot > (size_t)kReducePartials) {
+                const unsigned fb = reduce_blocks(n_dot);
+                hipLaunchKernelGGL((k_pcg_sum_stage1<T>), dim3(fb), dim3(kBlock), 0, s, d_dot, (uint64_t)n_dot, fold_scratch);
+                hipLaunchKernelGGL((k_pcg_alpha<T>), dim3(1), dim3(kBlock), 0, s, d_sc, fold_scratch, fb);
+            } else if (d_dot) {
+                hipLaunchKernelGGL((k_pcg_alpha<T>), dim3(1), dim3(kBlock), 0, s, d_sc, d_dot, (uint32_t)n_dot);
+            } else {
+                if (n) SMH_TRY(launch_dot(dt, d_p, d_ap, n, dot_scratch, dot_scratch + kReducePartials, s));
+                else SMH_HIP(hipMemsetAsync(dot_scratch + kReducePartials, 0, sizeof(T), s));
+                hipLaunchKernelGGL((k_pcg_alpha<T>), dim3(1), dim3(kBlock), 0, s, d_sc, dot_scratch + kReducePartials, 1u);
+            }
+            hipLaunchKernelGGL((k_pcg_update<T, true>), dim3(grid), dim3(kBlock), 0, s, d_sc, d_r, d_ap, d_d, (uint64_t)n, part_rr, part_rz);
+            hipLaunchKernelGGL((k_pcg_beta<T, false>), dim3(1), dim3(kBlock), 0, s, d_sc, part_rr, part_rz, grid);
+            hipLaunchKernelGGL((k_pcg_p<T, false>), dim3(grid), dim3(kBlock), 0, s, d_sc, d_p, d_r, d_d, d_x, (uint64_t)n);
             SMH_HIP(hipGetLastError());
-            SMH_HIP(hipMemcpyAsync(h_out, d_out, 2 * sizeof(T), hipMemcpyDeviceToHost, s));
-            SMH_HIP(hipStreamSynchronize(s));
-            ++iters;
-            rr_t = h_out[0];
-            rr = (double)rr_t;
-            if (std::sqrt(rr) < tol) break;
-            const T beta = h_out[1] / rz;
-            rz = h_out[1];
-            hipLaunchKernelGGL((k_pcg_p<T, false>), dim3(grid), dim3(kBlock), 0, s, d_p, d_r, d_d, (uint64_t)n, beta);
-            SMH_HIP(hipGetLastError());
+            return SMH_OK;
+        };
+        // batches of check_every bodies, captured once into a hipGraph and replayed (bodies past the stop are no-ops on the
+        // device); the host polls the scalar block once per batch
+        const size_t check_every = 8;
+        if (iter_max > check_every && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int crc = SMH_OK;
+            for (size_t i = 0; i < check_every && crc == SMH_OK; ++i) crc = body();
+            const hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (crc != SMH_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                graph_exec = nullptr;  // plain stream launches instead
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
         }
+        size_t launched = 0;
+        bool converged = false;
+        auto poll = [&]() -> int {
+            SMH_HIP(hipMemcpyAsync(h_sc, d_sc, sizeof(PcgScalars<T>), hipMemcpyDeviceToHost, s));
+            SMH_HIP(hipStreamSynchronize(s));
+            converged = h_sc->converged != 0;
+            iters = (size_t)h_sc->iters;
+            rr = (double)h_sc->rr;
+            return SMH_OK;
+        };
+        while (launched < iter_max) {
+            size_t batch = iter_max - launched < check_every ? iter_max - launched : check_every;
+            if (graph_exec) {
+                SMH_HIP(hipGraphLaunch(graph_exec, s));
+                batch = check_every;
+            } else {
+                for (size_t i = 0; i < batch; ++i) SMH_TRY(body());
+            }
+            launched += batch;
+            SMH_TRY(poll());
+            if (converged) break;
+        }
+        if (iter_max == 0) SMH_TRY(poll());
         if (n) SMH_HIP(hipMemcpyAsync(x_host, d_x, n * sizeof(T), hipMemcpyDeviceToHost, s));
         SMH_HIP(hipStreamSynchronize(s));
         return SMH_OK;
     };
     const int rc = go();
-    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    char keep[512];
+    strncpy(keep, smh_last_error(), sizeof keep);
+    keep[sizeof keep - 1] = 0;
+    if (s) (void)hipStreamSynchronize(s);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (s) (void)hipStreamDestroy(s);
     (void)hipFree(d_x); (void)hipFree(d_r); (void)hipFree(d_p); (void)hipFree(d_ap); (void)hipFree(d_d); (void)hipFree(d_part);
-    (void)hipFree(d_out); (void)hipFree(d_bad);
-    if (h_out) (void)hipHostFree(h_out);
+    (void)hipFree(d_dot); (void)hipFree(d_sc); (void)hipFree(d_bad);
+    if (h_sc) (void)hipHostFree(h_sc);
+    (void)hipGetLastError();
+    if (rc != SMH_OK) return fail(rc, "%s", keep);
     if (iters_out) *iters_out = iters;
     if (rr_out) *rr_out = rr;
     return rc;

@@ -145,11 +145,13 @@ __device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const void *__re
     }
 }
 
-template <typename T, int LANES, int CH, int SB, int GM, bool C16, int RING>
+// DOT (SparseMatrix::inner_prod, sparsematrix.rs:161-171): `y` then holds lhs, nothing is stored, and every lane adds
+// lhs[row] * (A x)[row] of the rows it would have stored to its *dacc
+template <typename T, int LANES, int CH, int SB, int GM, bool C16, int RING, bool DOT = false>
 __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t base, uint64_t row_end,
                                              const void *__restrict__ colp, const T *__restrict__ valp,
                                              const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
-                                             uint32_t nnz_lim, uint32_t lane) {
+                                             uint32_t nnz_lim, uint32_t lane, T *dacc = nullptr) {
     constexpr int RPS = kWave / LANES;
     const uint32_t j = lane % LANES;
     T out = T(0);
@@ -204,15 +206,19 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
         }
     }
     const uint64_t row = base + lane;
-    if (lane < (uint32_t)(SB * RPS) && row < row_end) y[row] = out;
+    if constexpr (DOT) {
+        if (lane < (uint32_t)(SB * RPS) && row < row_end) *dacc = r2_fma(y[row], out, *dacc);
+    } else {
+        if (lane < (uint32_t)(SB * RPS) && row < row_end) y[row] = out;
+    }
 }
 
 // col: the 32-bit column array, or (C16) the 16-bit one
-template <typename T, int LANES, int CH, int GM, bool C16, int RING>
+template <typename T, int LANES, int CH, int GM, bool C16, int RING, bool DOT = false>
 __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, const void *__restrict__ col,
                                            const T *__restrict__ val, const T *__restrict__ x, const T *ring,
                                            T *__restrict__ y, uint64_t rb, uint64_t re, uint32_t nnz_lim,
-                                           uint64_t last_chunk, uint32_t wave, uint32_t lane) {
+                                           uint64_t last_chunk, uint32_t wave, uint32_t lane, T *dacc = nullptr) {
     constexpr int STEPS = LANES;
     constexpr int SBMAX = sizeof(T) == 8 ? 1 : kRing2SB;  // f64 chunks take 12 VGPRs: one step per unit
     constexpr int SB = STEPS < SBMAX ? STEPS : SBMAX;
@@ -232,22 +238,22 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
     issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
     for (;;) {
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM, C16, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
             break;
         }
         // program order = age order: offsets(+2) older than chunks(+1); both stay in flight under consume
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB, C16>(B, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM, C16, RING>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
         A.o0 = N.o0; A.o1 = N.o1;
         base += STRIDE;
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM, C16, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+            consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
             break;
         }
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM, C16, RING>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane);
+        consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
         B.o0 = N.o0; B.o1 = N.o1;
         base += STRIDE;
     }
@@ -255,11 +261,15 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
 
 // C16: ring phases stream the 16-bit column array `col16` (6 instead of 8 bytes per f32 entry); phases with global
 // gathers need whole columns and keep reading `col`
-template <typename T, int LANES, int CH, bool C16, int RING>
+// DOT: y holds lhs (read only) and dot_partials[blockIdx.x] = this block's share of lhs . (A x); nothing else is stored
+template <typename T, int LANES, int CH, bool C16, int RING, bool DOT = false>
 __global__ void __launch_bounds__((Ring2Cfg<T, RING>::kThreads), 4)  // 4 waves per SIMD: 16 waves per CU either way
 k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint16_t *__restrict__ col16,
              const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
-             const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases, uint32_t bands) {
+             const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases, uint32_t bands,
+             T *__restrict__ dot_partials) {
+    T dacc_v = T(0);
+    T *dacc = DOT ? &dacc_v : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];  // RING * sizeof(T), dynamic
     T *ring = reinterpret_cast<T *>(ring_raw);
     // bands == 1: one window, slot = column mod RING.  bands == 4 (banded plan, C16 only): band k owns slots
@@ -289,14 +299,27 @@ k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
         // gather mode of the phase: 1 = LDS ring, 0 = L1/L2-cached global gathers, 2 = L1-bypassing (nt) global
         // gathers for phases whose columns have no locality to keep in the 32 KiB L1
         if (ph.use_ring == 1)
-            phase_rows<T, LANES, CH, 1, C16, RING>(off, C16 ? (const void *)col16 : (const void *)col, val, x, ring, y, ph.row_begin,
-                                                   ph.row_end, nnz_lim, last_chunk, wave, lane);
+            phase_rows<T, LANES, CH, 1, C16, RING, DOT>(off, C16 ? (const void *)col16 : (const void *)col, val, x, ring, y, ph.row_begin,
+                                                        ph.row_end, nnz_lim, last_chunk, wave, lane, dacc);
         else if (ph.use_ring == 2)
-            phase_rows<T, LANES, CH, 2, false, RING>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave,
-                                                     lane);
+            phase_rows<T, LANES, CH, 2, false, RING, DOT>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave,
+                                                          lane, dacc);
         else
-            phase_rows<T, LANES, CH, 0, false, RING>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave,
-                                                     lane);
+            phase_rows<T, LANES, CH, 0, false, RING, DOT>(off, col, val, x, ring, y, ph.row_begin, ph.row_end, nnz_lim, last_chunk, wave,
+                                                          lane, dacc);
+    }
+    if constexpr (DOT) {  // fixed order: lanes (butterfly), waves (index order) -- bitwise reproducible
+        __shared__ T s_dot[kRing2Threads / kWave];
+        T d = dacc_v;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
+        if (lane == 0) s_dot[wave] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            T t = T(0);
+            for (int w = 0; w < kRing2Threads / kWave; ++w) t += s_dot[w];
+            dot_partials[blockIdx.x] = t;
+        }
     }
 }
 
@@ -312,6 +335,22 @@ __global__ void k_ring2_tail(const uint32_t *__restrict__ off, const uint32_t *_
         while ((uint64_t)off[r + 1] <= k) ++r;
         y[r] = r2_fma(val[k], x[col[k]], y[r]);
     }
+}
+
+// ... and for the DOT form: *out = sum over those entries of lhs[row] * val * x[col] (their share of lhs . (A x))
+template <typename T>
+__global__ void k_ring2_tail_dot(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
+                                 const T *__restrict__ x, const T *__restrict__ lhs, T *__restrict__ out, uint64_t n_rows, uint64_t k_begin,
+                                 uint64_t nnz) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t r = n_rows - 1;
+    while (r > 0 && (uint64_t)off[r] > k_begin) --r;
+    T acc = T(0);
+    for (uint64_t k = k_begin; k < nnz; ++k) {
+        while ((uint64_t)off[r + 1] <= k) ++r;
+        acc = r2_fma(lhs[r], val[k] * x[col[k]], acc);
+    }
+    *out = acc;
 }
 
 // col16[k] = low half of col[k] (k < nnz), zero padding up to the next multiple of 4 entries and one chunk beyond
@@ -330,22 +369,25 @@ int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size
     return SMH_OK;
 }
 
+// dot_partials != NULL: the DOT form -- `y` is lhs (read only), dot_partials[0..n_blocks] receive the blocks' shares of
+// lhs . (A x) plus, in slot n_blocks, that of an unpadded array's last partial chunk
 template <typename T, int RING>
 static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16, const T *val,
                           const T *x, T *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
-                          const uint32_t *phase_ptr, const RingPhase *phases, uint32_t bands, hipStream_t s) {
+                          const uint32_t *phase_ptr, const RingPhase *phases, uint32_t bands, T *dot_partials, hipStream_t s) {
     if (bands == 4u && !col16) return fail(SMH_ERR_INVALID, "banded ring plan without the 16-bit slot array");
     // entries the streaming kernel may touch: everything when the arrays are padded to a multiple of 4,
     // else only whole chunks (the rest goes to k_ring2_tail)
     const uint64_t nnz_lim = padded ? nnz : (nnz & ~uint64_t(3));
+    if (dot_partials) SMH_HIP(hipMemsetAsync(dot_partials, 0, ((size_t)n_blocks + 1) * sizeof(T), s));
     if (nnz_lim == 0) {
-        SMH_HIP(hipMemsetAsync(y, 0, n_rows * sizeof(T), s));
+        if (!dot_partials) SMH_HIP(hipMemsetAsync(y, 0, n_rows * sizeof(T), s));
     } else {
         const uint64_t last_chunk = (nnz_lim - 1) & ~uint64_t(3);
         dim3 grid(n_blocks), block(Ring2Cfg<T, RING>::kThreads);
         constexpr size_t lds_bytes = (size_t)RING * sizeof(T);
         // dynamic LDS above 64 KiB must be allowed per kernel (idempotent, cheap)
-#define SMH_R2_LAUNCH1(L, C, N)                                                                                          \
+#define SMH_R2_LAUNCH2(L, C, N, D)                                                                                       \
     do {                                                                                                                 \
         /* once per (instantiation, DEVICE): function attributes are per device, and smh_par_* places blocks on       \
            several devices.  Bit d of the mask = device d has the opt-in; a second thread racing on the same bit only   \
@@ -353,12 +395,16 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
         static std::atomic<uint64_t> attr_mask{0};                                                                       \
         const uint64_t dev_bit = 1ull << (unsigned)(current_device() & 63);                                              \
         if (!(attr_mask.load(std::memory_order_acquire) & dev_bit)) {                                                    \
-            SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C, N, RING>),                  \
+            SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring2<T, L, C, N, RING, D>),               \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                    \
             attr_mask.fetch_or(dev_bit, std::memory_order_release);                                                      \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N, RING>), grid, block, lds_bytes, s, off, col, col16, val, x, y,      \
-                           (uint32_t)nnz_lim, last_chunk, phase_ptr, phases, bands);                                     \
+        hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N, RING, D>), grid, block, lds_bytes, s, off, col, col16, val, x, y,   \
+                           (uint32_t)nnz_lim, last_chunk, phase_ptr, phases, bands, dot_partials);                       \
+    } while (0)
+#define SMH_R2_LAUNCH1(L, C, N)                                                            \
+    do {                                                                                   \
+        if (dot_partials) SMH_R2_LAUNCH2(L, C, N, true); else SMH_R2_LAUNCH2(L, C, N, false); \
     } while (0)
 #define SMH_R2_LAUNCH(L, C)                                            \
     do {                                                               \
@@ -380,33 +426,41 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
         }
 #undef SMH_R2_LAUNCH
 #undef SMH_R2_LAUNCH1
+#undef SMH_R2_LAUNCH2
         SMH_HIP(hipGetLastError());
     }
     if (nnz_lim != nnz) {
-        hipLaunchKernelGGL(k_ring2_tail<T>, dim3(1), dim3(64), 0, s, off, col, val, x, y, (uint64_t)n_rows, nnz_lim, (uint64_t)nnz);
+        if (dot_partials)
+            hipLaunchKernelGGL(k_ring2_tail_dot<T>, dim3(1), dim3(64), 0, s, off, col, val, x, (const T *)y, dot_partials + n_blocks,
+                               (uint64_t)n_rows, nnz_lim, (uint64_t)nnz);
+        else
+            hipLaunchKernelGGL(k_ring2_tail<T>, dim3(1), dim3(64), 0, s, off, col, val, x, y, (uint64_t)n_rows, nnz_lim, (uint64_t)nnz);
         SMH_HIP(hipGetLastError());
     }
     return SMH_OK;
 }
 
-// ring_entries: what the phase plan was built for (kRingEntries; kRingEntriesWide for f32 matrices that need it)
+// ring_entries: what the phase plan was built for (kRingEntries; kRingEntriesWide for f32 matrices that need it).
+// dot_partials != NULL (n_blocks + 1 values): the DOT form, `y` = lhs (see launch_ring2_t).
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
                       const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, unsigned bands,
-                      hipStream_t s) {
+                      hipStream_t s, void *dot_partials) {
     if (n_rows == 0) return SMH_OK;
     if (bands != 1u && bands != 4u) return fail(SMH_ERR_INVALID, "ring kernel: %u bands", bands);
     if (dtype == SMH_F64) {
         if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "f64 ring kernel: ring of %u columns", ring_entries);
         return launch_ring2_t<double, kRingEntries>(lanes, chunks, off, col, col16, (const double *)val, (const double *)x,
-                                                    (double *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, s);
+                                                    (double *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands,
+                                                    (double *)dot_partials, s);
     }
     if (ring_entries == (unsigned)kRingEntriesWide)
         return launch_ring2_t<float, kRingEntriesWide>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x,
-                                                       (float *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, s);
+                                                       (float *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands,
+                                                       (float *)dot_partials, s);
     if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "ring kernel: ring of %u columns", ring_entries);
     return launch_ring2_t<float, kRingEntries>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x, (float *)y,
-                                               n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, s);
+                                               n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, (float *)dot_partials, s);
 }
 
 }  // namespace smh

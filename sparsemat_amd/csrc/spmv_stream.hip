@@ -147,8 +147,9 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 
 // ---- kernel ----------------------------------------------------------------------------------------------
 // RPT = rows per thread: a tile is RPT*256 consecutive rows (2 when every 512-row tile fits the LDS stage)
-// DOT: also leave dot_partials[tile] = sum over the tile's rows of x[row] * y[row] (square matrices): the
-// p.Ap of a CG iteration falls out of the SpMV epilogue, in a fixed order (bitwise reproducible).
+// DOT: also leave dot_partials[tile] = sum over the tile's rows of dot_lhs[row] * y[row]: with dot_lhs = x (square
+// matrices) the p.Ap of a CG iteration falls out of the SpMV epilogue, with any lhs it is SparseMatrix::inner_prod
+// (sparsematrix.rs:161-171; y == NULL then: nothing is stored).  Fixed order: bitwise reproducible.
 // ACC: y += A x (the column-blocked variant K2c accumulates one column block per launch).
 // MULTI: tiles may hold more entries than the LDS stage (pass loop).  MULTI = false is the host's promise that no
 // tile does; the body is then loop-free and needs 70 instead of 90 VGPRs (f32: 7 instead of 5 waves per SIMD).
@@ -196,7 +197,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
               uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials,
               const uint16_t *__restrict__ code, const uint32_t *__restrict__ cwin, const uint8_t *__restrict__ len8,
-              const uint32_t *__restrict__ tbase) {
+              const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs) {
     static_assert(!C16 || (RPT == 1 && !XWIN), "the code table describes 256-row tiles");
     static_assert(!L8 || (C16 && !MULTI), "row lengths as bytes: single-pass 256-row tiles with column codes");
     __shared__ uint32_t s_wtot[L8 ? kBlock / kWave : 1];
@@ -380,12 +381,12 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     for (int rr = 0; rr < RPT; ++rr) {
         const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
 #if SMH_STREAM_NT_STORE  // A/B: y leaves with a non-temporal store (it is not read again by this kernel)
-        if (r < r1) {
+        if (r < r1 && (!DOT || y)) {  // (DOT with y == NULL: only lhs . (A x) is wanted -- SparseMatrix::inner_prod)
             if constexpr (ACC) y[r] = st_add(y[r], sum[rr]);
             else __builtin_nontemporal_store(sum[rr], &y[r]);
         }
 #else
-        if (r < r1) y[r] = ACC ? st_add(y[r], sum[rr]) : sum[rr];
+        if (r < r1 && (!DOT || y)) y[r] = ACC ? st_add(y[r], sum[rr]) : sum[rr];
 #endif
     }
     if constexpr (DOT) {
@@ -394,7 +395,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
 #pragma unroll
         for (int rr = 0; rr < RPT; ++rr) {
             const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
-            if (r < r1) d += x[r] * sum[rr];
+            if (r < r1) d += dot_lhs[r] * sum[rr];
         }
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
@@ -413,7 +414,8 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
 template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
                            size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
-                           const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, hipStream_t s) {
+                           const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs,
+                           hipStream_t s) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
@@ -425,7 +427,7 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
 #define SMH_ST_LAUNCH(XW, R, D, M, C)                                                                                    \
     hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M, kStreamCap, C>), grid, block, lds_pad, s, off, col, val, x, y, \
                        (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin,                   \
-                       (const uint8_t *)nullptr, (const uint32_t *)nullptr)
+                       (const uint8_t *)nullptr, (const uint32_t *)nullptr, dot_lhs)
 #define SMH_ST_PICK(XW, R, C)                                                     \
     do {                                                                          \
         if (single_pass) {                                                        \
@@ -439,10 +441,10 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     else if (code && cwin && len8 && tbase && single_pass) {  // column codes + byte row lengths
         if (dot_partials)
             hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase);
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
         else
             hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase);
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
     }
     else if (code && cwin) SMH_ST_PICK(false, 1, true);  // 16-bit column codes (every tile described)
     else SMH_ST_PICK(false, 1, false);
@@ -464,7 +466,8 @@ static int launch_stream_block_t(const uint32_t *off, const uint32_t *col, const
 #define SMH_SB_LAUNCH(R, A, M)                                                                                          \
     hipLaunchKernelGGL((k_spmv_stream<T, false, R, false, A, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
                        (uint64_t)nnz_total, readable, n_tiles, (const uint32_t *)nullptr, (T *)nullptr,         \
-                       (const uint16_t *)nullptr, (const uint32_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr)
+                       (const uint16_t *)nullptr, (const uint32_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr,  \
+                       (const T *)nullptr)
 #define SMH_SB_PICK(R)                                                                      \
     do {                                                                                     \
         if (single_pass) { if (acc) SMH_SB_LAUNCH(R, true, false); else SMH_SB_LAUNCH(R, false, false); } \
@@ -502,13 +505,15 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
                        void *dot_partials, const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase,
-                       hipStream_t s) {
+                       const void *dot_lhs, hipStream_t s) {
     if (n_rows == 0) return SMH_OK;
+    if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
+    if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
     if (dtype == SMH_F64)
         return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
-                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, s);
+                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s);
     return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
-                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, s);
+                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s);
 }
 
 // row lengths as bytes (rows padded to whole 256-row tiles with zeros) and the tiles' first entries (n_tiles + 1 values);

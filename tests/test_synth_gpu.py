@@ -216,7 +216,7 @@ def test_full_size_c4_laplacian_512_spmv_and_cg(gpu):
     alpha / beta drift from the exact quotients by ~1e-3, while the device folds with a fixed tree.  As for the SpMV rows
     (tests/util.py), the device is therefore measured against an (effectively) exact restatement -- the same recurrence, the
     same f32 element-wise roundings, the two dot products per iteration accumulated in f64 -- and must be no further from
-    it than the oracle is: measured in r02, device 3e-7 of max|x| against the oracle's 2.9e-3."""
+    it than the oracle is: measured in r02, device 2.1e-6 of max|x| against the oracle's 2.9e-3."""
     g = 512
     n = g ** 3
     m = synth.crs_laplace3d(g, g, g, np.float32)

@@ -8,7 +8,6 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sparsemat_amd as sm  # noqa: E402
@@ -19,7 +18,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=512)
     args = ap.parse_args()
-    torch.cuda.init()
     g, dtype = args.grid, np.float32
     n = g ** 3
     a = synth.crs_laplace3d(g, g, g, dtype)
@@ -33,9 +31,10 @@ def main():
         solver(iters).solve(a, b, x)
         return time.perf_counter() - t0
 
-    # vector streams of the tail: PCG = p.Ap 2 + update 7 (x, r, p, Ap, d in; x, r out) + p 4 (r, d, p in; p out); CG = 9 (DESIGN K5)
-    for name, make, streams in (("Jacobi PCG", lambda it: sm.JacobiConjugateGradient(0.0, it), 13),
-                                ("CG (host vectors)", lambda it: sm.ConjugateGradient(0.0, it), 9)):
+    # vector streams of the tail (what the kernels move; p.Ap rides the K1s epilogue): PCG = update 4 (r, Ap, d in; r out) +
+    # x/p sweep 6 (p, x, r, d in; p, x out); CG = update 3 + x/p sweep 5 (DESIGN K5)
+    for name, make, streams in (("Jacobi PCG", lambda it: sm.JacobiConjugateGradient(0.0, it), 10),
+                                ("CG (host vectors)", lambda it: sm.ConjugateGradient(0.0, it), 8)):
         bytes_iter = spmv_bytes + streams * n * vs
         run(make, 3)  # warm-up (plans)
         t_a, t_b = run(make, 20), run(make, 80)
