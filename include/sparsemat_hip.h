@@ -162,6 +162,11 @@ int smh_crs_download(const smh_crs *m, uint32_t *offset_rows, uint32_t *columns,
 size_t smh_crs_n_rows(const smh_crs *m);
 size_t smh_crs_n_cols(const smh_crs *m);
 size_t smh_crs_nnz(const smh_crs *m);
+/* entries the reference's SparseMatCRS would still hold in columns / values although no row reaches them (the first-push
+ * quirk of smh_crs_replay / smh_crs_transpose / smh_crs_prod, see smh_crs_replay): 0 or 1.  The reference's
+ * n_non_zero_entries() (= columns.len(), sparsemat_crs.rs:132-134) and density() count them: they equal
+ * smh_crs_nnz() + smh_crs_orphans(); the arrays of this handle hold smh_crs_nnz() entries. */
+size_t smh_crs_orphans(const smh_crs *m);
 int smh_crs_dtype(const smh_crs *m);
 int smh_crs_max_row_len(const smh_crs *m, uint32_t *out);
 /* smallest / largest column index stored (0/0 for a matrix without entries): the part of x a

@@ -56,6 +56,7 @@ SIGNATURES = {
     "smh_crs_n_rows": (_sz, [_vp]),
     "smh_crs_n_cols": (_sz, [_vp]),
     "smh_crs_nnz": (_sz, [_vp]),
+    "smh_crs_orphans": (_sz, [_vp]),
     "smh_crs_dtype": (_int, [_vp]),
     "smh_crs_max_row_len": (_int, [_vp, _u32p]),
     "smh_crs_col_range": (_int, [_vp, _u32p, _u32p]),

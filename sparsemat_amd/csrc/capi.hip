@@ -819,8 +819,8 @@ static int assemble_common(smh_dtype dtype, size_t n_ops, const uint32_t *rows, 
             SMH_HIP(hipMemcpy(&v0, values, vs, kind));
             if (transposing) op0 = 1;
             else if (ops) SMH_HIP(hipMemcpy(&op0, ops, 1, kind));
-            if (n_ops == 1) return no_rows((size_t)c01[0] + 1);
-            if (r01[1] < r01[0]) { skip = 1; min_cols = (size_t)c01[0] + 1; }
+            if (n_ops == 1) { m->orphans = 1; return no_rows((size_t)c01[0] + 1); }
+            if (r01[1] < r01[0]) { skip = 1; min_cols = (size_t)c01[0] + 1; m->orphans = 1; }
             else if (r01[1] == r01[0] && c01[1] == c01[0]) { skip = 1; twin = true; }
         }
         const uint32_t *d_rows = rows, *d_cols = cols;
@@ -1008,6 +1008,7 @@ int smh_crs_download(const smh_crs *m, uint32_t *offset_rows, uint32_t *columns,
 size_t smh_crs_n_rows(const smh_crs *m) { return m ? m->n_rows : 0; }
 size_t smh_crs_n_cols(const smh_crs *m) { return m ? m->n_cols : 0; }
 size_t smh_crs_nnz(const smh_crs *m) { return m ? m->nnz : 0; }
+size_t smh_crs_orphans(const smh_crs *m) { return m ? m->orphans : 0; }
 int smh_crs_dtype(const smh_crs *m) { return m ? m->dtype : -1; }
 
 int smh_crs_max_row_len(const smh_crs *m, uint32_t *out) {

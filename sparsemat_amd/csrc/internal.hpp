@@ -155,6 +155,7 @@ struct smh_crs {
     int dtype = SMH_F32;
     int device = 0;
     size_t n_rows = 0, n_cols = 0, nnz = 0;
+    size_t orphans = 0;  // entries the reference's container still holds but no row reaches (first-push quirk of a replay): 0 or 1
     uint32_t *d_off = nullptr;
     uint32_t *d_col = nullptr;
     void *d_val = nullptr;

@@ -156,7 +156,13 @@ class SparseMatCRS:
         return lib().smh_crs_n_cols(self._h)
 
     def n_non_zero_entries(self):
+        """Entries the handle's arrays hold.  The reference's ``n_non_zero_entries()`` (``columns.len()``) additionally counts
+        an entry orphaned by the first-push quirk of a replay / transpose / prod: add ``orphans()``."""
         return lib().smh_crs_nnz(self._h)
+
+    def orphans(self):
+        """0 or 1: the entry the reference's container would still hold although no row reaches it (``smh_crs_orphans``)."""
+        return lib().smh_crs_orphans(self._h)
 
     def empty(self):  # sparsematrix.rs:119-121
         return self.n_rows() == 0

@@ -135,8 +135,12 @@ def test_transpose_bit_exact(gpu, dtype, kind):
     t = m.transpose()
     expect = oracle.transpose(off, col, val)
     same_crs(t, expect)
+    # the reference's n_non_zero_entries() (= columns.len()) counts an orphaned first entry: nnz + orphans on this side
+    assert t.n_non_zero_entries() + t.orphans() == expect[5]
     if kind == "first_row_descending":
-        assert expect[5] == len(expect[3]) + 1  # the orphan the reference still counts
+        assert expect[5] == len(expect[3]) + 1 and t.orphans() == 1  # the orphan the reference still counts
+    else:
+        assert t.orphans() == (1 if expect[5] != len(expect[3]) else 0)
     # (A^T) x through the hot path, bit-exact
     x = rng.uniform(-1, 1, n_rows).astype(dtype)
     assert t.mvp(x, variant="stream").tobytes() == oracle.spmv(expect[2], expect[3], expect[4], x).tobytes()

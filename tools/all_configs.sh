@@ -13,9 +13,10 @@ run() {  # title, command...
 }
 run "C1" python3 tests/bench/c1_bench.py &&
 run "C2 banded / contiguous band / uniform, C3 power law, C4 Laplacian 512^3 (quick_bench, single launches)" \
-    python3 tools/quick_bench.py --cases banded,diag,uniform,powerlaw,lap512,banded64 --lanes 8 &&
+    python3 tools/quick_bench.py --cases banded,diag,uniform,powerlaw,lap512,banded64 --lanes 8 --cb-shifts 18,19 &&
 run "C4 CG" python3 tools/cg_bench.py --iters 100 &&
 run "C4 Jacobi PCG (extension) next to CG" python3 tools/pcg_bench.py &&
+run "SparseMatrix::inner_prod next to the plain product" python3 tools/inner_prod_bench.py &&
 run "DenseVec kernels" python3 tools/blas1_bench.py &&
 run "assembly" python3 tests/bench/assemble_bench.py &&
 run "transpose, column tables" python3 tests/bench/transpose_bench.py &&
