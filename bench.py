@@ -237,12 +237,14 @@ def rendezvous_id(rank, make_id):
         os.replace(tmp, path)
         return uid, path
     deadline = time.time() + 600
+    fresh_after = time.time() - 900  # (a leftover of a crashed launch with a recycled pid would be older than this)
     while time.time() < deadline:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid, path
+            if os.path.getmtime(path) >= fresh_after:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    return uid, path
         except OSError:
             pass
         time.sleep(0.02)
