@@ -63,10 +63,13 @@ typedef enum {
                          /* (stencil-like matrices stream 16-bit column codes, built once)  */
     SMH_SPMV_COLBLOCK = 5, /* K2c: columns without locality and x larger than an L2: the     */
                          /* device copy is split into blocks of 2^19 columns, y += A_b x    */
-    SMH_SPMV_COLFUSED = 6 /* K2f: the same blocking in ONE sweep over y: a wave keeps the    */
+    SMH_SPMV_COLFUSED = 6, /* K2f: the same blocking in ONE sweep over y: a wave keeps the   */
                          /* sums of its rows in registers while all waves walk the column   */
                          /* blocks together (AUTO's choice when the rows are of similar     */
                          /* length; runs K2c when a (row, block) pair exceeds 255 entries)  */
+    SMH_SPMV_COLSPLIT = 7 /* K2s: skewed rows without column locality (BASELINE C3): the rows */
+                         /* of >= 64 entries as a compacted matrix through K2c, the rest     */
+                         /* through K2f, y assembled from both (K2c when not worth it)      */
 } smh_spmv_variant;
 
 typedef struct smh_crs smh_crs; /* device-resident SparseMatCRS<T,u32>  (sparsemat_crs.rs:9-17) */
@@ -236,6 +239,13 @@ int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int 
 int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_blocks_out, uint32_t *rows_per_lane_out,
                      size_t *n_tiles_out, uint32_t *tile_rows_out, uint32_t *segments_out, uint8_t *counts_out,
                      uint32_t *columns_out, void *values_out);
+
+/* K2s, the row-length split (built on first use): *split_out == 1 when the handle keeps its rows of >= *min_long_out
+ * entries as a compacted sub-matrix (row i of it = row long_rows_out[i], n_long of them; global columns) and all rows
+ * with those emptied as a second one -- both are ordinary handles owned by `m` (inspect, do not destroy) -- and 0 when
+ * that is not worth it (long rows more than a quarter of the rows, or holding less than a quarter of the entries). */
+int smh_crs_colsplit(smh_crs *m, int *split_out, uint32_t *min_long_out, size_t *n_long_out, uint32_t *long_rows_out,
+                     smh_crs **long_out, smh_crs **short_out);
 
 /* SparseMatrix::mvp (sparsematrix.rs:146-158) == `A * v` (Mul, sparsematrix.rs:435-443):
  * y[0..n_rows) = A.x.  x_len is x.dim(); a column index >= x_len is SMH_ERR_INDEX_RANGE

@@ -153,6 +153,14 @@ static void drop_colblock(smh_crs *m) {
     m->d_cf_cnt = nullptr;
     m->d_cf_val = nullptr;
     m->cf_built = m->cf_ok = false;
+    (void)smh_crs_destroy(m->split_long);
+    (void)smh_crs_destroy(m->split_short);
+    m->split_long = m->split_short = nullptr;
+    (void)hipFree(m->d_split_rows); (void)hipFree(m->d_split_y);
+    m->d_split_rows = nullptr;
+    m->d_split_y = nullptr;
+    m->split_built = m->split_ok = false;
+    m->split_n_long = 0;
 }
 // K2f geometry: blocks of 2^18 columns (1 MiB of f32 x, 2 MiB of f64 x): its waves walk the blocks without a barrier and
 // spread over a few of them, so the L2 has to hold more than one (measured on C2-uniform, f32: 2^18 2.05 ms, 2^19 2.40 ms);
@@ -183,9 +191,20 @@ static int resolve_variant(const smh_crs *m, int variant) {
         // similar length.  Skewed rows (BASELINE C3, power law 1..2048) let them drift over all column blocks at once
         // -- 5.2-5.6 ms against K2c's 3.25 ms, and a lock step costs more than it recovers (profiles/r02_k2f_sweep.log) --
         // so those stay with the per-block launches, whose tiles the dispatcher hands out dynamically.
+        // (measured on parts of C3, profiles/r02_c3_split_probe.log: rows of up to 63 / 127 entries, mean 5.5 / 7.9, still run
+        // best through K2f -- 0.82 / 1.15 ms against K2c's 0.97 / 1.26; up to 255 entries K2c wins, 1.61 against 1.79)
         const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
-        if ((double)m->max_row_len > 2.0 * mean + 8.0) return SMH_SPMV_COLBLOCK;
-        return SMH_SPMV_COLFUSED;
+        const double similar = 2.0 * mean + 8.0 > 128.0 ? 2.0 * mean + 8.0 : 128.0;
+        if ((double)m->max_row_len <= similar) return SMH_SPMV_COLFUSED;
+        // ... and a matrix with a minority of long rows is taken apart by row length (K2s)
+        static const bool split_off = getenv("SMH_COLBLOCK_SPLIT") && atoi(getenv("SMH_COLBLOCK_SPLIT")) == 0;  // tuning knob
+        // ... when K2c's sweeps (per column block and row: one offset, y read and written) weigh as much as the entries
+        // themselves: C3 (f64, 10M rows, 20 blocks) 4.0 GB of sweeps for 3.8 GB of entries -> 2.78 against 3.26 ms; a 3M-row
+        // f32 power law (6 blocks) 0.22 GB for 0.76 GB -> K2c stays ahead, 0.61 against 0.75 ms
+        const double vs = (double)dtype_size(m->dtype);
+        const double sweeps = (double)cb_blocks_for(m) * (double)m->n_rows * (4.0 + 2.0 * vs), entries = (double)m->nnz * (4.0 + vs);
+        if (!split_off && !m->no_split && !(m->split_built && !m->split_ok) && sweeps >= 0.6 * entries) return SMH_SPMV_COLSPLIT;
+        return SMH_SPMV_COLBLOCK;
     }
     const int lanes = mean_lanes(m);
     // short rows (stencils, FEM): the dense CSR-stream kernel (a tile denser than its LDS stage takes several passes)
@@ -429,6 +448,58 @@ static int ensure_colfused(smh_crs *m) {
     return SMH_OK;
 }
 
+// K2s: the row-length split, once per matrix (split_ok == false afterwards: not worth it / not possible -> K2c)
+constexpr uint32_t kSplitMinLong = 64;  // rows of this many entries and more form the LONG part
+static int finish_create(smh_crs *m, int validate);
+static int ensure_split(smh_crs *m) {
+    if (m->split_built) return SMH_OK;
+    m->split_built = true;
+    m->split_ok = false;
+    if (m->no_split || m->n_rows == 0 || m->nnz == 0) return SMH_OK;
+    size_t n_long = 0, nnz_long = 0;
+    uint32_t *rows = nullptr, *off_l = nullptr, *col_l = nullptr, *off_s = nullptr, *col_s = nullptr;
+    void *val_l = nullptr, *val_s = nullptr;
+    SMH_TRY(build_colsplit(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, kSplitMinLong, &n_long, &nnz_long, &rows, &off_l, &col_l,
+                           &val_l, &off_s, &col_s, &val_s, m->stream));
+    auto wrap = [&](size_t n_rows, size_t nnz, uint32_t *off, uint32_t *col, void *val, uint32_t shift, smh_crs **out) -> int {
+        smh_crs *p = new (std::nothrow) smh_crs();
+        if (!p) { (void)hipFree(off); (void)hipFree(col); (void)hipFree(val); return fail(SMH_ERR_OOM, "host allocation failed"); }
+        p->dtype = m->dtype; p->device = m->device; p->n_rows = n_rows; p->n_cols = m->n_cols; p->nnz = nnz;
+        p->d_off = off; p->d_col = col; p->d_val = val; p->owns = true;
+        p->no_split = true;
+        p->cb_forced_shift = shift;
+        const int rc = finish_create(p, 0);
+        if (rc != SMH_OK) { char keep[512]; strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0; smh_crs_destroy(p); return fail(rc, "%s", keep); }
+        *out = p;
+        return SMH_OK;
+    };
+    // worth it when the long rows are a minority that holds a good part of the entries
+    const bool worth = n_long > 0 && n_long * 4 <= m->n_rows && nnz_long * 4 >= m->nnz;
+    if (!worth) {
+        (void)hipFree(rows); (void)hipFree(off_l); (void)hipFree(col_l); (void)hipFree(val_l); (void)hipFree(off_s); (void)hipFree(col_s); (void)hipFree(val_s);
+        return SMH_OK;
+    }
+    m->d_split_rows = rows;
+    m->split_n_long = n_long;
+    // LONG: K2c with 2^18-column blocks (1.93 against 2.03 ms with 2^19 on C3's long part); SHORT: its own AUTO with 2^19
+    int rc = wrap(n_long, nnz_long, off_l, col_l, val_l, 18u, &m->split_long);
+    if (rc == SMH_OK) rc = wrap(m->n_rows, m->nnz - nnz_long, off_s, col_s, val_s, 19u, &m->split_short);
+    else { (void)hipFree(off_s); (void)hipFree(col_s); (void)hipFree(val_s); }
+    if (rc == SMH_OK) {
+        const hipError_t e = hipMalloc(&m->d_split_y, (n_long ? n_long : 1) * dtype_size(m->dtype));
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(split y)", __FILE__, __LINE__);
+    }
+    if (rc != SMH_OK) {
+        char keep[512]; strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0;
+        (void)smh_crs_destroy(m->split_long); (void)smh_crs_destroy(m->split_short);
+        m->split_long = m->split_short = nullptr;
+        (void)hipFree(m->d_split_rows); m->d_split_rows = nullptr;
+        return fail(rc, "%s", keep);
+    }
+    m->split_ok = true;
+    return SMH_OK;
+}
+
 // K1s: 16-bit column codes, once per matrix.  Kept only when EVERY tile has a description (stencils, bands): the kernel
 // variant then has no per-tile branch; any other matrix streams its u32 columns as before and nothing stays allocated.
 static int ensure_stream_codes(smh_crs *m) {
@@ -574,6 +645,19 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
             }
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt,
                                       single_pass, dot_partials, code, cwin, len8, tbase, dot_lhs, s);
+        }
+        case SMH_SPMV_COLSPLIT: {
+            SMH_TRY(ensure_split(m));
+            if (m->split_ok) {
+                SMH_TRY(spmv_enqueue(m->split_short, x, x_len, y, SMH_SPMV_AUTO, s));             // every row (0 for the long ones)
+                SMH_TRY(spmv_enqueue(m->split_long, x, x_len, m->d_split_y, SMH_SPMV_AUTO, s));   // the long rows, compacted
+                return launch_split_scatter(m->dtype, m->d_split_rows, m->d_split_y, m->split_n_long, y, s);
+            }
+            SMH_TRY(ensure_colblock(m));  // not worth splitting: the per-block launches
+            for (size_t b = 0; b < m->cb_blocks; ++b)
+                SMH_TRY(launch_spmv_stream_block(m->dtype, m->d_cb_off + b * (m->n_rows + 1), m->d_cb_col, m->d_cb_val, x, y,
+                                                 m->n_rows, m->nnz, m->cb_rpt, m->cb_single_pass, b > 0, s));
+            return SMH_OK;
         }
         case SMH_SPMV_COLFUSED: {
             SMH_TRY(ensure_colfused(m));
@@ -983,6 +1067,8 @@ int smh_crs_destroy(smh_crs *m) {
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);
     (void)hipFree(m->d_cf_seg); (void)hipFree(m->d_cf_cnt); (void)hipFree(m->d_cf_col); (void)hipFree(m->d_cf_val);
     (void)hipFree(m->d_cf_tile_row); (void)hipFree(m->d_cf_progress);
+    (void)smh_crs_destroy(m->split_long); (void)smh_crs_destroy(m->split_short);
+    (void)hipFree(m->d_split_rows); (void)hipFree(m->d_split_y);
     (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
@@ -1029,6 +1115,10 @@ int smh_crs_scale(smh_crs *m, double a) {
     SMH_TRY(launch_scale_values(m->dtype, m->d_val, m->nnz, a, m->stream));
     if (m->cb_built) SMH_TRY(launch_scale_values(m->dtype, m->d_cb_val, m->nnz, a, m->stream));
     if (m->cf_built && m->cf_ok) SMH_TRY(launch_scale_values(m->dtype, m->d_cf_val, m->nnz, a, m->stream));
+    if (m->split_built && m->split_ok) {
+        SMH_TRY(smh_crs_scale(m->split_long, a));
+        SMH_TRY(smh_crs_scale(m->split_short, a));
+    }
     SMH_HIP(hipStreamSynchronize(m->stream));
     return SMH_OK;
 }
@@ -1075,6 +1165,20 @@ int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_b
     if (counts_out && n_tiles) SMH_HIP(hipMemcpy(counts_out, m->d_cf_cnt, n_tiles * m->cf_blocks * tile_rows, hipMemcpyDeviceToHost));
     if (columns_out && m->nnz) SMH_HIP(hipMemcpy(columns_out, m->d_cf_col, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (values_out && m->nnz) SMH_HIP(hipMemcpy(values_out, m->d_cf_val, m->nnz * dtype_size(m->dtype), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+int smh_crs_colsplit(smh_crs *m, int *split_out, uint32_t *min_long_out, size_t *n_long_out, uint32_t *long_rows_out, smh_crs **long_out,
+                     smh_crs **short_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(ensure_split(m));
+    if (split_out) *split_out = m->split_ok ? 1 : 0;
+    if (min_long_out) *min_long_out = kSplitMinLong;
+    if (n_long_out) *n_long_out = m->split_ok ? m->split_n_long : 0;
+    if (long_out) *long_out = m->split_ok ? m->split_long : nullptr;
+    if (short_out) *short_out = m->split_ok ? m->split_short : nullptr;
+    if (long_rows_out && m->split_ok && m->split_n_long)
+        SMH_HIP(hipMemcpy(long_rows_out, m->d_split_rows, m->split_n_long * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SMH_OK;
 }
 
@@ -1169,6 +1273,11 @@ int smh_crs_prepare(smh_crs *m, int variant) {
         case SMH_SPMV_COLFUSED:
             SMH_TRY(ensure_colfused(m));
             return m->cf_ok ? SMH_OK : ensure_colblock(m);
+        case SMH_SPMV_COLSPLIT:
+            SMH_TRY(ensure_split(m));
+            if (!m->split_ok) return ensure_colblock(m);
+            SMH_TRY(smh_crs_prepare(m->split_short, SMH_SPMV_AUTO));
+            return smh_crs_prepare(m->split_long, SMH_SPMV_AUTO);
         case SMH_SPMV_STREAM: return m->use_stream_win == 1 ? ensure_stream_windows(m) : ensure_stream_codes(m);
         case SMH_SPMV_SEQ: return SMH_OK;
         default: return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);

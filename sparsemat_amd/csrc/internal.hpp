@@ -87,6 +87,11 @@ int build_colfused(int dtype, const uint32_t *off, const uint32_t *col, const vo
 int launch_spmv_colfused(int dtype, uint32_t rt, const uint32_t *tile_row, size_t n_tiles, const uint32_t *seg, const uint8_t *cnt,
                          const uint32_t *col, const void *val, const void *x, void *y, size_t n_rows, size_t nnz, uint32_t n_blocks,
                          uint32_t *progress, int device, hipStream_t s);
+// K2s (a skewed matrix as a long-row and a short-row column-blocked matrix; spmv_colsplit.hip)
+int build_colsplit(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t min_long,
+                   size_t *n_long_out, size_t *nnz_long_out, uint32_t **long_rows_out, uint32_t **off_l_out, uint32_t **col_l_out, void **val_l_out,
+                   uint32_t **off_s_out, uint32_t **col_s_out, void **val_s_out, hipStream_t s);
+int launch_split_scatter(int dtype, const uint32_t *long_rows, const void *y_long, size_t n_long, void *y, hipStream_t s);
 // on-device assembly (assemble.hip): add_to/set stream -> CRS; sort_row for all rows.  Device pointers.
 int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t *cols, const void *vals, const uint8_t *ops,
                       bool reverse_rows, bool all_set, bool repeats_adjacent, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
@@ -196,6 +201,13 @@ struct smh_crs {
     uint32_t *d_cb_off = nullptr, *d_cb_col = nullptr;
     void *d_cb_val = nullptr;
     double span_fraction = 0.0;  // mean column span of a 64-row tile / n_cols (1: no locality at all)
+    // K2s row-length split (lazy): two sub-handles (owned) + the rows of the long one
+    bool split_built = false, split_ok = false;  // ok: the split was worth building (few long rows holding many entries)
+    bool no_split = false;                       // this handle IS a part of a split: never split again
+    smh_crs *split_long = nullptr, *split_short = nullptr;
+    uint32_t *d_split_rows = nullptr;
+    void *d_split_y = nullptr;
+    size_t split_n_long = 0;
     // K2f fused column-blocked copy (lazy)
     bool cf_built = false;       // the build was attempted (cf_ok: and the byte table could describe the matrix)
     bool cf_ok = false;

@@ -195,11 +195,38 @@ class SparseMatCRS:
     def resolved_variant(self):
         v, lanes = C.c_int(), C.c_int()
         check(lib().smh_crs_resolved_variant(self._h, C.byref(v), C.byref(lanes)))
-        return {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused"}[v.value], lanes.value
+        return {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused", 7: "colsplit"}[v.value], lanes.value
 
     def set_colblock_shift(self, shift):
         """K2c: column blocks of 2**shift columns (0: automatic, 2 MiB of x)."""
         check(lib().smh_crs_set_colblock_shift(self._h, shift))
+
+    def colsplit_flag(self):
+        """True when the handle keeps a row-length split (builds it on first use)."""
+        flag = C.c_int()
+        check(lib().smh_crs_colsplit(self._h, C.byref(flag), None, None, None, None, None))
+        return bool(flag.value)
+
+    def colsplit(self):
+        """The row-length split (``smh_crs_colsplit``): dict with split (bool), min_long, n_long, long_rows and the two
+        sub-matrices' raw parts ``long`` / ``short`` = (n_rows, offsets, columns, values)."""
+        flag, ml, nl = C.c_int(), C.c_uint32(), C.c_size_t()
+        check(lib().smh_crs_colsplit(self._h, C.byref(flag), C.byref(ml), C.byref(nl), None, None, None))
+        out = {"split": bool(flag.value), "min_long": ml.value, "n_long": nl.value}
+        if out["split"]:
+            rows = np.zeros(nl.value, np.uint32)
+            hl, hs = C.c_void_p(), C.c_void_p()
+            check(lib().smh_crs_colsplit(self._h, None, None, None, rows.ctypes.data, C.byref(hl), C.byref(hs)))
+            out["long_rows"] = rows
+            for name, h in (("long", hl), ("short", hs)):
+                nr, nnz = lib().smh_crs_n_rows(h), lib().smh_crs_nnz(h)
+                off, col, val = np.zeros(nr + 1, np.uint32), np.zeros(nnz, np.uint32), np.zeros(nnz, self._dtype)
+                check(lib().smh_crs_download(h, off.ctypes.data, col.ctypes.data if nnz else None, val.ctypes.data if nnz else None))
+                var, lanes = C.c_int(), C.c_int()
+                check(lib().smh_crs_resolved_variant(h, C.byref(var), C.byref(lanes)))
+                out[name] = (nr, off, col, val)
+                out[name + "_variant"] = {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused", 7: "colsplit"}[var.value]
+        return out
 
     def colfused(self, arrays=True):
         """The K2f copy (``smh_crs_colfused``): dict with fits, shift, n_blocks, rows_per_lane, n_tiles and -- with

@@ -282,3 +282,52 @@ def test_colfused_edge_shapes(gpu):
     m = sm.SparseMatCRS.from_raw_parts(2500, 900, off, col, val)
     assert m.colfused(arrays=False)["n_blocks"] == 1
     assert np.array_equal(bits(m.mvp(x, variant="colfused")), bits(oracle.spmv(off, col, val, x)))
+
+
+# ---- K2s: a skewed matrix as a long-row and a short-row matrix (spmv_colsplit.hip) -----------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_colsplit_structure_and_product(gpu, dtype):
+    rng = np.random.default_rng(41)
+    n_rows, n_cols = 9001, 7003
+    lens = rng.integers(0, 12, n_rows)
+    heavy = rng.random(n_rows) < 0.04           # a minority of long rows holding most of the entries
+    lens[heavy] = rng.integers(64, 700, heavy.sum())
+    lens[11] = 63                                # just below the threshold: stays in the short part
+    lens[12] = 64                                # exactly the threshold: long
+    off, col, val = random_crs(rng, n_rows, n_cols, lens, dtype, dup=True)
+    x = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    m.set_colblock_shift(9)
+    cs = m.colsplit()
+    assert cs["split"] and cs["min_long"] == 64
+    is_long = lens >= 64
+    rows_long = np.nonzero(is_long)[0]
+    assert cs["n_long"] == len(rows_long) and np.array_equal(cs["long_rows"], rows_long.astype(np.uint32))
+    ent_long = np.repeat(is_long, lens)
+    off_l = np.zeros(len(rows_long) + 1, np.uint32)
+    np.cumsum(lens[rows_long], out=off_l[1:])
+    off_s = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(np.where(is_long, 0, lens), out=off_s[1:])
+    for name, want in (("long", (len(rows_long), off_l, col[ent_long], val[ent_long])), ("short", (n_rows, off_s, col[~ent_long], val[~ent_long]))):
+        got = cs[name]
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), name
+        assert np.array_equal(bits(got[3]), bits(want[3])), name
+    y = m.mvp(x, variant="colsplit")
+    assert_spmv_close(y, off, col, val, x, "colsplit")
+    assert np.array_equal(bits(y), bits(m.mvp(x, variant="colsplit")))  # run-to-run reproducible
+    m.scale(-2.0)                                                        # both parts follow value changes
+    assert_spmv_close(m.mvp(x, variant="colsplit"), off, col, (val * dtype(-2.0)).astype(dtype), x, "colsplit scaled")
+    val2 = rng.uniform(-1, 1, len(val)).astype(dtype)
+    m.update_values(val2)
+    assert_spmv_close(m.mvp(x, variant="colsplit"), off, col, val2, x, "colsplit updated")
+
+
+def test_colsplit_declines_when_it_is_not_worth_it(gpu):
+    """Rows of similar length (no long minority): no split is kept; the variant runs K2c, bit for bit."""
+    rng = np.random.default_rng(43)
+    off, col, val = random_crs(rng, 4000, 3000, rng.integers(0, 40, 4000), np.float32)
+    x = rng.uniform(-1, 1, 3000).astype(np.float32)
+    m = sm.SparseMatCRS.from_raw_parts(4000, 3000, off, col, val)
+    m.set_colblock_shift(8)
+    assert not m.colsplit()["split"]
+    assert np.array_equal(bits(m.mvp(x, variant="colsplit")), bits(m.mvp(x, variant="colblock")))

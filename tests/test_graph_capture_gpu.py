@@ -12,13 +12,13 @@ from util import assert_spmv_close, random_crs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", ["vector", "merge", "stream", "colblock", "colfused", "seq"])
+@pytest.mark.parametrize("variant", ["vector", "merge", "stream", "colblock", "colfused", "colsplit", "seq"])
 def test_spmv_dev_replays_from_a_captured_graph(gpu, variant):
     rng = np.random.default_rng(31)
     n_rows, n_cols = 20_011, 17_003
     off, col, val = random_crs(rng, n_rows, n_cols, rng.integers(0, 40, n_rows), np.float32)
     m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
-    if variant in ("colblock", "colfused"):
+    if variant in ("colblock", "colfused", "colsplit"):
         m.set_colblock_shift(12)  # 5 column blocks
     m.prepare(variant)
     x = torch.from_numpy(rng.uniform(-1, 1, n_cols).astype(np.float32)).cuda()

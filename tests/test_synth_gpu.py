@@ -185,14 +185,17 @@ def test_full_size_c3_powerlaw_properties(gpu):
     and the bit-exact K1s agree on every row to 1e-12 of the row's scale; sampled rows against the oracle."""
     n = 10_000_000
     m = synth.crs_powerlaw(synth.SEED_MATRIX, n, n, np.float64)
-    assert m.resolved_variant()[0] == "colblock" and m.max_row_len() == 2048  # skewed rows: the per-block launches (K2c)
+    assert m.resolved_variant()[0] == "colsplit" and m.max_row_len() == 2048  # skewed rows: taken apart by row length (K2s)
+    cs_flag = m.colsplit()
+    assert cs_flag["split"] and 700_000 < cs_flag["n_long"] < 800_000 and cs_flag["long_variant"] == "colblock" and cs_flag["short_variant"] == "colfused"
     xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float64)
     x = xbuf.download(np.float64, n)
     y_cb = _run(m, xptr, n, "auto", np.float64)
     y_mg = _run(m, xptr, n, "merge", np.float64)
     y_st = _run(m, xptr, n, "stream", np.float64)
-    y_k2f = _run(m, xptr, n, "colfused", np.float64)  # the one-sweep form must agree too (AUTO does not take it here)
-    assert np.abs(y_k2f - y_st).max() < 2.1e-9
+    y_k2f = _run(m, xptr, n, "colfused", np.float64)  # the one-sweep form and the per-block launches must agree too
+    y_k2c = _run(m, xptr, n, "colblock", np.float64)
+    assert np.abs(y_k2f - y_st).max() < 2.1e-9 and np.abs(y_k2c - y_st).max() < 2.1e-9
     # |row| <= 2048 entries of magnitude < 1: sum|a x| <= 2048; bound 1e-12 * 2048 covers every row
     assert np.abs(y_cb - y_st).max() < 2.1e-9 and np.abs(y_mg - y_st).max() < 2.1e-9
     off_all = synth.powerlaw_offsets(synth.SEED_MATRIX, n)

@@ -105,6 +105,9 @@ def main():
                 med, mn = time_variant(m, xptr, nr, ybuf.ptr, "colfused", reps=8)
                 report("colfused 2^%d x%d rt%d" % (cf["shift"], cf["n_blocks"], cf["rows_per_lane"]), B, med, mn)
         m.set_colblock_shift(0)
+        if args.cb_shifts and m.colsplit_flag():
+            med, mn = time_variant(m, xptr, nr, ybuf.ptr, "colsplit", reps=8)
+            report("colsplit (long rows K2c + short rows K2f)", B, med, mn)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "auto")
         report("auto", B, med, mn)
         del m, xbuf, ybuf
