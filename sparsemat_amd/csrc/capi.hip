@@ -161,6 +161,9 @@ static void drop_colblock(smh_crs *m) {
     m->d_split_y = nullptr;
     m->split_built = m->split_ok = false;
     m->split_n_long = 0;
+    if (m->split_stream) { (void)hipStreamSynchronize(m->split_stream); (void)hipStreamDestroy(m->split_stream); m->split_stream = nullptr; }
+    if (m->split_fork) { (void)hipEventDestroy(m->split_fork); m->split_fork = nullptr; }
+    if (m->split_join) { (void)hipEventDestroy(m->split_join); m->split_join = nullptr; }
 }
 // K2f geometry: blocks of 2^18 columns (1 MiB of f32 x, 2 MiB of f64 x): its waves walk the blocks without a barrier and
 // spread over a few of them, so the L2 has to hold more than one (measured on C2-uniform, f32: 2^18 2.05 ms, 2^19 2.40 ms);
@@ -486,8 +489,11 @@ static int ensure_split(smh_crs *m) {
     if (rc == SMH_OK) rc = wrap(m->n_rows, m->nnz - nnz_long, off_s, col_s, val_s, 19u, &m->split_short);
     else { (void)hipFree(off_s); (void)hipFree(col_s); (void)hipFree(val_s); }
     if (rc == SMH_OK) {
-        const hipError_t e = hipMalloc(&m->d_split_y, (n_long ? n_long : 1) * dtype_size(m->dtype));
-        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(split y)", __FILE__, __LINE__);
+        hipError_t e = hipMalloc(&m->d_split_y, (n_long ? n_long : 1) * dtype_size(m->dtype));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->split_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->split_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->split_join, hipEventDisableTiming);
+        if (e != hipSuccess) rc = hip_fail(e, "split workspace", __FILE__, __LINE__);
     }
     if (rc != SMH_OK) {
         char keep[512]; strncpy(keep, g_err, sizeof keep); keep[sizeof keep - 1] = 0;
@@ -649,8 +655,20 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
         case SMH_SPMV_COLSPLIT: {
             SMH_TRY(ensure_split(m));
             if (m->split_ok) {
+                // The two parts lean on different resources (LONG: the L2 gather path; SHORT: HBM streams and latency), which
+                // suggests running LONG on a stream of its own beside SHORT (fork and join by events).  Measured on C3, one box:
+                // 2.90 ms overlapped against 2.79 ms back to back -- K2f sizes its rounds to the whole chip and the blocks of
+                // x of the two parts evict each other -- so it is a knob, off by default (SMH_COLSPLIT_OVERLAP=1)
+                static const bool overlap = getenv("SMH_COLSPLIT_OVERLAP") && atoi(getenv("SMH_COLSPLIT_OVERLAP")) != 0;
+                hipStream_t sl = overlap ? m->split_stream : s;
+                if (overlap) {
+                    SMH_HIP(hipEventRecord(m->split_fork, s));
+                    SMH_HIP(hipStreamWaitEvent(sl, m->split_fork, 0));
+                }
+                SMH_TRY(spmv_enqueue(m->split_long, x, x_len, m->d_split_y, SMH_SPMV_AUTO, sl));  // the long rows, compacted
+                if (overlap) SMH_HIP(hipEventRecord(m->split_join, sl));
                 SMH_TRY(spmv_enqueue(m->split_short, x, x_len, y, SMH_SPMV_AUTO, s));             // every row (0 for the long ones)
-                SMH_TRY(spmv_enqueue(m->split_long, x, x_len, m->d_split_y, SMH_SPMV_AUTO, s));   // the long rows, compacted
+                if (overlap) SMH_HIP(hipStreamWaitEvent(s, m->split_join, 0));
                 return launch_split_scatter(m->dtype, m->d_split_rows, m->d_split_y, m->split_n_long, y, s);
             }
             SMH_TRY(ensure_colblock(m));  // not worth splitting: the per-block launches

@@ -208,6 +208,8 @@ struct smh_crs {
     uint32_t *d_split_rows = nullptr;
     void *d_split_y = nullptr;
     size_t split_n_long = 0;
+    hipStream_t split_stream = nullptr;  // the LONG part runs beside the SHORT one (fork / join by events)
+    hipEvent_t split_fork = nullptr, split_join = nullptr;
     // K2f fused column-blocked copy (lazy)
     bool cf_built = false;       // the build was attempted (cf_ok: and the byte table could describe the matrix)
     bool cf_ok = false;
