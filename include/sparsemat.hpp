@@ -289,6 +289,35 @@ class SparseMatPar {
     }
     smh_par *handle() const { return h_; }
 
+    // A DenseVec distributed over the blocks: one full-length device buffer per block, block b owns [b R, (b+1) R).
+    class ParVec {
+      public:
+        ParVec(const SparseMatPar &m, size_t n) { detail::check(smh_par_vec_create(m.h_, n, &v_)); }
+        ParVec(const SparseMatPar &m, const std::vector<T> &host) : ParVec(m, host.size()) {
+            detail::check(smh_par_vec_upload(v_, host.data()));
+        }
+        ParVec(ParVec &&o) noexcept : v_(o.v_) { o.v_ = nullptr; }
+        ParVec(const ParVec &) = delete;
+        ~ParVec() { smh_par_vec_destroy(v_); }
+        size_t dim() const { return smh_par_vec_dim(v_); }
+        std::vector<T> to_vec() const {  // the owned slices of all blocks = the whole vector
+            std::vector<T> out(dim());
+            detail::check(smh_par_vec_download(v_, out.data()));
+            return out;
+        }
+        smh_par_vec *handle() const { return v_; }
+
+      private:
+        smh_par_vec *v_ = nullptr;
+    };
+    // The reference's intended mvp_par (sparsemat_par.rs:37-68), device resident: every block multiplies against the
+    // shared x, its results go to offset b * R of y, then ONE exchange inside the library (RCCL all-gather, or only the
+    // entries each block references) makes y usable as the next x.  Asynchronous: synchronize() waits.
+    void mvp_par(const ParVec &x, ParVec &y, int variant = SMH_SPMV_AUTO, int exchange = SMH_EXCHANGE_AUTO) const {
+        detail::check(smh_par_spmv_dev(h_, x.handle(), y.handle(), variant, exchange));
+    }
+    void synchronize() const { detail::check(smh_par_synchronize(h_)); }
+
   private:
     SparseMatPar() = default;
     smh_par *h_ = nullptr;

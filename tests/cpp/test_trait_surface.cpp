@@ -130,6 +130,18 @@ int main() {
         auto y = par.mvp(std::vector<float>{2.0f, 4.8f, 1.2f}, SMH_SPMV_STREAM);
         CHECK(y[0] == 34.544f);              // assert_eq!(mvp.get(0), 34.544)
         CHECK((par.get_block_and_row_id(7) == std::pair<size_t, size_t>{1, 3}));
+        // the intended mvp_par (sparsemat_par.rs:37-68), device resident: results at b * R, one exchange, y = the next x
+        {
+            std::vector<uint32_t> o2 = {0, 2, 4, 6, 8}, c2 = {0, 1, 1, 2, 2, 3, 3, 0};
+            std::vector<float> v2 = {2.0f, 1.0f, 3.0f, 1.0f, 4.0f, 1.0f, 5.0f, 1.0f};
+            auto sq = SparseMatPar<float>::with_sub_matrices(2, 4, 4, o2, c2, v2, {0, 0});
+            SparseMatPar<float>::ParVec xv(sq, std::vector<float>{1.0f, 2.0f, 3.0f, 4.0f}), yv(sq, 4), zv(sq, 4);
+            sq.mvp_par(xv, yv, SMH_SPMV_STREAM);
+            sq.mvp_par(yv, zv, SMH_SPMV_STREAM);
+            sq.synchronize();
+            CHECK((yv.to_vec() == std::vector<float>{4.0f, 9.0f, 16.0f, 21.0f}));     // A x
+            CHECK((zv.to_vec() == std::vector<float>{17.0f, 43.0f, 85.0f, 109.0f}));   // A (A x): the exchanged y was the next x
+        }
         // ConjugateGradient::solve on a partitioned SPD matrix (two blocks on device 0)
         auto spd = SparseMatPar<double>::with_sub_matrices(2, 2, 2, {0, 2, 4}, {0, 1, 0, 1}, {4.0, 1.0, 1.0, 3.0}, {0, 0});
         std::vector<double> b = {1.0, 2.0}, x = {2.0, 1.0};
