@@ -593,15 +593,59 @@ static int stream_rpt(const smh_crs *m) {
 
 // Can y = A x also leave the partial sums of x.y (CG's p.Ap) in its epilogue?  Only the K1s kernel does;
 // returns the number of partials it would write (0: not fused -- run a separate dot).
+// K1s configuration the STREAM variant runs with for this handle (builds the code tables on first use)
+struct StreamCfg {
+    const uint32_t *win = nullptr;
+    int rpt = 1;
+    bool single_pass = false;
+    const uint16_t *code = nullptr;
+    const uint32_t *cwin = nullptr;
+    const uint8_t *len8 = nullptr;
+    const uint32_t *tbase = nullptr;
+    bool pipe = false;  // K1s-p: persistent blocks, three tiles in flight
+};
+static int stream_cfg(smh_crs *m, StreamCfg *c) {
+    *c = StreamCfg();
+    if (m->use_stream_win == 1) {
+        SMH_TRY(ensure_stream_windows(m));
+        // measured (512^3 Laplacian): the windowed body is SLOWER (2.77 vs 1.80 ms: an extra barrier,
+        // 5 instead of 8 blocks per CU, as many window-load as gather instructions), so only on request
+        c->win = m->d_stream_win;
+    }
+    // a 512-row tiling is only chosen when every such tile fits the LDS stage; the 256-row tiling takes
+    // tiles of any density (loop-free body when the create-time statistic says that none overflows)
+    c->rpt = c->win ? 1 : stream_rpt(m);
+    c->single_pass = m->have_stats && (c->rpt == 2 || m->max_tile_entries <= (uint32_t)kStreamCap);
+    // 16-bit column codes when every tile's columns fall into <= 4 intervals of <= 16384 (stencils, bands)
+    const char *c16_env = getenv("SMH_STREAM_C16");  // tuning knob: 0 = always the u32 columns
+    // (single-pass tiles only: on dense multi-pass tiles -- banded C2 through K1s -- the decode costs more than
+    // the bytes save, 0.83 vs 0.80 ms)
+    if (!(c16_env && atoi(c16_env) == 0) && !c->win && c->rpt == 1 && c->single_pass) {
+        SMH_TRY(ensure_stream_codes(m));
+        c->code = m->d_stream_code;
+        c->cwin = m->d_stream_code ? m->d_stream_cwin : nullptr;
+        static const bool l8_off = getenv("SMH_STREAM_L8") && atoi(getenv("SMH_STREAM_L8")) == 0;  // tuning knob
+        if (c->cwin && !l8_off) { c->len8 = m->d_stream_len8; c->tbase = m->d_stream_tbase; }
+        // K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip) is an experiment kept behind a knob: on the
+        // 512^3 Laplacian it measured 1.86 ms against K1s's 1.55 ms (profiles/r02_k1s_pipe_ab.log)
+        static const bool pipe_on = getenv("SMH_STREAM_PIPE") && atoi(getenv("SMH_STREAM_PIPE")) == 1;
+        c->pipe = pipe_on && c->cwin && c->len8 && c->tbase && m->max_tile_entries <= stream_pipe_cap() && (m->owns || m->nnz % 4 == 0);
+    }
+    return SMH_OK;
+}
+
 // any_lhs: the dot is taken with a vector of its own (n_rows entries; SparseMatrix::inner_prod) instead of x itself, so
 // the matrix need not be square
-size_t spmv_fused_dot_partials(const smh_crs *m, size_t x_len, int variant, bool any_lhs) {
+size_t spmv_fused_dot_partials(smh_crs *m, size_t x_len, int variant, bool any_lhs) {
     if (const char *e = getenv("SMH_CG_FUSED_DOT")) {  // tuning knob: 0 = always the separate dot
         if (atoi(e) == 0) return 0;
     }
     if (resolve_variant(m, variant) != SMH_SPMV_STREAM) return 0;
     if (!any_lhs && (m->n_rows != m->n_cols || x_len < m->n_rows)) return 0;
-    return stream_tiles(m->n_rows, m->use_stream_win == 1 ? 1 : stream_rpt(m));
+    StreamCfg c;
+    if (stream_cfg(m, &c) != SMH_OK) return 0;
+    if (c.pipe) return stream_pipe_blocks(m->dtype, m->device);  // one partial per persistent block
+    return stream_tiles(m->n_rows, c.rpt);
 }
 
 // enqueue y = A x on stream s (device pointers); dot_partials (optional, K1s only): see above
@@ -623,34 +667,13 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
         case SMH_SPMV_SEQ:
             return launch_spmv_seq(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, s);
         case SMH_SPMV_STREAM: {
-            const uint32_t *win = nullptr;
-            if (m->use_stream_win == 1) {
-                SMH_TRY(ensure_stream_windows(m));
-                // measured (512^3 Laplacian): the windowed body is SLOWER (2.77 vs 1.80 ms: an extra barrier,
-                // 5 instead of 8 blocks per CU, as many window-load as gather instructions), so only on request
-                if (m->use_stream_win == 1) win = m->d_stream_win;
-            }
-            // a 512-row tiling is only chosen when every such tile fits the LDS stage; the 256-row tiling takes
-            // tiles of any density (loop-free body when the create-time statistic says that none overflows)
-            const int rpt = win ? 1 : stream_rpt(m);
-            const bool single_pass = m->have_stats && (rpt == 2 || m->max_tile_entries <= (uint32_t)kStreamCap);
-            // 16-bit column codes when every tile's columns fall into <= 4 intervals of <= 16384 (stencils, bands)
-            const uint16_t *code = nullptr;
-            const uint32_t *cwin = nullptr;
-            const uint8_t *len8 = nullptr;
-            const uint32_t *tbase = nullptr;
-            const char *c16_env = getenv("SMH_STREAM_C16");  // tuning knob: 0 = always the u32 columns
-            // (single-pass tiles only: on dense multi-pass tiles -- banded C2 through K1s -- the decode costs more than
-            // the bytes save, 0.83 vs 0.80 ms)
-            if (!(c16_env && atoi(c16_env) == 0) && !win && rpt == 1 && single_pass) {
-                SMH_TRY(ensure_stream_codes(m));
-                code = m->d_stream_code;
-                cwin = m->d_stream_code ? m->d_stream_cwin : nullptr;
-                static const bool l8_off = getenv("SMH_STREAM_L8") && atoi(getenv("SMH_STREAM_L8")) == 0;  // tuning knob
-                if (cwin && !l8_off) { len8 = m->d_stream_len8; tbase = m->d_stream_tbase; }
-            }
-            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, win, rpt,
-                                      single_pass, dot_partials, code, cwin, len8, tbase, dot_lhs, s);
+            StreamCfg c;
+            SMH_TRY(stream_cfg(m, &c));
+            if (c.pipe)
+                return launch_spmv_stream_pipe(m->dtype, m->d_val, x, y, m->n_rows, m->nnz, dot_partials, c.code, c.cwin, c.len8, c.tbase,
+                                               dot_lhs, m->device, s);
+            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt,
+                                      c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s);
         }
         case SMH_SPMV_COLSPLIT: {
             SMH_TRY(ensure_split(m));

@@ -67,6 +67,12 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
                        const void *dot_lhs /* with dot_partials: the vector dotted with y (NULL: x); y may then be NULL */,
                        hipStream_t s);
 int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
+// K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip)
+uint32_t stream_pipe_cap();
+unsigned stream_pipe_blocks(int dtype, int device);
+int launch_spmv_stream_pipe(int dtype, const void *val, const void *x, void *y, size_t n_rows, size_t nnz, void *dot_partials,
+                            const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs,
+                            int device, hipStream_t s);
 size_t stream_tiles(size_t n_rows, int rows_per_thread);
 int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, bool for_codes, uint32_t *win,
                           uint32_t *d_count, hipStream_t s);
@@ -142,7 +148,7 @@ int launch_crs_stats(const uint32_t *off, const uint32_t *col, size_t n_rows, si
                      hipStream_t s);
 // y = A x on stream s with the handle's kernel (capi.hip).  dot_partials (optional): when spmv_fused_dot_partials() > 0 the
 // kernel also leaves that many partial sums of x.y there (K1s epilogue; square matrices) -- CG's / PCG's p.Ap for free
-size_t spmv_fused_dot_partials(const ::smh_crs *m, size_t x_len, int variant, bool any_lhs = false);
+size_t spmv_fused_dot_partials(::smh_crs *m, size_t x_len, int variant, bool any_lhs = false);
 int spmv_enqueue(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, void *dot_partials = nullptr,
                  const void *dot_lhs = nullptr);
 // BLAS-1 (a_dev: scalar read from device memory when non-null, else `a`)
