@@ -259,9 +259,11 @@ int smh_crs_prepare(smh_crs *m, int variant);
 int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant,
                      void *stream);
 /* SparseMatrix::inner_prod (sparsematrix.rs:161-171): lhs^T A rhs = sum over all entries of
- * lhs[i] * a_ij * rhs[j].  lhs_len < n_rows or a column index >= rhs_len is SMH_ERR_INDEX_RANGE
- * (the reference panics in densevec.rs:41).  Computed as dot(lhs, A rhs): one SpMV with the
- * matrix's kernel plus a two-stage deterministic reduction (tolerance-level parity, like dot). */
+ * lhs[i] * a_ij * rhs[j].  An lhs that ends at or before the last row holding entries, or a column
+ * index >= rhs_len, is SMH_ERR_INDEX_RANGE (the reference panics in densevec.rs:41; rows without
+ * entries never index lhs, so trailing empty rows may lie beyond lhs_len, as in the reference).
+ * Computed as dot(lhs, A rhs): the dot rides the SpMV's epilogue where the kernel has one, then a
+ * two-stage deterministic reduction (tolerance-level parity, like dot). */
 int smh_crs_inner_prod(smh_crs *m, const void *lhs_host, size_t lhs_len, const void *rhs_host,
                        size_t rhs_len, int variant, double *out);
 /* merge-path tile table (integer structure, checked bit-exact in tests): tile t starts at

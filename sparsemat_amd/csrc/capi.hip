@@ -1479,9 +1479,30 @@ static int inner_prod_dev(smh_crs *m, const void *d_lhs, size_t lhs_len, const v
     if (!out) return fail(SMH_ERR_INVALID, "out is NULL");
     *out = 0.0;
     if (m->n_rows == 0 || m->nnz == 0) return SMH_OK;
-    if (lhs_len < m->n_rows)  // lhs.get(i) for every row: densevec.rs:41
-        return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %zu", lhs_len, m->n_rows - 1);
     const size_t vs = dtype_size(m->dtype);
+    // lhs.get(i) is evaluated inside the entry loop (sparsematrix.rs:165-168): only rows that hold entries index lhs, so a
+    // short lhs is an error only if it ends before the last non-empty row (densevec.rs:41 panics there).  The kernels read
+    // lhs for every row, so a short-but-legal lhs is continued with zeros in a scratch copy.
+    struct Padded {
+        void *d = nullptr;
+        ~Padded() { if (d) (void)hipFree(d); }
+    } padded;
+    if (lhs_len < m->n_rows) {
+        size_t lo = 0, hi = m->n_rows;  // smallest i with offset_rows[i] == nnz; rows i.. are empty
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo) / 2;
+            uint32_t off = 0;
+            SMH_HIP(hipMemcpyAsync(&off, m->d_off + mid, sizeof off, hipMemcpyDeviceToHost, m->stream));
+            SMH_HIP(hipStreamSynchronize(m->stream));
+            if ((size_t)off >= m->nnz) hi = mid; else lo = mid + 1;
+        }
+        if (lhs_len < lo)  // row lo - 1 is the last one with entries
+            return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %zu", lhs_len, lo - 1);
+        SMH_HIP(hipMalloc(&padded.d, m->n_rows * vs));
+        SMH_HIP(hipMemsetAsync(padded.d, 0, m->n_rows * vs, m->stream));
+        if (lhs_len) SMH_HIP(hipMemcpyAsync(padded.d, d_lhs, lhs_len * vs, hipMemcpyDeviceToDevice, m->stream));
+        d_lhs = padded.d;
+    }
     void *scratch = nullptr;
     SMH_TRY(reduce_scratch(&scratch));
     char *res = (char *)scratch + kReducePartials * sizeof(double);

@@ -233,9 +233,41 @@ def test_matrix_inner_prod(gpu, dtype, shape):
     assert got_v == got  # same kernels, deterministic reduction: bitwise reproducible
     for variant in ("stream", "merge", "vector"):
         assert abs(m.inner_prod(lhs, rhs, variant=variant) - ref) <= tol, variant
-    # the reference panics (densevec.rs:41) when a vector is too short
+    # the reference panics (densevec.rs:41) when a vector is too short -- for lhs that means shorter than the last row that
+    # holds entries: lhs.get(i) sits inside the entry loop (sparsematrix.rs:165-168)
+    last = int(np.nonzero(np.diff(off.astype(np.int64)))[0][-1])
     with pytest.raises(sm.SparseMatPanic) as e:
-        m.inner_prod(lhs[:-1], rhs)
+        m.inner_prod(lhs[:last], rhs)
     assert e.value.status == _lib.SMH_ERR_INDEX_RANGE
+    assert "the index is %d" % last in str(e.value)
     with pytest.raises(sm.SparseMatPanic):
         m.inner_prod(lhs, rhs[:int(col.max())])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_matrix_inner_prod_with_trailing_empty_rows_takes_a_short_lhs(gpu, dtype):
+    """Only rows with entries index lhs (sparsematrix.rs:165-168): with the last rows empty, an lhs that ends right after
+    the last non-empty row is legal in the reference and gives the same sum; one entry shorter panics."""
+    rng = np.random.default_rng(11)
+    n_rows, n_cols, last = 5000, 3000, 4321
+    lens = rng.integers(0, 9, n_rows)
+    lens[last] = 5
+    lens[last + 1:] = 0
+    off = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = rng.integers(0, n_cols, int(off[-1]), dtype=np.uint32)
+    val = rng.uniform(-1, 1, len(col)).astype(dtype)
+    lhs = rng.uniform(-1, 1, n_rows).astype(dtype)
+    rhs = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    ref = float(oracle.mat_inner_prod(off, col, val, lhs, rhs))
+    scale = float(oracle.mat_inner_prod(off, col, np.abs(val), np.abs(lhs), np.abs(rhs)))
+    tol = (1e-5 if dtype == np.float32 else 1e-12) * scale
+    for variant in ("auto", "stream", "merge", "vector"):
+        full = m.inner_prod(lhs, rhs, variant=variant)
+        short = m.inner_prod(lhs[:last + 1], rhs, variant=variant)
+        assert abs(full - ref) <= tol and short == full, variant
+    assert m.inner_prod(sm.DenseVec.from_vec(lhs[:last + 1]), sm.DenseVec.from_vec(rhs)) == m.inner_prod(lhs, rhs)
+    with pytest.raises(sm.SparseMatPanic) as e:
+        m.inner_prod(lhs[:last], rhs)
+    assert e.value.status == _lib.SMH_ERR_INDEX_RANGE
