@@ -258,3 +258,52 @@ def test_blocks_on_distinct_devices(gpu, backend, dtype):
     iters, rr = mc.cg_solve(bh, xs, tol=tol, iter_max=500)
     ox, oit, _ = oracle.cg(nn, nn, off, col, val, bh, np.zeros(nn, dtype), tol=tol, iter_max=500)
     assert abs(iters - oit) <= 1 and np.abs(xs.astype(np.float64) - ox).max() < 10 * tol
+
+
+def test_full_size_c5_eight_blocks_on_one_device(gpu):
+    """BASELINE configs[4] at its size as far as one GPU goes: 80 M rows x 32 = 2.56e9 entries in 8 row blocks of 10 M
+    (global columns, sparsemat_par.rs:20-35), all adopted on device 0 (PEER backend), x born on the device, y = A x, the
+    window exchange, z = A y.  Checked: the plan (window, <= 2 x 4096 received entries per block), every block's copy of y
+    on the column interval it references against the owners' slices (bit for bit: the exchange moves bits), y and z on row blocks
+    that straddle every block boundary against the oracle (K1r: the north-star bound; z from the exchanged y)."""
+    from util import assert_spmv_close
+    nb, r, k = 8, 10_000_000, 32
+    n = nb * r
+    blocks = [synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32, b * r, (b + 1) * r) for b in range(nb)]
+    m = sm.SparseMatParLocal.adopt(blocks, n)
+    assert m.n_non_zero_entries() == n * k > 2 ** 31
+    assert m.backend() == "peer"
+    mode, max_recv = m.exchange_mode("auto")
+    assert mode == "window" and 0 < max_recv <= 2 * 4096
+    x, y, z = m.vec(), m.vec(), m.vec()
+    m.synchronize()
+    for b in range(nb):
+        synth.gen_x(synth.SEED_X, n, np.float32, ptr=x.ptr(b))
+    sm.lib().smh_device_synchronize()
+    m.mvp_dev(x, y)      # AUTO kernel per block, then the exchange (AUTO: window)
+    m.mvp_dev(y, z)
+    m.synchronize()
+    assert blocks[0].resolved_variant()[0] == "vector"
+    x_host = x.download_block(0)
+    y_host, z_host = y.download(), z.download()
+    for b in range(nb):  # the exchange: block b's copy holds the owners' bits on the columns it references
+        lo, hi = blocks[b].col_range()
+        hi += 1
+        assert max(0, b * r - 4096) <= lo <= max(0, b * r - 3840) and min(n, (b + 1) * r + 3840) <= hi <= min(n, (b + 1) * r + 4096)
+        mine = y.download_block(b)
+        assert np.array_equal(mine[lo:hi].view(np.uint32), y_host[lo:hi].view(np.uint32)), b
+        del mine
+    for edge in range(nb + 1):  # rows on both sides of every block boundary
+        rb, re = max(0, edge * r - 1500), min(n, edge * r + 1500)
+        off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32, rb, re)
+        assert_spmv_close(y_host[rb:re], off, col, val, x_host, "C5 y rows %d.." % rb)
+        assert_spmv_close(z_host[rb:re], off, col, val, y_host, "C5 z rows %d.." % rb)
+    # the bit-exact kernel on the same partition agrees with the oracle on those rows bit for bit
+    m.mvp_dev(x, y, variant="stream")
+    m.synchronize()
+    y_st = y.download()
+    for edge in (0, 3, nb):
+        rb, re = max(0, edge * r - 1500), min(n, edge * r + 1500)
+        off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32, rb, re)
+        assert np.array_equal(y_st[rb:re].view(np.uint32), oracle.spmv(off, col, val, x_host).view(np.uint32))
+    assert np.abs(y_st.astype(np.float64) - y_host).max() < 5e-5
