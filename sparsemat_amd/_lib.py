@@ -198,6 +198,9 @@ def lib():
                     sys.modules["torch"].cuda.init()
             except Exception:
                 pass
+        # one process per GPU over RCCL shares device memory between processes through dmabuf handles; the host driver of
+        # this platform supports only that mode, and the HSA runtime reads the switch when it initialises (first HIP call)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
