@@ -459,7 +459,8 @@ int smh_par_cg_solve(smh_par *p, const void *b_host, size_t b_len, void *x_host_
 /* ---- synthetic workloads (bench / test support, DESIGN.md "Synthetic inputs") ------------
  * Counter-based generators writing straight into device memory so 10M..80M-row inputs never
  * cross PCIe.  pattern: 0 banded-stratified (ascending), 1 uniform (draw order),
- * 2 contiguous band (k consecutive columns around the diagonal).          */
+ * 2 contiguous band (k consecutive columns around the diagonal), 3 window (k <= 64 distinct
+ * columns drawn without replacement from [row - 4096, row + 4096], ascending).              */
 int smh_synth_x(smh_dtype dtype, uint64_t seed, size_t begin, size_t n, void *x_dev, void *stream);
 int smh_synth_fixed(smh_dtype dtype, uint64_t seed, int pattern, size_t n, uint32_t k,
                     size_t row_begin, size_t row_end, uint32_t *offset_rows_dev,

@@ -318,7 +318,7 @@ def gen_x(seed, n, dtype=np.float32, begin=0):
     return x
 
 
-PATTERN_BANDED, PATTERN_UNIFORM, PATTERN_DIAG = 0, 1, 2
+PATTERN_BANDED, PATTERN_UNIFORM, PATTERN_DIAG, PATTERN_WINDOW = 0, 1, 2, 3
 
 
 def gen_fixed(seed, pattern, n, k, dtype=np.float32, row_begin=0, row_end=None):

@@ -259,6 +259,28 @@ void orc_gen_x_f64(uint64_t seed, size_t begin, size_t n, double *x) {
             int64_t base = (int64_t)row - (int64_t)(w / 2);                                   \
             if (base > (int64_t)n - (int64_t)w) base = (int64_t)n - (int64_t)w;               \
             if (base < 0) base = 0;                                                           \
+            if (pattern == 3) { /* SURVEY 8(d) "banded" to the letter: k distinct columns drawn */ \
+                /* without replacement from [row - 4096, row + 4096] within [0, n), stored ascending */ \
+                uint64_t lo = row > 4096 ? row - 4096 : 0;                                    \
+                uint64_t hi = row + 4096 < n - 1 ? row + 4096 : n - 1;                        \
+                uint64_t ww = hi - lo + 1;                                                    \
+                uint32_t *c = columns + o;                                                    \
+                uint32_t got = 0;                                                             \
+                for (uint64_t t = 0; got < k; ++t) { /* draw t: accepted unless already drawn */ \
+                    uint32_t cand = (uint32_t)(lo + orc_splitmix64(rk + 2ull * t) % ww);      \
+                    uint32_t q = 0;                                                           \
+                    while (q < got && c[q] != cand) ++q;                                      \
+                    if (q == got) c[got++] = cand;                                            \
+                }                                                                             \
+                for (uint32_t a = 1; a < k; ++a) { /* ascending (insertion sort) */           \
+                    uint32_t v = c[a];                                                        \
+                    uint32_t b = a;                                                           \
+                    while (b > 0 && c[b - 1] > v) { c[b] = c[b - 1]; --b; }                   \
+                    c[b] = v;                                                                 \
+                }                                                                             \
+                for (uint32_t j = 0; j < k; ++j) values[o + j] = H2V(orc_splitmix64(rk + 2ull * j + 1ull)); \
+                continue;                                                                     \
+            }                                                                                 \
             for (uint32_t j = 0; j < k; ++j) {                                                \
                 uint64_t hc = orc_splitmix64(rk + 2ull * j);                                  \
                 uint64_t hv = orc_splitmix64(rk + 2ull * j + 1ull);                           \

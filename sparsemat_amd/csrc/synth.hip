@@ -69,6 +69,43 @@ __global__ void k_synth_fixed(uint64_t seed, int pattern, uint64_t n, uint32_t k
     if (blockIdx.x == 0 && threadIdx.x == 0) off[rows] = (uint32_t)total;
 }
 
+// pattern 3 (SURVEY 8(d) "banded" to the letter): k <= kWindowMaxK distinct columns drawn without replacement from
+// [row - 4096, row + 4096] within [0, n), stored ascending.  One thread per row: the draws of a row depend on each other.
+constexpr uint32_t kWindowMaxK = 64;
+template <typename T>
+__global__ void k_synth_window(uint64_t seed, uint64_t n, uint32_t k, uint64_t row_begin, uint64_t row_end,
+                               uint32_t *__restrict__ off, uint32_t *__restrict__ col, T *__restrict__ val) {
+    const uint64_t rows = row_end - row_begin;
+    for (uint64_t lr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lr < rows; lr += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = row_begin + lr;
+        const uint64_t rk = rowkey(seed, row);
+        const uint64_t lo = row > 4096 ? row - 4096 : 0;
+        const uint64_t hi = row + 4096 < n - 1 ? row + 4096 : n - 1;
+        const uint64_t ww = hi - lo + 1;
+        uint32_t c[kWindowMaxK];
+        uint32_t got = 0;
+        for (uint64_t t = 0; got < k; ++t) {  // draw t: accepted unless already drawn
+            const uint32_t cand = (uint32_t)(lo + splitmix64(rk + 2ull * t) % ww);
+            uint32_t q = 0;
+            while (q < got && c[q] != cand) ++q;
+            if (q == got) c[got++] = cand;
+        }
+        for (uint32_t a = 1; a < k; ++a) {  // ascending
+            const uint32_t v = c[a];
+            uint32_t b = a;
+            while (b > 0 && c[b - 1] > v) { c[b] = c[b - 1]; --b; }
+            c[b] = v;
+        }
+        const uint64_t o = lr * k;
+        off[lr] = (uint32_t)o;
+        for (uint32_t j = 0; j < k; ++j) {
+            col[o + j] = c[j];
+            val[o + j] = hash_to_unit<T>(splitmix64(rk + 2ull * j + 1ull));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[rows] = (uint32_t)(rows * k);
+}
+
 // one (sub)wave-strided loop per row: rows given by offsets
 template <typename T>
 __global__ void k_synth_fill(uint64_t seed, uint64_t n_cols, uint64_t row_begin, uint64_t rows,
@@ -151,6 +188,19 @@ int synth_x(int dtype, uint64_t seed, size_t begin, size_t n, void *x, hipStream
 int synth_fixed(int dtype, uint64_t seed, int pattern, size_t n, uint32_t k, size_t row_begin, size_t row_end,
                 uint32_t *off, uint32_t *col, void *val, hipStream_t s) {
     const uint64_t total = (uint64_t)(row_end - row_begin) * k;
+    if (pattern < 0 || pattern > 3) return fail(SMH_ERR_INVALID, "unknown generator pattern %d", pattern);
+    if (pattern == 3) {
+        if (k > kWindowMaxK) return fail(SMH_ERR_INVALID, "the window pattern draws at most %u columns per row (%u asked)", kWindowMaxK, k);
+        const uint64_t rows = row_end - row_begin;
+        if (dtype == SMH_F64)
+            hipLaunchKernelGGL(k_synth_window<double>, dim3(gen_grid(rows ? rows : 1)), dim3(kBlock), 0, s, seed, (uint64_t)n, k,
+                               (uint64_t)row_begin, (uint64_t)row_end, off, col, (double *)val);
+        else
+            hipLaunchKernelGGL(k_synth_window<float>, dim3(gen_grid(rows ? rows : 1)), dim3(kBlock), 0, s, seed, (uint64_t)n, k,
+                               (uint64_t)row_begin, (uint64_t)row_end, off, col, (float *)val);
+        SMH_HIP(hipGetLastError());
+        return SMH_OK;
+    }
     if (dtype == SMH_F64)
         hipLaunchKernelGGL(k_synth_fixed<double>, dim3(gen_grid(total)), dim3(kBlock), 0, s, seed, pattern, (uint64_t)n, k,
                            (uint64_t)row_begin, (uint64_t)row_end, off, col, (double *)val);

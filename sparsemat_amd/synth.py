@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import check, lib
 from .sparsemat_crs import SparseMatCRS
 
-PATTERN_BANDED, PATTERN_UNIFORM, PATTERN_DIAG = 0, 1, 2
+PATTERN_BANDED, PATTERN_UNIFORM, PATTERN_DIAG, PATTERN_WINDOW = 0, 1, 2, 3
 SEED_MATRIX, SEED_X = 0x5EED0001, 0x5EED0002
 
 

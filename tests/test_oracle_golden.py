@@ -369,6 +369,20 @@ def test_generators_are_deterministic_and_in_range():
     off2, col2, val2 = oracle.gen_fixed(1, oracle.PATTERN_BANDED, 10_000, 32, np.float32, 100, 400)
     assert np.array_equal(col, col2) and np.array_equal(val, val2)
     assert val.min() >= -1 and val.max() < 1
+    # SURVEY 8(d)'s "banded" to the letter: k distinct columns without replacement from [i - 4096, i + 4096], ascending
+    for n, k, rb, re in ((50_000, 32, 0, 50_000), (50_000, 32, 45_000, 50_000), (40, 32, 0, 40), (9000, 64, 100, 1100)):
+        off, col, val = oracle.gen_fixed(3, oracle.PATTERN_WINDOW, n, k, np.float64, rb, re)
+        c = col.reshape(-1, k).astype(np.int64)
+        rows = np.arange(rb, re)[:, None]
+        assert off[-1] == (re - rb) * k and np.all(np.diff(c, axis=1) > 0) and c.min() >= 0 and c.max() < n
+        assert np.all(np.abs(c - rows) <= 4096)
+        sub = oracle.gen_fixed(3, oracle.PATTERN_WINDOW, n, k, np.float64, rb + 7, re - 3)  # a row's draw is its own
+        assert np.array_equal(sub[1], col[7 * k:(re - rb - 3) * k]) and np.array_equal(sub[2], val[7 * k:(re - rb - 3) * k])
+    off, col, val = oracle.gen_fixed(3, oracle.PATTERN_WINDOW, 2_000_000, 32, np.float32, 1_000_000, 1_020_000)
+    d = (col.reshape(-1, 32).astype(np.int64) - np.arange(1_000_000, 1_020_000)[:, None]).ravel()
+    hist = np.histogram(d, bins=16, range=(-4096, 4097))[0]
+    assert hist.min() > 0.9 * hist.mean() and hist.max() < 1.1 * hist.mean()  # uniform over the window, not stratified
+    assert np.diff(col.reshape(-1, 32), axis=1).max() > 1500                  # (strata of 256 columns bound a gap by 511)
     cdf = oracle.powerlaw_cdf()
     assert np.all(np.diff(cdf.astype(np.int64)) >= 0) and cdf[-1] == 0xFFFFFFFF
     off, col, val = oracle.gen_powerlaw(5, 20_000, 20_000)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("pattern", [synth.PATTERN_BANDED, synth.PATTERN_UNIFORM], ids=["banded", "uniform"])
+@pytest.mark.parametrize("pattern", [synth.PATTERN_BANDED, synth.PATTERN_UNIFORM, synth.PATTERN_WINDOW], ids=["banded", "uniform", "window"])
 @pytest.mark.parametrize("n,k,rb,re", [(5000, 32, 0, 5000), (40, 32, 0, 40), (100_000, 32, 30_000, 41_234), (9000, 7, 8000, 9000)])
 def test_fixed_generator_bit_exact(gpu, dtype, pattern, n, k, rb, re):
     m = synth.crs_fixed(synth.SEED_MATRIX, pattern, n, k, dtype, rb, re)
@@ -21,9 +21,13 @@ def test_fixed_generator_bit_exact(gpu, dtype, pattern, n, k, rb, re):
     assert np.array_equal(off, off_r) and np.array_equal(col, col_r)
     assert np.array_equal(val.view(np.uint8), val_r.view(np.uint8))
     assert col.max() < n
-    if pattern == synth.PATTERN_BANDED:  # ascending and distinct inside every row
+    if pattern in (synth.PATTERN_BANDED, synth.PATTERN_WINDOW):  # ascending and distinct inside every row
         c = col.reshape(-1, k).astype(np.int64)
         assert np.all(np.diff(c, axis=1) > 0)
+    if pattern == synth.PATTERN_WINDOW:
+        assert np.all(np.abs(c - np.arange(rb, re)[:, None]) <= 4096)
+        with pytest.raises(sm.SparseMatPanic):
+            synth.crs_fixed(synth.SEED_MATRIX, pattern, 1000, 65, dtype)
 
 
 def test_x_and_powerlaw_and_laplace_generators_bit_exact(gpu):
@@ -97,6 +101,32 @@ def _run(m, xptr, n_x, variant, dtype):
     m.mvp_dev(xptr, n_x, ybuf.ptr, variant)
     sm.lib().smh_device_synchronize()
     return ybuf.download(dtype, m.n_rows())
+
+
+def test_full_size_c2_window_without_replacement(gpu):
+    """SURVEY 8(d)'s primary pattern to the letter -- 32 distinct columns drawn WITHOUT REPLACEMENT from [i - 4096, i + 4096],
+    ascending -- at BASELINE C2's size (the headline generator is the stratified subset of it).  AUTO takes the same ring
+    kernel (a 64-row tile references 8 256 columns: inside the 16 384-column ring); sampled row blocks against the oracle
+    under the north-star bound, the bit-exact kernels bit for bit, every kernel against every other on all rows."""
+    n, k = 10_000_000, 32
+    m = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_WINDOW, n, k, np.float32)
+    assert m.n_non_zero_entries() == n * k
+    assert m.resolved_variant()[0] == "vector"
+    _, ring_frac, ring_active, _, _ = m.ring_plan()
+    assert ring_active and ring_frac == 1.0
+    xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
+    x = xbuf.download(np.float32, n)
+    y_auto = _run(m, xptr, n, "auto", np.float32)
+    y_st = _run(m, xptr, n, "stream", np.float32)
+    y_mg = _run(m, xptr, n, "merge", np.float32)
+    for rb in (0, 4_999_000, n - 3000):
+        re = min(n, rb + 3000)
+        off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_WINDOW, n, k, np.float32, rb, re)
+        assert np.array_equal(y_st[rb:re].view(np.uint32), oracle.spmv(off, col, val, x).view(np.uint32))
+        assert_spmv_close(y_auto[rb:re], off, col, val, x, "K1r rows %d.." % rb)
+        assert_spmv_close(y_mg[rb:re], off, col, val, x, "merge rows %d.." % rb)
+    assert np.abs(y_auto.astype(np.float64) - y_st).max() < 5e-5
+    assert np.abs(y_mg.astype(np.float64) - y_st).max() < 5e-5
 
 
 def test_more_than_2_to_the_31_entries_in_one_matrix(gpu):

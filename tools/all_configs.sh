@@ -12,8 +12,8 @@ run() {  # title, command...
     timeout -k 10 600 "$@" >> "$out" 2>&1 || { echo "FAILED: $*" >> "$out"; return 1; }
 }
 run "C1" python3 tests/bench/c1_bench.py &&
-run "C2 banded / contiguous band / uniform, C3 power law, C4 Laplacian 512^3 (quick_bench, single launches)" \
-    python3 tools/quick_bench.py --cases banded,diag,uniform,powerlaw,lap512,banded64 --lanes 8 --cb-shifts 18,19 &&
+run "C2 banded (stratified) / window (without replacement) / contiguous band / uniform, C3 power law, C4 Laplacian 512^3 (quick_bench, single launches)" \
+    python3 tools/quick_bench.py --cases banded,window,diag,uniform,powerlaw,lap512,banded64 --lanes 8 --cb-shifts 18,19 &&
 run "C4 CG" python3 tools/cg_bench.py --iters 100 &&
 run "C4 Jacobi PCG (extension) next to CG" python3 tools/pcg_bench.py &&
 run "SparseMatrix::inner_prod next to the plain product" python3 tools/inner_prod_bench.py &&

@@ -61,7 +61,7 @@ def main():
             m = synth.crs_laplace3d(g, g, g, dtype)
         else:
             dtype = np.float64 if case.endswith("64") else np.float32
-            pat = {"banded": synth.PATTERN_BANDED, "uniform": synth.PATTERN_UNIFORM, "diag": synth.PATTERN_DIAG}[
+            pat = {"banded": synth.PATTERN_BANDED, "uniform": synth.PATTERN_UNIFORM, "diag": synth.PATTERN_DIAG, "window": synth.PATTERN_WINDOW}[
                 case.replace("64", "")]
             m = synth.crs_fixed(synth.SEED_MATRIX, pat, n, args.k, dtype)
         nr = m.n_rows()
