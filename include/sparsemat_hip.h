@@ -478,6 +478,17 @@ int smh_synth_laplace3d(smh_dtype dtype, size_t nx, size_t ny, size_t nz, size_t
                         size_t row_end, uint32_t *offset_rows_dev, uint32_t *columns_dev,
                         void *values_dev, size_t *nnz_out, void *stream);
 
+/* ---- device memory kept by the library ---------------------------------------------------
+ * Everything the library allocates on a device (matrix arrays, plans, scratch of assembly /
+ * transpose / prod, vectors, smh_dev_alloc) goes through a caching layer (csrc/pool.hip): freed
+ * blocks of 1 MiB and more stay with the library, at most SMH_POOL_MAX_BYTES per device (environment,
+ * default 16 GiB, 0 = off), because a fresh hipMalloc of a few GB takes 1.2-1.4 s every few calls
+ * on this platform.  smh_pool_trim returns everything kept to the HIP runtime (call it before
+ * another library in the process needs the memory); smh_pool_stats reports kept and in-use bytes
+ * of pooled blocks.  Not part of the reference's interface (its Vec allocations have no such cost). */
+int smh_pool_trim(void);
+int smh_pool_stats(size_t *kept_bytes_out, size_t *live_bytes_out);
+
 /* ---- raw device memory helpers for hosts without a HIP binding (the Rust shim) ---------- */
 int smh_dev_alloc(size_t bytes, void **out);
 int smh_dev_free(void *p);

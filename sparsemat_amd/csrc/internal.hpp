@@ -250,3 +250,13 @@ struct smh_vec {
     void *d = nullptr;
     bool owns = true;
 };
+
+// ---- device memory goes through the caching layer of pool.hip (see there for why) ---------------------------------------
+namespace smh {
+hipError_t pool_malloc(void **out, size_t bytes);
+hipError_t pool_free(void *p);
+}  // namespace smh
+#ifndef SMH_POOL_IMPL
+#define hipMalloc(p, n) ::smh::pool_malloc((void **)(p), (n))
+#define hipFree(p) ::smh::pool_free((void *)(p))
+#endif
