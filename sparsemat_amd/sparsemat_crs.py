@@ -95,6 +95,12 @@ class SparseMatCRS:
         check(lib().smh_crs_transpose(self._h, C.byref(h)))
         return type(self)(h, self.dtype)
 
+    @staticmethod
+    def last_transpose_route():
+        """"general" (stable sort by target row) or "windowed" (counting placement, csrc/transpose_win.hip): how this
+        thread's last ``transpose`` was carried out."""
+        return ("general", "windowed")[lib().smh_last_transpose_route()]
+
     def column_info(self):
         """ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as arrays ``(rows, col_ptr, entries)``:
         ``rows[k]`` = row of entry k; column j's entries in storage order are ``entries[col_ptr[j]:col_ptr[j+1]]``."""

@@ -229,3 +229,101 @@ def test_column_info_at_scale_and_errors(gpu):
     with pytest.raises(sm.SparseMatPanic) as e:
         bad.column_info()
     assert e.value.status == _lib.SMH_ERR_INDEX_RANGE
+
+
+# ---- the windowed route (csrc/transpose_win.hip) -------------------------------------------------------------------------
+def band_crs(rng, n_rows, n_cols, slope, below, above, max_len, dtype, shuffle):
+    """rows with up to max_len distinct columns from [slope r - below, slope r + above] (clipped), empty rows included"""
+    lens = rng.integers(0, max_len + 1, n_rows)
+    cols, off = [], np.zeros(n_rows + 1, np.uint32)
+    for r in range(n_rows):
+        c0, c1 = max(0, int(slope * r) - below), min(n_cols, int(slope * r) + above + 1)
+        k = min(int(lens[r]), max(0, c1 - c0))
+        c = np.sort(rng.choice(np.arange(c0, c1), k, replace=False)) if k else np.zeros(0, np.int64)
+        if shuffle:
+            rng.shuffle(c)
+        cols.append(c)
+        off[r + 1] = off[r] + k
+    col = np.concatenate(cols).astype(np.uint32)
+    val = rng.uniform(-1, 1, len(col)).astype(dtype)
+    return off, col, val
+
+
+def transposed_both_routes(m):
+    os.environ.pop("SMH_TRANSPOSE_WINDOWED", None)
+    t = m.transpose()
+    route = sm.SparseMatCRS.last_transpose_route()
+    os.environ["SMH_TRANSPOSE_WINDOWED"] = "0"
+    try:
+        g = m.transpose()
+        assert sm.SparseMatCRS.last_transpose_route() == "general"
+    finally:
+        os.environ.pop("SMH_TRANSPOSE_WINDOWED", None)
+    assert (t.n_rows(), t.n_cols(), t.n_non_zero_entries(), t.orphans()) == (g.n_rows(), g.n_cols(), g.n_non_zero_entries(), g.orphans())
+    for a, b in zip(t.raw_parts(), g.raw_parts()):
+        assert a.tobytes() == b.tobytes()
+    return t, route
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", ["band", "band_storage_order", "tall", "wide", "steep_long_result_rows", "repeat", "second_entry_smaller"])
+def test_transpose_windowed_route_bit_exact(gpu, dtype, shape):
+    """Matrices whose columns move with their rows take the counting placement; its result is the general route's and the
+    oracle's bit for bit.  Repeated pairs, result rows beyond 512 entries and the first-push quirk fall back."""
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
+    expect_route = "windowed"
+    if shape in ("band", "band_storage_order", "repeat", "second_entry_smaller"):
+        n_rows, n_cols = 5000, 5100
+        off, col, val = band_crs(rng, n_rows, n_cols, 1.0, 40, 60, 24, dtype, shape != "band")
+        if shape == "repeat":  # one (row, column) pair twice: `set` keeps one entry with the later value
+            r = 2500
+            while off[r + 1] - off[r] < 2:
+                r += 1
+            col[off[r] + 1] = col[off[r]]
+            expect_route = "general"
+        if shape == "second_entry_smaller":
+            r = 0
+            while off[r + 1] - off[r] == 0:
+                r += 1
+            k = int(off[r])  # the first two stored entries (of one row or of two): the second gets the smaller column
+            a, b = int(col[k]), int(col[k + 1])
+            col[k], col[k + 1] = max(a, b) + (1 if a == b else 0), min(a, b)
+            expect_route = "general"
+    elif shape == "tall":      # result rows of ~100 entries: several entries per ranking lane
+        n_rows, n_cols = 30000, 1000
+        off, col, val = band_crs(rng, n_rows, n_cols, 1 / 30, 4, 4, 6, dtype, True)
+        assert np.bincount(col).max() > 64
+    elif shape == "wide":
+        n_rows, n_cols = 1500, 12000
+        off, col, val = band_crs(rng, n_rows, n_cols, 8.0, 30, 30, 40, dtype, True)
+    else:                      # 6000 rows into 12 columns: result rows far beyond 512 entries
+        n_rows, n_cols = 6000, 12
+        off, col, val = band_crs(rng, n_rows, n_cols, 12 / 6000, 1, 1, 3, dtype, True)
+        expect_route = "general"
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    t, route = transposed_both_routes(m)
+    assert route == expect_route
+    expect = oracle.transpose(off, col, val)
+    same_crs(t, expect)
+    assert t.n_non_zero_entries() + t.orphans() == expect[5]
+
+
+def test_transpose_windowed_at_scale(gpu):
+    """1 M x 32 banded-stratified and window patterns (BASELINE C2's generators) and a 3-D Laplacian: both routes agree bit
+    for bit; the band patterns take the windowed route, the Laplacian's far diagonals would re-read the source too often."""
+    from sparsemat_amd import synth
+    for pattern, dtype in ((synth.PATTERN_BANDED, np.float32), (synth.PATTERN_WINDOW, np.float64)):
+        m = synth.crs_fixed(synth.SEED_MATRIX, pattern, 1_000_000, 32, dtype)
+        t, route = transposed_both_routes(m)
+        assert route == "windowed"
+        off, col, val = m.raw_parts()
+        ref = sp.csr_matrix((val, col, off), shape=(m.n_rows(), m.n_cols())).T.tocsr()
+        ref.sort_indices()
+        t_off, t_col, t_val = t.raw_parts()
+        assert np.array_equal(t_off, ref.indptr.astype(np.uint32))
+        t.sort_rows()
+        _, s_col, s_val = t.raw_parts()
+        assert np.array_equal(s_col, ref.indices.astype(np.uint32)) and s_val.tobytes() == ref.data.astype(dtype).tobytes()
+    lap = synth.crs_laplace3d(96, 96, 96, np.float32)
+    _, route = transposed_both_routes(lap)
+    assert route == "general"
