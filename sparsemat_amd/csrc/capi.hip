@@ -1015,8 +1015,7 @@ int smh_crs_transpose(const smh_crs *a, smh_crs **out) {
     SMH_HIP(hipStreamSynchronize(a->stream));
     if (a->nnz == 0) return assemble_common((smh_dtype)a->dtype, 0, nullptr, nullptr, nullptr, nullptr, true, true, out);
     g_transpose_route = 0;
-    // matrices whose columns move with their rows: counting placement through LDS windows instead of the sort
-    // (transpose_win.hip).  The container's first-push quirks (second target row below the first: the first entry is
+    // matrices with local structure: two bucketed passes instead of the device-wide sort (transpose_bucket.hip).  The container's first-push quirks (second target row below the first: the first entry is
     // orphaned; a single operation) and repeated (row, column) pairs stay with the general route.
     const bool windowed_allowed = !(getenv("SMH_TRANSPOSE_WINDOWED") && atoi(getenv("SMH_TRANSPOSE_WINDOWED")) == 0);
     if (windowed_allowed && a->nnz >= 2 && a->have_stats) {

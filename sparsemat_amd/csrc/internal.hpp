@@ -103,7 +103,7 @@ int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t 
                       bool reverse_rows, bool all_set, bool repeats_adjacent, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
                       uint32_t **off_out, uint32_t **col_out, void **val_out, hipStream_t s);
 int expand_rows(const uint32_t *off, size_t n_rows, uint32_t *rows_out, hipStream_t s);
-// transpose_win.hip: transposition by counting placement through LDS windows; *done == false: not applicable, nothing produced
+// transpose_bucket.hip: transposition by two bucketed passes; *done == false: not applicable, nothing produced
 int transpose_windowed(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t max_col,
                        uint32_t **off_out, uint32_t **col_out, void **val_out, size_t *n_rows_out, size_t *n_cols_out, bool *done, hipStream_t s);
 int append_to_row(int dtype, uint32_t *off, uint32_t **col, void **val, size_t n_rows, size_t *nnz, size_t row, uint32_t column,

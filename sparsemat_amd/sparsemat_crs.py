@@ -97,9 +97,9 @@ class SparseMatCRS:
 
     @staticmethod
     def last_transpose_route():
-        """"general" (stable sort by target row) or "windowed" (counting placement, csrc/transpose_win.hip): how this
+        """"general" (stable sort by target row) or "bucketed" (two bucketed passes, csrc/transpose_bucket.hip): how this
         thread's last ``transpose`` was carried out."""
-        return ("general", "windowed")[lib().smh_last_transpose_route()]
+        return ("general", "bucketed")[lib().smh_last_transpose_route()]
 
     def column_info(self):
         """ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as arrays ``(rows, col_ptr, entries)``:

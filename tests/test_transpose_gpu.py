@@ -231,7 +231,7 @@ def test_column_info_at_scale_and_errors(gpu):
     assert e.value.status == _lib.SMH_ERR_INDEX_RANGE
 
 
-# ---- the windowed route (csrc/transpose_win.hip) -------------------------------------------------------------------------
+# ---- the bucketed route (csrc/transpose_bucket.hip) -------------------------------------------------------------------------
 def band_crs(rng, n_rows, n_cols, slope, below, above, max_len, dtype, shuffle):
     """rows with up to max_len distinct columns from [slope r - below, slope r + above] (clipped), empty rows included"""
     lens = rng.integers(0, max_len + 1, n_rows)
@@ -266,12 +266,12 @@ def transposed_both_routes(m):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("shape", ["band", "band_storage_order", "tall", "wide", "steep_long_result_rows", "repeat", "second_entry_smaller"])
-def test_transpose_windowed_route_bit_exact(gpu, dtype, shape):
-    """Matrices whose columns move with their rows take the counting placement; its result is the general route's and the
-    oracle's bit for bit.  Repeated pairs, result rows beyond 512 entries and the first-push quirk fall back."""
+@pytest.mark.parametrize("shape", ["band", "band_storage_order", "tall", "wide", "steep_long_result_rows", "result_row_beyond_a_bucket", "repeat", "second_entry_smaller"])
+def test_transpose_bucketed_route_bit_exact(gpu, dtype, shape):
+    """Matrices with local structure take the two bucketed passes; the result is the general route's and the oracle's bit for
+    bit.  Repeated pairs, buckets beyond the LDS capacity and the first-push quirk fall back."""
     rng = np.random.default_rng(zlib.crc32(shape.encode()))
-    expect_route = "windowed"
+    expect_route = "bucketed"
     if shape in ("band", "band_storage_order", "repeat", "second_entry_smaller"):
         n_rows, n_cols = 5000, 5100
         off, col, val = band_crs(rng, n_rows, n_cols, 1.0, 40, 60, 24, dtype, shape != "band")
@@ -296,10 +296,17 @@ def test_transpose_windowed_route_bit_exact(gpu, dtype, shape):
     elif shape == "wide":
         n_rows, n_cols = 1500, 12000
         off, col, val = band_crs(rng, n_rows, n_cols, 8.0, 30, 30, 40, dtype, True)
-    else:                      # 6000 rows into 12 columns: result rows far beyond 512 entries
+    elif shape == "steep_long_result_rows":   # 6000 rows into 12 columns: result rows of ~750 entries, buckets of 8 rows
         n_rows, n_cols = 6000, 12
         off, col, val = band_crs(rng, n_rows, n_cols, 12 / 6000, 1, 1, 3, dtype, True)
+        assert np.bincount(col).max() > 512
+    else:                      # 60000 rows into 3 columns: one result row alone is larger than a bucket may be
+        n_rows, n_cols = 60000, 3
+        off, col, val = band_crs(rng, n_rows, n_cols, 3 / 60000, 1, 1, 2, dtype, True)
+        assert np.bincount(col).max() > 9728
         expect_route = "general"
+    if shape != "second_entry_smaller" and col[1] < col[0]:  # (keep the container's first-push quirk out of the other shapes)
+        col[0], col[1] = col[1], col[0]
     m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
     t, route = transposed_both_routes(m)
     assert route == expect_route
@@ -308,14 +315,14 @@ def test_transpose_windowed_route_bit_exact(gpu, dtype, shape):
     assert t.n_non_zero_entries() + t.orphans() == expect[5]
 
 
-def test_transpose_windowed_at_scale(gpu):
+def test_transpose_bucketed_at_scale(gpu):
     """1 M x 32 banded-stratified and window patterns (BASELINE C2's generators) and a 3-D Laplacian: both routes agree bit
-    for bit; the band patterns take the windowed route, the Laplacian's far diagonals would re-read the source too often."""
+    for bit; bands and stencils take the bucketed route, uniformly random columns (a tile reaches thousands of buckets) do not."""
     from sparsemat_amd import synth
     for pattern, dtype in ((synth.PATTERN_BANDED, np.float32), (synth.PATTERN_WINDOW, np.float64)):
         m = synth.crs_fixed(synth.SEED_MATRIX, pattern, 1_000_000, 32, dtype)
         t, route = transposed_both_routes(m)
-        assert route == "windowed"
+        assert route == "bucketed"
         off, col, val = m.raw_parts()
         ref = sp.csr_matrix((val, col, off), shape=(m.n_rows(), m.n_cols())).T.tocsr()
         ref.sort_indices()
@@ -324,6 +331,9 @@ def test_transpose_windowed_at_scale(gpu):
         t.sort_rows()
         _, s_col, s_val = t.raw_parts()
         assert np.array_equal(s_col, ref.indices.astype(np.uint32)) and s_val.tobytes() == ref.data.astype(dtype).tobytes()
-    lap = synth.crs_laplace3d(96, 96, 96, np.float32)
+    lap = synth.crs_laplace3d(96, 96, 96, np.float32)   # a stencil: seven diagonals, a handful of buckets per tile
     _, route = transposed_both_routes(lap)
+    assert route == "bucketed"
+    uni = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_UNIFORM, 400_000, 16, np.float32)  # columns without locality
+    _, route = transposed_both_routes(uni)
     assert route == "general"
