@@ -136,7 +136,7 @@ int smh_crs_transpose(const smh_crs *a, smh_crs **out);
 /* Diagnostics: how this thread's last smh_crs_transpose was carried out -- 0 the general route (stable device-wide sort
  * by target row through the replay machinery), 1 two bucketed passes (csrc/transpose_bucket.hip: matrices with local
  * structure -- bands, stencils, block orderings -- without repeated entries; the same result bit for bit, about twice
- * as fast).  SMH_TRANSPOSE_WINDOWED=0 (environment) keeps every call on the general route. */
+ * as fast).  SMH_TRANSPOSE_BUCKETED=0 (environment) keeps every call on the general route. */
 int smh_last_transpose_route(void);
 /* ColumnIter::assemble_column_info (sparsemat_crs.rs:180-191) as flat arrays: rows[k] = row of
  * entry k (the reference's `rows` vector), and its per-column IndexList (entry indices in storage

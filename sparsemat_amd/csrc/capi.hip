@@ -1017,8 +1017,8 @@ int smh_crs_transpose(const smh_crs *a, smh_crs **out) {
     g_transpose_route = 0;
     // matrices with local structure: two bucketed passes instead of the device-wide sort (transpose_bucket.hip).  The container's first-push quirks (second target row below the first: the first entry is
     // orphaned; a single operation) and repeated (row, column) pairs stay with the general route.
-    const bool windowed_allowed = !(getenv("SMH_TRANSPOSE_WINDOWED") && atoi(getenv("SMH_TRANSPOSE_WINDOWED")) == 0);
-    if (windowed_allowed && a->nnz >= 2 && a->have_stats) {
+    const bool bucketed_allowed = !(getenv("SMH_TRANSPOSE_BUCKETED") && atoi(getenv("SMH_TRANSPOSE_BUCKETED")) == 0);
+    if (bucketed_allowed && a->nnz >= 2 && a->have_stats) {
         uint32_t c01[2] = {0, 0};
         SMH_HIP(hipMemcpy(c01, a->d_col, sizeof c01, hipMemcpyDeviceToHost));
         if (c01[1] >= c01[0]) {
@@ -1026,7 +1026,7 @@ int smh_crs_transpose(const smh_crs *a, smh_crs **out) {
             void *t_val = nullptr;
             size_t t_rows = 0, t_cols = 0;
             bool done = false;
-            SMH_TRY(transpose_windowed(a->dtype, a->d_off, a->d_col, a->d_val, a->n_rows, a->nnz, a->max_col, &t_off, &t_col, &t_val, &t_rows, &t_cols, &done,
+            SMH_TRY(transpose_bucketed(a->dtype, a->d_off, a->d_col, a->d_val, a->n_rows, a->nnz, a->max_col, &t_off, &t_col, &t_val, &t_rows, &t_cols, &done,
                                        nullptr));
             if (done) {
                 smh_crs *m = new (std::nothrow) smh_crs();

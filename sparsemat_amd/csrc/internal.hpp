@@ -104,7 +104,7 @@ int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t 
                       uint32_t **off_out, uint32_t **col_out, void **val_out, hipStream_t s);
 int expand_rows(const uint32_t *off, size_t n_rows, uint32_t *rows_out, hipStream_t s);
 // transpose_bucket.hip: transposition by two bucketed passes; *done == false: not applicable, nothing produced
-int transpose_windowed(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t max_col,
+int transpose_bucketed(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t max_col,
                        uint32_t **off_out, uint32_t **col_out, void **val_out, size_t *n_rows_out, size_t *n_cols_out, bool *done, hipStream_t s);
 int append_to_row(int dtype, uint32_t *off, uint32_t **col, void **val, size_t n_rows, size_t *nnz, size_t row, uint32_t column,
                   const void *value_host, hipStream_t s);

@@ -408,7 +408,7 @@ int run(const uint32_t *off, const uint32_t *col, const V *val, size_t n_rows, s
 }  // namespace
 
 // *done == false with SMH_OK: the matrix does not qualify, nothing was produced
-int transpose_windowed(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t max_col,
+int transpose_bucketed(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t max_col,
                        uint32_t **off_out, uint32_t **col_out, void **val_out, size_t *n_rows_out, size_t *n_cols_out, bool *done, hipStream_t s) {
     *done = false;
     if (n_rows == 0 || nnz == 0) return SMH_OK;

@@ -250,15 +250,15 @@ def band_crs(rng, n_rows, n_cols, slope, below, above, max_len, dtype, shuffle):
 
 
 def transposed_both_routes(m):
-    os.environ.pop("SMH_TRANSPOSE_WINDOWED", None)
+    os.environ.pop("SMH_TRANSPOSE_BUCKETED", None)
     t = m.transpose()
     route = sm.SparseMatCRS.last_transpose_route()
-    os.environ["SMH_TRANSPOSE_WINDOWED"] = "0"
+    os.environ["SMH_TRANSPOSE_BUCKETED"] = "0"
     try:
         g = m.transpose()
         assert sm.SparseMatCRS.last_transpose_route() == "general"
     finally:
-        os.environ.pop("SMH_TRANSPOSE_WINDOWED", None)
+        os.environ.pop("SMH_TRANSPOSE_BUCKETED", None)
     assert (t.n_rows(), t.n_cols(), t.n_non_zero_entries(), t.orphans()) == (g.n_rows(), g.n_cols(), g.n_non_zero_entries(), g.orphans())
     for a, b in zip(t.raw_parts(), g.raw_parts()):
         assert a.tobytes() == b.tobytes()
