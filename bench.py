@@ -213,6 +213,41 @@ class Events:
         return out
 
 
+def exchange_check(lib, check, synth, np, par, x, y, n, comm):
+    """N > 1, after a step: every local block holds, next to its own slice of y, the entries it RECEIVED in the exchange.
+    It can generate any rows of the synthetic matrix and x is complete on every device, so it multiplies the 64 rows on
+    either side of its slice itself (bit-exact K1s kernel) and compares them with what arrived.  A missing or stale halo
+    is an O(1) error; two kernels' rounding differs by ~1e-6.  The worst error over all ranks goes into the JSON line."""
+    tol, worst, rows_checked = 1e-4, 0.0, 0
+    try:
+        for b in range(par.n_local_blocks()):
+            r0, r1, dev, _ = par.block(b)
+            check(lib.smh_set_device(dev))
+            for ra, rb in ((max(0, r0 - 64), r0), (r1, min(n, r1 + 64))):
+                if ra >= rb:
+                    continue
+                small = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, ra, rb)
+                out = synth.DeviceBuffer((rb - ra) * 4)
+                small.mvp_dev(x.ptr(b), n, out.ptr, "stream")
+                check(lib.smh_device_synchronize())
+                want = out.download(np.float32, rb - ra)
+                got = np.empty(rb - ra, np.float32)
+                check(lib.smh_dev_download(got.ctypes.data, C.c_void_p(y.ptr(b) + ra * 4), got.nbytes))
+                worst = max(worst, float(np.max(np.abs(got.astype(np.float64) - want))))
+                rows_checked += rb - ra
+        check(lib.smh_set_device(par.block(0)[2]))
+        err = None
+    except Exception as e:  # the bench line is still worth printing
+        err, worst = "%s: %s" % (type(e).__name__, e), float("inf")
+    if comm is not None:
+        worst = comm.max(worst)
+    out = {"what": "rows received in the exchange against the receiver's own product of those rows",
+           "rows_per_rank": rows_checked, "max_abs_err": worst if worst != float("inf") else None, "tol": tol, "ok": bool(worst <= tol)}
+    if err:
+        out["error"] = err
+    return out
+
+
 def stats(ts):
     s = sorted(ts)
     return {"mean": sum(s) / len(s), "median": s[len(s) // 2], "min": s[0], "max": s[-1], "launches": len(s)}
@@ -356,8 +391,11 @@ def main():
         def spmv():
             par.mvp_dev(x, y, args.variant, "none")
 
+        skip_exchange = os.environ.get("SMH_BENCH_SKIP_EXCHANGE") == "1"  # test knob: exchange_check must then fail
+
         def exchange():
-            par.exchange(y, exchange_req)
+            if not skip_exchange:
+                par.exchange(y, exchange_req)
 
         def sync():
             par.synchronize()
@@ -410,6 +448,10 @@ def main():
         sync()
         cold = stats(cev.times_ms())
         del flush
+
+    xcheck = None
+    if par is not None and n_gpus > 1:
+        xcheck = exchange_check(lib, check, synth, np, par, x, y, n, comm)  # (collective: every rank calls it)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = bytes_gpu * n_gpus / (elapsed / args.steps) / 1e9
@@ -466,6 +508,8 @@ def main():
             "layout": "f32 values + 16-bit ring-slot columns for LDS-ring phases (u32 columns kept for the rest)",
         },
     }
+    if xcheck is not None:
+        result["exchange_check"] = xcheck
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             if par is None:

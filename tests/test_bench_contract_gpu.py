@@ -1,0 +1,65 @@
+"""bench.py as the driver runs it, at small sizes: ONE JSON line on stdout with the contract's keys, `roofline` and `cpu_baseline`
+at N = 1; the N > 1 code path (one process, blocks sharing the device) with its exchange self-check -- which must fail when
+the exchange is skipped; and the one-process-per-GPU launch with a lone rank under torch.distributed.run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def run_bench(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]  # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(gpu):
+    d = run_bench(["--rows", "1000000", "--steps", "7", "--warmup", "2", "--no-traffic"])
+    for k in CONTRACT:
+        assert k in d, k
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["dtype"], d["scaling"], d["vs_baseline"]) == (1, 7, 2, "f32", "weak", None)
+    assert d["metric"] == "csr_spmv_effective_hbm_GBps" and d["unit"] == "GB/s" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches"] == 7 and r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"] and r["traffic"] is None
+    assert r["cold"]["launches"] == 20
+    assert abs(d["value"] - d["algorithmic_bytes_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.02
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["parity_ok"] is True and c["value"] > 0
+    assert d["cpu_baseline_all_cores"]["cores"] >= 1
+
+
+def test_n_gpus_rehearsal_checks_its_exchange(gpu):
+    env = {"SMH_BENCH_SHARE_DEVICES": "1"}
+    d = run_bench(["--gpus", "4", "--rows", "500000", "--steps", "5", "--warmup", "2"], env)
+    assert d["n_gpus"] == 4 and d["config"]["exchange"] == "window" and d["config"]["exchange_backend"] == "peer"
+    assert d["roofline"]["traffic"] is None and d.get("cpu_baseline") is None
+    x = d["exchange_check"]
+    assert x["ok"] is True and x["rows_per_rank"] == 2 * 64 + 2 * 128 and x["max_abs_err"] <= x["tol"]
+    # whole-job value: all blocks' bytes over the step time
+    assert abs(d["value"] - 4 * d["algorithmic_bytes_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    d = run_bench(["--gpus", "3", "--rows", "400000", "--steps", "3", "--warmup", "1", "--exchange", "allgather"], env)
+    assert d["config"]["exchange"] == "allgather" and d["exchange_check"]["ok"] is True
+    bad = run_bench(["--gpus", "4", "--rows", "500000", "--steps", "3", "--warmup", "1"], dict(env, SMH_BENCH_SKIP_EXCHANGE="1"))
+    assert bad["exchange_check"]["ok"] is False and bad["exchange_check"]["max_abs_err"] > 1e-2
+
+
+def test_one_rank_under_the_launcher(gpu):
+    """python -m torch.distributed.run --nproc-per-node 1: the rank-per-GPU path (communicator from a file rendezvous,
+    smh_par_create_rank, RCCL calls with a lone rank)."""
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29631"]
+    d = run_bench(["--gpus", "1", "--rows", "500000", "--steps", "4", "--warmup", "1", "--no-traffic", "--no-cpu-baseline"],
+                  {"SMH_BENCH_FORCE_PAR": "1", "SMH_PAR_EXCHANGE_SINGLE": "1"}, launcher)
+    assert d["n_gpus"] == 1 and d["config"]["launch"].startswith("torch.distributed.run") and d["config"]["exchange_backend"] == "rccl"
