@@ -449,9 +449,31 @@ def main():
         cold = stats(cev.times_ms())
         del flush
 
-    xcheck = None
+    xcheck = allgather_leg = None
     if par is not None and n_gpus > 1:
         xcheck = exchange_check(lib, check, synth, np, par, x, y, n, comm)  # (collective: every rank calls it)
+        # BASELINE configs[4] names the all-gather of the dense vector: when AUTO chose the cheaper window exchange, the same
+        # K steps are timed once more with the in-place all-gather and reported beside the headline (never instead of it)
+        if exchange_mode != "allgather" and os.environ.get("SMH_BENCH_NO_ALLGATHER_LEG") != "1":
+            try:
+                for _ in range(min(args.warmup, 2) + 1):
+                    spmv()
+                    par.exchange(y, "allgather")
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    spmv()
+                    par.exchange(y, "allgather")
+                barrier()
+                el = time.perf_counter() - t0
+                if comm is not None:
+                    el = comm.max(el)
+                allgather_leg = {"exchange": "allgather", "ms_per_step": el / args.steps * 1e3,
+                                 "value": bytes_gpu * n_gpus / (el / args.steps) / 1e9, "unit": "GB/s",
+                                 "received_bytes_per_gpu_step": (n - rows) * 4,
+                                 "exchange_check": exchange_check(lib, check, synth, np, par, x, y, n, comm)}
+            except Exception as e:
+                allgather_leg = {"exchange": "allgather", "error": "%s: %s" % (type(e).__name__, e)}
 
     ms_per_step = elapsed / args.steps * 1e3
     value = bytes_gpu * n_gpus / (elapsed / args.steps) / 1e9
@@ -510,6 +532,8 @@ def main():
     }
     if xcheck is not None:
         result["exchange_check"] = xcheck
+    if allgather_leg is not None:
+        result["allgather_leg"] = allgather_leg
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             if par is None:

@@ -47,10 +47,13 @@ def test_n_gpus_rehearsal_checks_its_exchange(gpu):
     assert d["roofline"]["traffic"] is None and d.get("cpu_baseline") is None
     x = d["exchange_check"]
     assert x["ok"] is True and x["rows_per_rank"] == 2 * 64 + 2 * 128 and x["max_abs_err"] <= x["tol"]
+    a = d["allgather_leg"]  # configs[4]'s literal exchange, timed beside the headline
+    assert a["exchange"] == "allgather" and a["exchange_check"]["ok"] is True and a["ms_per_step"] > 0
+    assert a["received_bytes_per_gpu_step"] == 3 * 500000 * 4
     # whole-job value: all blocks' bytes over the step time
     assert abs(d["value"] - 4 * d["algorithmic_bytes_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
     d = run_bench(["--gpus", "3", "--rows", "400000", "--steps", "3", "--warmup", "1", "--exchange", "allgather"], env)
-    assert d["config"]["exchange"] == "allgather" and d["exchange_check"]["ok"] is True
+    assert d["config"]["exchange"] == "allgather" and d["exchange_check"]["ok"] is True and "allgather_leg" not in d
     bad = run_bench(["--gpus", "4", "--rows", "500000", "--steps", "3", "--warmup", "1"], dict(env, SMH_BENCH_SKIP_EXCHANGE="1"))
     assert bad["exchange_check"]["ok"] is False and bad["exchange_check"]["max_abs_err"] > 1e-2
 
