@@ -23,6 +23,8 @@ extern "C" {
     pub fn smh_abi_version() -> c_int;
     pub fn smh_last_error() -> *const c_char;
     pub fn smh_device_count(count_out: *mut c_int) -> c_int;
+    pub fn smh_pool_trim() -> c_int;  // return the device memory the library keeps (csrc/pool.hip) to the HIP runtime
+    pub fn smh_pool_stats(kept_bytes_out: *mut usize, live_bytes_out: *mut usize) -> c_int;
     pub fn smh_crs_create(dtype: c_int, n_rows: usize, n_cols: usize, nnz: usize,
                           offset_rows: *const u32, columns: *const u32, values: *const c_void,
                           validate: c_int, out: *mut *mut smh_crs) -> c_int;
@@ -46,6 +48,8 @@ extern "C" {
     pub fn smh_crs_replay(dtype: c_int, n_ops: usize, rows: *const u32, cols: *const u32, values: *const c_void,
                           ops: *const u8, out: *mut *mut smh_crs) -> c_int;
     pub fn smh_crs_transpose(a: *const smh_crs, out: *mut *mut smh_crs) -> c_int;
+    pub fn smh_last_transpose_route() -> c_int;  // 0 general (device-wide sort), 1 two bucketed passes: diagnostics only
+    pub fn smh_crs_orphans(m: *const smh_crs) -> usize;
     pub fn smh_crs_prod(a: *const smh_crs, b: *const smh_crs, out: *mut *mut smh_crs) -> c_int;
     pub fn smh_crs_is_symmetric(m: *const smh_crs, out: *mut c_int) -> c_int;
     pub fn smh_crs_is_sorted(m: *const smh_crs, out: *mut c_int) -> c_int;
