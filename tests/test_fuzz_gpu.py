@@ -176,3 +176,62 @@ def test_fuzz_column_tables_and_predicates(gpu):
         e_rows, e_ptr, e_entries = oracle.column_info(off, col, n)
         assert np.array_equal(rows, e_rows) and np.array_equal(col_ptr, e_ptr) and np.array_equal(entries, e_entries)
     assert min(seen.values()) > 10, seen
+
+
+def _structured(rng, dtype):
+    """A matrix with local structure: row r takes len_r distinct columns from a window around slope * r (plus, sometimes, a few
+    far diagonals like a stencil), stored shuffled; some rows empty, sometimes one very long row or dense tile."""
+    n_rows = int(rng.choice([1, 2, 255, 256, 257, 1000, 4097, 20_000, 70_001]))
+    slope = float(rng.choice([0.03, 0.5, 1.0, 1.0, 3.0, 9.0]))
+    w = int(rng.choice([0, 1, 7, 40, 300]))
+    max_len = int(rng.choice([1, 3, 8, 33, 70]))
+    n_cols = int(slope * n_rows) + w + 2
+    width = 2 * w + 1
+    lens = rng.integers(0, min(max_len, width) + 1, n_rows)
+    if rng.integers(0, 3) == 0:
+        lens[rng.integers(0, n_rows)] = min(width, int(rng.integers(1, 600)))
+    order = np.argsort(rng.random((n_rows, width)), axis=1)          # a random subset of the window per row, in random order
+    keep = np.arange(width)[None, :] < lens[:, None]
+    rows_idx = np.repeat(np.arange(n_rows), lens)
+    cols = (np.floor(slope * np.arange(n_rows))[:, None].astype(np.int64) + order - w)[keep]
+    far = int(rng.choice([0, 0, 17, 4096])) if n_rows > 300 else 0
+    cols = np.where((far > 0) & (rng.random(len(cols)) < 0.2), cols + far * rng.integers(-1, 2, len(cols)), cols)
+    cols = np.clip(cols, 0, n_cols - 1)
+    off = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    # clipping and the far diagonals may have produced a repeated (row, column) pair: that is a legal input (general route)
+    val = rng.uniform(-1, 1, len(cols)).astype(dtype)
+    return n_rows, n_cols, off, cols.astype(np.uint32), val, rows_idx
+
+
+def test_fuzz_transpose_routes_agree(gpu):
+    """150 structured matrices: the bucketed transposition and the general route give the same arrays bit for bit, whichever
+    route the first call took; small ones also against the literal restatement of the reference's container."""
+    import os
+    rng = np.random.default_rng(20261004)
+    taken = {"bucketed": 0, "general": 0}
+    for it in range(150):
+        dtype = np.float32 if it % 2 else np.float64
+        n_rows, n_cols, off, col, val, _ = _structured(rng, dtype)
+        if len(col) == 0:
+            continue
+        m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+        os.environ.pop("SMH_TRANSPOSE_BUCKETED", None)
+        t = m.transpose()
+        route = sm.SparseMatCRS.last_transpose_route()
+        taken[route] += 1
+        os.environ["SMH_TRANSPOSE_BUCKETED"] = "0"
+        try:
+            g = m.transpose()
+        finally:
+            os.environ.pop("SMH_TRANSPOSE_BUCKETED", None)
+        what = "case %d: %d x %d, %d entries, route %s" % (it, n_rows, n_cols, len(col), route)
+        assert (t.n_rows(), t.n_cols(), t.n_non_zero_entries(), t.orphans()) == (g.n_rows(), g.n_cols(), g.n_non_zero_entries(), g.orphans()), what
+        for a, b in zip(t.raw_parts(), g.raw_parts()):
+            assert a.tobytes() == b.tobytes(), what
+        if len(col) <= 6000:
+            e = oracle.transpose(off, col, val)
+            t_off, t_col, t_val = t.raw_parts()
+            assert (t.n_rows(), t.n_cols()) == (e[0], e[1]) and np.array_equal(t_off[:e[0] + 1], e[2]) and np.array_equal(t_col, e[3]), what
+            assert t_val.tobytes() == e[4].tobytes(), what
+    assert taken["bucketed"] >= 40 and taken["general"] >= 10, taken
