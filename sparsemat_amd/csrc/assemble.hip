@@ -771,6 +771,16 @@ int column_info(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t 
         return SMH_OK;
     }
     SMH_TRY(expand_rows(off, n_rows, rows, s));
+    // matrices with local structure: the lists by two bucketed passes instead of the device-wide sort (transpose_bucket.hip;
+    // the same arrays bit for bit, tests/test_transpose_gpu.py runs both); SMH_COLUMN_INFO_BUCKETED=0 keeps the sort
+    if (!(getenv("SMH_COLUMN_INFO_BUCKETED") && atoi(getenv("SMH_COLUMN_INFO_BUCKETED")) == 0)) {
+        bool done = false;
+        SMH_TRY(column_lists_bucketed(off, col, n_rows, n_cols, nnz, max_col, col_ptr, entries, &done, s));
+        if (done) {
+            SMH_HIP(hipStreamSynchronize(s));
+            return SMH_OK;
+        }
+    }
     Scratch tmp_bufs;
     uint32_t *col_s = nullptr, *idx = nullptr;
     SMH_TRY(tmp_bufs.alloc(&col_s, nnz));

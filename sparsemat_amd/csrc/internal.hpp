@@ -103,6 +103,9 @@ int assemble_triplets(int dtype, size_t n, const uint32_t *rows, const uint32_t 
                       bool reverse_rows, bool all_set, bool repeats_adjacent, size_t *n_rows_out, size_t *n_cols_out, size_t *nnz_out,
                       uint32_t **off_out, uint32_t **col_out, void **val_out, hipStream_t s);
 int expand_rows(const uint32_t *off, size_t n_rows, uint32_t *rows_out, hipStream_t s);
+// transpose_bucket.hip: the column lists of ColumnIter by the same two bucketed passes (col_ptr [n_cols + 1], entries [nnz]: device arrays)
+int column_lists_bucketed(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t n_cols, size_t nnz, uint32_t max_col, uint32_t *col_ptr,
+                          uint32_t *entries, bool *done, hipStream_t s);
 // transpose_bucket.hip: transposition by two bucketed passes; *done == false: not applicable, nothing produced
 int transpose_bucketed(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t max_col,
                        uint32_t **off_out, uint32_t **col_out, void **val_out, size_t *n_rows_out, size_t *n_cols_out, bool *done, hipStream_t s);

@@ -138,7 +138,7 @@ k_tb_max(const uint32_t *__restrict__ total, uint64_t n_b, TbScalars *__restrict
 constexpr uint32_t kTbChunk = 4096;
 constexpr uint32_t kTbPartThreads = 512;  // (8 entries per thread and chunk: 16 cost 207-220 VGPRs, two waves per SIMD)
 
-template <typename V>
+template <typename V, bool INFO>  // INFO: the column tables (keys = entry indices, no values); else the transposition
 __global__ void __launch_bounds__(kTbPartThreads)
 k_tb_part(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const V *__restrict__ val, uint64_t n_rows, uint32_t shift,
           uint32_t *__restrict__ cursor, uint32_t *__restrict__ bk_src, uint8_t *__restrict__ bk_t, V *__restrict__ bk_val) {
@@ -169,9 +169,12 @@ k_tb_part(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, co
             const uint32_t i = tid + (uint32_t)j * kTbPartThreads;
             const bool in = i < n;
             c[j] = in ? col[c0 + i] : kTbEmpty;
-            v[j] = in ? __builtin_nontemporal_load(val + c0 + i) : V(0);
+            if constexpr (INFO) v[j] = V(0); else v[j] = in ? __builtin_nontemporal_load(val + c0 + i) : V(0);
         }
-        {   // the rows of the chunk's entries (bisection in the tile's offsets, the lookups of a thread interleaved)
+        if constexpr (INFO) {
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) hr[j] = 0;
+        } else {   // the rows of the chunk's entries (bisection in the tile's offsets, the lookups of a thread interleaved)
             uint32_t a[kPer], b[kPer];
 #pragma unroll
             for (int j = 0; j < kPer; ++j) { a[j] = 0; b[j] = kTbSrcRows; }
@@ -222,8 +225,8 @@ k_tb_part(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, co
         for (int j = 0; j < kPer; ++j) {
             if (tid + (uint32_t)j * kTbPartThreads >= n) continue;
             const uint32_t h = (hr[j] >> 12) & 0x3FFu, p = lpre[h] + (hr[j] & 0xFFFu);
-            st_src[p] = (uint32_t)r0 + (hr[j] >> 24);
-            st_val[p] = v[j];
+            if constexpr (INFO) st_src[p] = (uint32_t)(c0 + tid + (uint64_t)j * kTbPartThreads);  // the entry's index
+            else { st_src[p] = (uint32_t)r0 + (hr[j] >> 24); st_val[p] = v[j]; }
             st_h[p] = (uint16_t)h;
             st_t[p] = (uint8_t)(c[j] & low);
         }
@@ -233,7 +236,7 @@ k_tb_part(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, co
             const uint32_t gpos = start[h] + (p - lpre[h]);
             bk_src[gpos] = st_src[p];
             bk_t[gpos] = st_t[p];
-            bk_val[gpos] = st_val[p];
+            if constexpr (!INFO) bk_val[gpos] = st_val[p];
         }
         __syncthreads();  // (the table and the stage are reset by the next chunk)
     }
@@ -249,7 +252,7 @@ constexpr uint32_t kTbPer = (kTbCap + kTbSortThreads - 1) / kTbSortThreads;  // 
 constexpr uint32_t kTbSlots = kTbCap + 3 * 256;  // LDS slots: every result row starts at a multiple of four (16-byte reads)
 constexpr size_t kTbSortLds = (kTbSlots + kTbCap / 32 + 256 + 257 + 257 + 3) * 4 + 16;
 
-template <typename V>
+template <typename V, bool INFO>
 __global__ void __launch_bounds__(kTbSortThreads)
 k_tb_sort(const uint32_t *__restrict__ bucket_off, const uint32_t *__restrict__ bk_src, const uint8_t *__restrict__ bk_t, const V *__restrict__ bk_val,
           uint64_t n_t, uint32_t shift, uint32_t *__restrict__ off_t, uint32_t *__restrict__ out_col, V *__restrict__ out_val, TbScalars *__restrict__ sc) {
@@ -270,7 +273,7 @@ k_tb_sort(const uint32_t *__restrict__ bucket_off, const uint32_t *__restrict__ 
         const bool in = i < n;
         t[j] = in ? bk_t[b0 + i] : 256u;
         src[j] = in ? bk_src[b0 + i] : 0u;
-        v[j] = in ? __builtin_nontemporal_load(bk_val + b0 + i) : V(0);
+        if constexpr (INFO) v[j] = V(0); else v[j] = in ? __builtin_nontemporal_load(bk_val + b0 + i) : V(0);
     }
     if (tid < 256) rcnt[tid] = 0;
     for (uint32_t i = tid; i < kTbCap / 32; i += kTbSortThreads) taken[i] = 0;
@@ -319,18 +322,22 @@ k_tb_sort(const uint32_t *__restrict__ bucket_off, const uint32_t *__restrict__ 
         uint32_t gt = 0;
         for (uint32_t q = 0; q < len; q += 4) {
             const uint4 o = *reinterpret_cast<const uint4 *>(keys + base + q);
-            gt += (o.x > me) + (o.y > me) + (o.z > me) + (o.w > me);
+            if constexpr (INFO) gt += (o.x && o.x < me) + (o.y && o.y < me) + (o.z && o.z < me) + (o.w && o.w < me);  // ascending: the SMALLER keys (0 = padding)
+            else gt += (o.x > me) + (o.y > me) + (o.z > me) + (o.w > me);
         }
         const uint32_t pos = rofs[t[j]] + gt;
-        const uint32_t bit = 1u << (pos & 31u);
-        repeat |= (atomicOr(&taken[pos >> 5], bit) & bit) != 0u;  // equal source rows rank equal
         out_col[b0 + pos] = src[j];
-        out_val[b0 + pos] = v[j];
+        if constexpr (!INFO) {
+            const uint32_t bit = 1u << (pos & 31u);
+            repeat |= (atomicOr(&taken[pos >> 5], bit) & bit) != 0u;  // equal source rows rank equal
+            out_val[b0 + pos] = v[j];
+        }
     }
     if (repeat) atomicOr(&sc->repeats, 1u);
 }
 
-template <typename V>
+// INFO: col_ptr / entries are the caller's device arrays (*off_out / *col_out on entry, at least max_col + 2 and nnz elements)
+template <typename V, bool INFO>
 int run(const uint32_t *off, const uint32_t *col, const V *val, size_t n_rows, size_t nnz, uint32_t max_col, uint32_t **off_out, uint32_t **col_out,
         V **val_out, size_t *n_cols_out, bool *done, hipStream_t s) {
     *done = false;
@@ -348,7 +355,7 @@ int run(const uint32_t *off, const uint32_t *col, const V *val, size_t n_rows, s
     TbScalars *d_sc = nullptr;
     auto cleanup = [&](bool keep_result) {
         (void)hipFree(d_total); (void)hipFree(d_cursor); (void)hipFree(d_src); (void)hipFree(d_t); (void)hipFree(d_bval);
-        if (!keep_result) { (void)hipFree(d_offt); (void)hipFree(d_col); (void)hipFree(d_val); }
+        if (!keep_result && !INFO) { (void)hipFree(d_offt); (void)hipFree(d_col); (void)hipFree(d_val); }
     };
     auto go = [&]() -> int {
         TbScalars sc;
@@ -378,19 +385,24 @@ int run(const uint32_t *off, const uint32_t *col, const V *val, size_t n_rows, s
         SMH_HIP(hipMemcpyAsync(d_cursor, d_total, n_b * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         SMH_HIP(hipMalloc((void **)&d_src, (nnz + 4) * sizeof(uint32_t)));
         SMH_HIP(hipMalloc((void **)&d_t, nnz + 16));
-        SMH_HIP(hipMalloc((void **)&d_bval, (nnz + 4) * sizeof(V)));
-        SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tb_part<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_part_lds<V>()));
-        SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tb_sort<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTbSortLds));
-        hipLaunchKernelGGL((k_tb_part<V>), dim3((unsigned)n_st), dim3(kTbPartThreads), tb_part_lds<V>(), s, off, col, val, (uint64_t)n_rows, shift, d_cursor, d_src, d_t, d_bval);
+        if (!INFO) SMH_HIP(hipMalloc((void **)&d_bval, (nnz + 4) * sizeof(V)));
+        SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tb_part<V, INFO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_part_lds<V>()));
+        SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tb_sort<V, INFO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTbSortLds));
+        hipLaunchKernelGGL((k_tb_part<V, INFO>), dim3((unsigned)n_st), dim3(kTbPartThreads), tb_part_lds<V>(), s, off, col, val, (uint64_t)n_rows, shift, d_cursor, d_src, d_t, d_bval);
         SMH_HIP(hipGetLastError());
-        SMH_HIP(hipMalloc((void **)&d_offt, (n_t + 1) * sizeof(uint32_t)));
-        SMH_HIP(hipMalloc((void **)&d_col, (nnz + 4) * sizeof(uint32_t)));
-        SMH_HIP(hipMalloc((void **)&d_val, (nnz + 4) * sizeof(V)));
-        SMH_HIP(hipMemsetAsync(d_col + nnz, 0, 4 * sizeof(uint32_t), s));
-        SMH_HIP(hipMemsetAsync(d_val + nnz, 0, 4 * sizeof(V), s));
+        if (INFO) {
+            d_offt = *off_out;
+            d_col = *col_out;
+        } else {
+            SMH_HIP(hipMalloc((void **)&d_offt, (n_t + 1) * sizeof(uint32_t)));
+            SMH_HIP(hipMalloc((void **)&d_col, (nnz + 4) * sizeof(uint32_t)));
+            SMH_HIP(hipMalloc((void **)&d_val, (nnz + 4) * sizeof(V)));
+            SMH_HIP(hipMemsetAsync(d_col + nnz, 0, 4 * sizeof(uint32_t), s));
+            SMH_HIP(hipMemsetAsync(d_val + nnz, 0, 4 * sizeof(V), s));
+        }
         const uint32_t nnz32 = (uint32_t)nnz;
         SMH_HIP(hipMemcpyAsync(d_offt + n_t, &nnz32, sizeof nnz32, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL((k_tb_sort<V>), dim3((unsigned)n_b), dim3(kTbSortThreads), kTbSortLds, s, d_total, d_src, d_t, d_bval, n_t, shift, d_offt, d_col, d_val, d_sc);
+        hipLaunchKernelGGL((k_tb_sort<V, INFO>), dim3((unsigned)n_b), dim3(kTbSortThreads), kTbSortLds, s, d_total, d_src, d_t, d_bval, n_t, shift, d_offt, d_col, d_val, d_sc);
         SMH_HIP(hipGetLastError());
         SMH_HIP(hipMemcpyAsync(&sc, d_sc, sizeof sc, hipMemcpyDeviceToHost, s));
         SMH_HIP(hipStreamSynchronize(s));
@@ -401,7 +413,7 @@ int run(const uint32_t *off, const uint32_t *col, const V *val, size_t n_rows, s
     };
     const int rc = go();
     cleanup(rc == SMH_OK && *done);
-    if (rc == SMH_OK && *done) { *off_out = d_offt; *col_out = d_col; *val_out = d_val; }
+    if (rc == SMH_OK && *done && !INFO) { *off_out = d_offt; *col_out = d_col; *val_out = d_val; }
     return rc;
 }
 
@@ -414,8 +426,33 @@ int transpose_bucketed(int dtype, const uint32_t *off, const uint32_t *col, cons
     if (n_rows == 0 || nnz == 0) return SMH_OK;
     *n_rows_out = (size_t)max_col + 1;
     if (dtype == SMH_F64)
-        return run<double>(off, col, (const double *)val, n_rows, nnz, max_col, off_out, col_out, (double **)val_out, n_cols_out, done, s);
-    return run<float>(off, col, (const float *)val, n_rows, nnz, max_col, off_out, col_out, (float **)val_out, n_cols_out, done, s);
+        return run<double, false>(off, col, (const double *)val, n_rows, nnz, max_col, off_out, col_out, (double **)val_out, n_cols_out, done, s);
+    return run<float, false>(off, col, (const float *)val, n_rows, nnz, max_col, off_out, col_out, (float **)val_out, n_cols_out, done, s);
+}
+
+__global__ void __launch_bounds__(kBlock) k_tb_fill(uint32_t *__restrict__ p, uint64_t n, uint32_t v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) p[i] = v;
+}
+
+// ColumnIter::assemble_column_info's per-column lists (sparsemat_crs.rs:180-191) by the same passes: the entry indices grouped
+// by column, ascending inside a column (= storage order: the stable sort of assemble.hip::column_info).  col_ptr [n_cols + 1]
+// and entries [nnz] are the caller's device arrays; *done == false: not applicable (columns without locality), nothing valid
+// was written.
+int column_lists_bucketed(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t n_cols, size_t nnz, uint32_t max_col, uint32_t *col_ptr,
+                          uint32_t *entries, bool *done, hipStream_t s) {
+    *done = false;
+    if (n_rows == 0 || nnz == 0 || (size_t)max_col >= n_cols) return SMH_OK;
+    size_t dummy_cols = 0;
+    float *no_val = nullptr;
+    SMH_TRY((run<float, true>(off, col, nullptr, n_rows, nnz, max_col, &col_ptr, &entries, &no_val, &dummy_cols, done, s)));
+    if (*done && n_cols > (size_t)max_col + 1) {  // columns beyond the last one that occurs: empty lists at the end
+        const uint64_t n = n_cols - ((size_t)max_col + 1);
+        hipLaunchKernelGGL(k_tb_fill, dim3((unsigned)std::min<uint64_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, s, col_ptr + (size_t)max_col + 2, n,
+                           (uint32_t)nnz);
+        SMH_HIP(hipGetLastError());
+        SMH_HIP(hipStreamSynchronize(s));
+    }
+    return SMH_OK;
 }
 
 }  // namespace smh

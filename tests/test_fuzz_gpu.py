@@ -206,7 +206,8 @@ def _structured(rng, dtype):
 
 def test_fuzz_transpose_routes_agree(gpu):
     """150 structured matrices: the bucketed transposition and the general route give the same arrays bit for bit, whichever
-    route the first call took; small ones also against the literal restatement of the reference's container."""
+    route the first call took, and so do the column tables by buckets and by the stable sort; small ones also against the
+    literal restatement of the reference's container."""
     import os
     rng = np.random.default_rng(20261004)
     taken = {"bucketed": 0, "general": 0}
@@ -229,6 +230,18 @@ def test_fuzz_transpose_routes_agree(gpu):
         assert (t.n_rows(), t.n_cols(), t.n_non_zero_entries(), t.orphans()) == (g.n_rows(), g.n_cols(), g.n_non_zero_entries(), g.orphans()), what
         for a, b in zip(t.raw_parts(), g.raw_parts()):
             assert a.tobytes() == b.tobytes(), what
+        # the column tables: the bucketed passes (keys = entry indices, ascending) against the device-wide stable sort
+        info = m.column_info()
+        os.environ["SMH_COLUMN_INFO_BUCKETED"] = "0"
+        try:
+            info_sorted = m.column_info()
+        finally:
+            os.environ.pop("SMH_COLUMN_INFO_BUCKETED", None)
+        for a, b in zip(info, info_sorted):
+            assert np.array_equal(a, b), what
+        if len(col) <= 6000:
+            e_rows, e_ptr, e_entries = oracle.column_info(off, col, n_cols)
+            assert np.array_equal(info[0], e_rows) and np.array_equal(info[1], e_ptr) and np.array_equal(info[2], e_entries), what
         if len(col) <= 6000:
             e = oracle.transpose(off, col, val)
             t_off, t_col, t_val = t.raw_parts()

@@ -331,6 +331,9 @@ def test_transpose_bucketed_at_scale(gpu):
         t.sort_rows()
         _, s_col, s_val = t.raw_parts()
         assert np.array_equal(s_col, ref.indices.astype(np.uint32)) and s_val.tobytes() == ref.data.astype(dtype).tobytes()
+        rows, col_ptr, entries = m.column_info()  # (by buckets) = the stable order of the entry indices by column
+        assert np.array_equal(entries, np.argsort(col, kind="stable").astype(np.uint32))
+        assert np.array_equal(col_ptr, ref.indptr.astype(np.uint32)) and np.array_equal(rows, np.repeat(np.arange(m.n_rows(), dtype=np.uint32), 32))
     lap = synth.crs_laplace3d(96, 96, 96, np.float32)   # a stencil: seven diagonals, a handful of buckets per tile
     _, route = transposed_both_routes(lap)
     assert route == "bucketed"
