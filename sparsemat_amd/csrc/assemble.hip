@@ -53,8 +53,9 @@ static unsigned grid_for(uint64_t n) {
 // sort key (row), payload (column << 32 | stream position) + the matrix dimensions (integer max: exact)
 __global__ void __launch_bounds__(kBlock)
 k_asm_keys(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ cols, uint64_t n, uint32_t *__restrict__ row_key,
-           uint64_t *__restrict__ cp, uint32_t *__restrict__ dims /* [0] max row, [1] max column */) {
+           uint64_t *__restrict__ cp, uint32_t *__restrict__ dims /* [0] max row, [1] max column, [2] != 0: the rows are not non-decreasing */) {
     uint32_t mr = 0, mc = 0;
+    bool unsorted = false;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
     const uint64_t n4 = (((uintptr_t)rows | (uintptr_t)cols) & 15u) ? 0 : n / 4;  // 16-B loads need aligned arrays
@@ -69,6 +70,7 @@ k_asm_keys(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ cols,
         reinterpret_cast<u64x2 *>(cp)[2 * q + 1] = b;
         mr = max(max(mr, r.x), max(max(r.y, r.z), r.w));
         mc = max(max(mc, c.x), max(max(c.y, c.z), c.w));
+        unsorted |= (r.x > r.y) | (r.y > r.z) | (r.z > r.w) | (q > 0 && rows[k - 1] > r.x);
     }
     for (uint64_t k = 4 * n4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = rows[k], c = cols[k];
@@ -76,7 +78,9 @@ k_asm_keys(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ cols,
         cp[k] = ((uint64_t)c << 32) | (uint32_t)k;
         mr = max(mr, r);
         mc = max(mc, c);
+        unsorted |= k > 0 && rows[k - 1] > r;
     }
+    if (unsorted) dims[2] = 1u;  // (every writer stores the same value)
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) {
         mr = max(mr, (uint32_t)__shfl_down(mr, o, kWave));
@@ -474,23 +478,31 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
     uint64_t *cp = nullptr, *cp_s = nullptr;
     T *vals_s = nullptr;
     uint8_t *ops_s = nullptr;
-    SMH_TRY(tmp_bufs.alloc(&dims, 2));
-    SMH_HIP(hipMemsetAsync(dims, 0, 2 * sizeof(uint32_t), s));
+    SMH_TRY(tmp_bufs.alloc(&dims, 3));
+    SMH_HIP(hipMemsetAsync(dims, 0, 3 * sizeof(uint32_t), s));
     SMH_TRY(tmp_bufs.alloc(&row_key, n));
-    SMH_TRY(tmp_bufs.alloc(&row_s, n));
     SMH_TRY(tmp_bufs.alloc(&cp, n));
-    SMH_TRY(tmp_bufs.alloc(&cp_s, n));
     lap("scratch allocation");
     hipLaunchKernelGGL(k_asm_keys, dim3(grid_for(n) < 4096u ? grid_for(n) : 4096u), dim3(kBlock), 0, s, rows, cols, n, row_key, cp, dims);
     SMH_HIP(hipGetLastError());
     lap("keys");
-    uint32_t h_dims[2];
+    uint32_t h_dims[3];
     SMH_HIP(hipMemcpyAsync(h_dims, dims, sizeof h_dims, hipMemcpyDeviceToHost, s));
     SMH_HIP(hipStreamSynchronize(s));
     const uint64_t n_rows = (uint64_t)h_dims[0] + 1, n_cols = (uint64_t)h_dims[1] + 1;
-    // 1. by row (stable): cp_s holds the rows' operations in stream order
-    SMH_ROCPRIM(rocprim::radix_sort_pairs(tmp, bytes, row_key, row_s, cp, cp_s, (size_t)n, 0u, bits_for(h_dims[0]), s));
-    lap("sort by row");
+    // 1. by row (stable): cp_s holds the rows' operations in stream order.  A stream whose rows never decrease -- a row-major
+    // assembly loop, the products of SparseMatrix::prod -- is in that order already: nothing to sort (3 of 7 ms per prod batch)
+    static const bool allow_presorted = !(getenv("SMH_ASSEMBLE_PRESORTED") && atoi(getenv("SMH_ASSEMBLE_PRESORTED")) == 0);
+    if (allow_presorted && !h_dims[2]) {
+        row_s = row_key;
+        cp_s = cp;
+        lap("sort by row (skipped: rows non-decreasing)");
+    } else {
+        SMH_TRY(tmp_bufs.alloc(&row_s, n));
+        SMH_TRY(tmp_bufs.alloc(&cp_s, n));
+        SMH_ROCPRIM(rocprim::radix_sort_pairs(tmp, bytes, row_key, row_s, cp, cp_s, (size_t)n, 0u, bits_for(h_dims[0]), s));
+        lap("sort by row");
+    }
     // 2. inside every row by (column, stream position); output back into `cp`
     SMH_TRY(tmp_bufs.alloc(&seg, n_rows + 1));
     hipLaunchKernelGGL(k_asm_segments, dim3(grid_for(n)), dim3(kBlock), 0, s, row_s, n, n_rows, seg);
@@ -574,9 +586,11 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
         return SMH_OK;
     }
     // long rows: segmented sorts (rocPRIM takes long segments in several passes)
-    SMH_ROCPRIM(rocprim::segmented_radix_sort_keys(tmp, bytes, cp_s, cp, (unsigned)n, (unsigned)n_rows, seg, seg + 1, 0u,
+    uint64_t *runs_buf = cp;
+    if (cp_s == cp) SMH_TRY(tmp_bufs.alloc(&runs_buf, n));  // (presorted stream: cp is the sort's input, not a free buffer)
+    SMH_ROCPRIM(rocprim::segmented_radix_sort_keys(tmp, bytes, cp_s, runs_buf, (unsigned)n, (unsigned)n_rows, seg, seg + 1, 0u,
                                                    32u + bits_for(h_dims[1]), s));
-    const uint64_t *runs = cp;  // (row_s[k], runs[k]) ascending in (row, column, stream position)
+    const uint64_t *runs = runs_buf;  // (row_s[k], runs[k]) ascending in (row, column, stream position)
     // 3. runs -> entries
     SMH_TRY(tmp_bufs.alloc(&head, n));
     SMH_TRY(tmp_bufs.alloc(&vals_s, n));
