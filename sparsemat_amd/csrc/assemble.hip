@@ -492,7 +492,7 @@ static int assemble_t(uint64_t n, const uint32_t *rows, const uint32_t *cols, co
     const uint64_t n_rows = (uint64_t)h_dims[0] + 1, n_cols = (uint64_t)h_dims[1] + 1;
     // 1. by row (stable): cp_s holds the rows' operations in stream order.  A stream whose rows never decrease -- a row-major
     // assembly loop, the products of SparseMatrix::prod -- is in that order already: nothing to sort (3 of 7 ms per prod batch)
-    static const bool allow_presorted = !(getenv("SMH_ASSEMBLE_PRESORTED") && atoi(getenv("SMH_ASSEMBLE_PRESORTED")) == 0);
+    const bool allow_presorted = !(getenv("SMH_ASSEMBLE_PRESORTED") && atoi(getenv("SMH_ASSEMBLE_PRESORTED")) == 0);
     if (allow_presorted && !h_dims[2]) {
         row_s = row_key;
         cp_s = cp;

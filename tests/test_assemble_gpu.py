@@ -162,3 +162,42 @@ def test_assemble_then_solve_on_device(gpu):
     assert abs(cg.iterations - it_ref) <= 2
     np.testing.assert_allclose(xd.to_numpy(), np.ones(n), rtol=0, atol=1e-8)
     np.testing.assert_allclose(xd.to_numpy(), x_ref, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", ["short_rows", "one_long_row", "heavy_duplicates", "gaps_and_plateaus"])
+@pytest.mark.parametrize("into_crs", [False, True], ids=["to_crs", "replay"])
+def test_streams_in_row_order_skip_the_sort_by_row(gpu, dtype, shape, into_crs):
+    """A stream whose rows never decrease (a row-major assembly loop, the products of SparseMatrix::prod) is in the order the
+    stable sort by row would give: the assembly skips that sort.  Same arrays as with the sort (SMH_ASSEMBLE_PRESORTED=0)
+    and as the restatement of the reference's containers, on the row-wise and on the long-row route."""
+    rng = np.random.default_rng({"short_rows": 21, "one_long_row": 22, "heavy_duplicates": 23, "gaps_and_plateaus": 24}[shape])
+    n = 30_000
+    if shape == "short_rows":
+        rows, n_c = np.sort(rng.integers(0, 4_000, n)), 900
+    elif shape == "one_long_row":          # beyond the row-wise replay: the segmented-sort route
+        rows, n_c = np.sort(np.concatenate([rng.integers(0, 300, n - 9000), np.full(9000, 123)])), 5_000
+    elif shape == "heavy_duplicates":
+        rows, n_c = np.sort(rng.integers(0, 50, n)), 20
+    else:
+        rows, n_c = np.sort(rng.choice([3, 4, 4000, 70_000, 70_001, 150_000], n)), 60
+    cols = rng.integers(0, n_c, n)
+    vals = rng.uniform(-1, 1, n).astype(dtype)
+    vals[rng.random(n) < 0.02] = dtype(-0.0)
+    ops = (rng.random(n) < 0.3).astype(np.uint8)
+    if into_crs and rows[1] == rows[0] and cols[1] == cols[0]:
+        cols[1] = (cols[0] + 1) % n_c      # (keep the first-push twin quirk out of this test)
+    expect = (oracle.crs_replay if into_crs else oracle.assemble)(rows, cols, vals, ops)[:5]
+    got = sm.SparseMatCRS.from_triplets(rows, cols, vals, ops, into_crs=into_crs)
+    same_crs(got, expect)
+    os.environ["SMH_ASSEMBLE_PRESORTED"] = "0"
+    try:
+        sorted_route = sm.SparseMatCRS.from_triplets(rows, cols, vals, ops, into_crs=into_crs)
+    finally:
+        os.environ.pop("SMH_ASSEMBLE_PRESORTED", None)
+    same_crs(sorted_route, expect)
+    # ... and a stream that is NOT in row order still is sorted (one operation moved to the front)
+    rows2, cols2, vals2, ops2 = np.roll(rows, 1), np.roll(cols, 1), np.roll(vals, 1), np.roll(ops, 1)
+    if rows2[0] > rows2[1]:
+        e2 = (oracle.crs_replay if into_crs else oracle.assemble)(rows2, cols2, vals2, ops2)[:5]
+        same_crs(sm.SparseMatCRS.from_triplets(rows2, cols2, vals2, ops2, into_crs=into_crs), e2)
