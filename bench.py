@@ -365,7 +365,9 @@ def main():
             check(lib.smh_stream_synchronize(C.c_void_p(stream)))
     else:
         if launched:
-            check(lib.smh_set_device(local_rank))
+            # (SMH_BENCH_SHARE_DEVICES: ranks share the visible devices -- only meaningful with the test suite's stand-in for RCCL,
+            # tests/mock_rccl; real RCCL refuses two ranks on one device)
+            check(lib.smh_set_device(local_rank % n_dev.value if share else local_rank))
             uid, rdzv_path = rendezvous_id(rank, sm.Comm.unique_id)
             comm = sm.Comm(uid, world, rank)  # ncclCommInitRank: collective
             blocks = [synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, rank * rows, (rank + 1) * rows)]

@@ -1,0 +1,149 @@
+"""The one-process-per-GPU code of the library (csrc/par.hip with a communicator from smh_comm_create) with MORE THAN ONE RANK
+on the one GPU of this build: RCCL refuses two ranks on one device, so the rank processes run with tests/mock_rccl (a stand-in
+for the dozen RCCL entry points par.hip calls, bytes through POSIX shared memory, LD_PRELOADed -- test infrastructure, see its
+header).  What runs is the library's own rank logic, unchanged: the plan table all-gather of smh_par_create_rank, the window
+exchange's send / receive pairing, the in-place all-gather with a ragged last block, the CG folds -- checked against the oracle
+on the GLOBAL matrix, bit for bit where the kernel is bit-exact.  bench.py's launcher path runs the same way with three ranks."""
+import json
+import os
+import secrets
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK_SRC = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
+MOCK_SO = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+
+
+@pytest.fixture(scope="module")
+def mock_so(gpu):
+    if not os.path.exists(MOCK_SO) or os.path.getmtime(MOCK_SO) < os.path.getmtime(MOCK_SRC):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", MOCK_SRC, "-o", MOCK_SO,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return MOCK_SO
+
+
+RANK = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import oracle
+import sparsemat_amd as sm
+from sparsemat_amd import _lib, synth
+
+rank, world = int(os.environ["SMH_T_RANK"]), int(os.environ["SMH_T_WORLD"])
+_lib.check(sm.lib().smh_set_device(0))
+comm = sm.Comm(bytes.fromhex(os.environ["SMH_T_UID"]), world, rank)
+assert (comm.size(), comm.rank()) == (world, rank)
+comm.barrier()
+assert comm.max(float(rank)) == float(world - 1)
+
+
+def my_block(n, off, col, val, dtype):
+    r = n // world
+    r0, r1 = rank * r, (n if rank == world - 1 else (rank + 1) * r)   # sparsemat_par.rs:21; the last block takes the remainder
+    o = off[r0:r1 + 1].astype(np.int64)
+    blk = sm.SparseMatCRS.from_raw_parts(r1 - r0, n, (o - o[0]).astype(np.uint32), col[o[0]:o[-1]], val[o[0]:o[-1]])
+    return blk, r0, r1
+
+
+def check_products(n, off, col, val, dtype, want_mode, tag):
+    blk, r0, r1 = my_block(n, off, col, val, dtype)
+    par = sm.SparseMatParLocal.for_rank(comm, n, blk)
+    assert par.backend() == "rccl" and par.n_local_blocks() == 1
+    mode, _ = par.exchange_mode("auto")
+    assert mode == want_mode, (tag, mode)
+    x_host = oracle.gen_x(synth.SEED_X, n, dtype)
+    y_ref = oracle.spmv(off, col, val, x_host)
+    z_ref = oracle.spmv(off, col, val, y_ref)
+    x, y, z = par.vec(host=x_host), par.vec(), par.vec()
+    for exch in ("auto", "allgather") + (("window",) if want_mode == "window" else ()):
+        par.mvp_dev(x, y, "stream", exch)      # y slices, then the exchange
+        par.mvp_dev(y, z, "stream", exch)      # reads what the exchange delivered
+        par.synchronize()
+        got_y, got_z = y.download_block(0), z.download_block(0)
+        assert got_y[r0:r1].tobytes() == y_ref[r0:r1].tobytes(), (tag, exch, "own slice of y")
+        assert got_z[r0:r1].tobytes() == z_ref[r0:r1].tobytes(), (tag, exch, "z = A y from the exchanged y")
+        if exch == "allgather" or mode == "allgather":
+            assert got_y.tobytes() == y_ref.tobytes(), (tag, exch, "gathered y")
+        elif blk.n_non_zero_entries():
+            lo, hi = blk.col_range()
+            assert got_y[lo:hi + 1].tobytes() == y_ref[lo:hi + 1].tobytes(), (tag, exch, "window of y")
+    return par
+
+
+rng = np.random.default_rng(5)
+# 1. BASELINE C5's shape in small, ragged last block: window exchange with both neighbours
+n = 50_003
+check_products(n, *oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, 32, np.float32), np.float32, "window", "banded f32")
+# 2. columns everywhere: the all-gather (in place at b R) + the ragged tail's broadcast
+n = 9_001
+check_products(n, *oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_UNIFORM, n, 9, np.float64), np.float64, "allgather", "uniform f64")
+# 3. one-directional coupling (row i takes columns i - 700 .. i - 690 and itself): every rank receives from below only; rank 0 nothing
+n = 12_000
+lens = np.full(n, 12, np.int64)
+off = np.zeros(n + 1, np.uint32); np.cumsum(lens, out=off[1:])
+col = np.clip(np.arange(n)[:, None] - 700 + np.arange(12)[None, :], 0, None)
+col[:, 11] = np.arange(n)
+col = col.astype(np.uint32).ravel()
+val = rng.uniform(-1, 1, len(col)).astype(np.float32)
+check_products(n, off, col, val, np.float32, "window", "one-directional")
+# 4. block diagonal: nobody needs anybody -- every rank's group is empty
+n = 8_000
+r = n // world
+col = ((np.arange(n) // r).clip(0, world - 1) * r)[:, None] + rng.integers(0, r, (n, 5))
+off = (np.arange(n + 1) * 5).astype(np.uint32)
+val = rng.uniform(-1, 1, n * 5).astype(np.float64)
+check_products(n, off, col.astype(np.uint32).ravel(), val, np.float64, "window", "block diagonal")
+# 5. the solver: ConjugateGradient::solve with M = SparseMatPar, scalars folded across the ranks on the devices
+for dtype, tol in ((np.float64, 1e-10), (np.float32, 1e-4)):
+    g = 14
+    off, col, val = oracle.laplace3d(g, g, g, dtype)
+    n = g ** 3
+    b_host = oracle.spmv(off, col, val, np.random.default_rng(11).uniform(-1, 1, n).astype(dtype))
+    blk, r0, r1 = my_block(n, off, col, val, dtype)
+    par = sm.SparseMatParLocal.for_rank(comm, n, blk)
+    b, x = par.vec(host=b_host), par.vec()
+    iters, rr = par.cg_solve_vec(b, x, tol=tol, iter_max=500, check_every=3)
+    o_x, o_iters, o_rr = oracle.cg(n, n, off, col, val, b_host, np.zeros(n, dtype), tol=tol, iter_max=500)
+    assert abs(iters - o_iters) <= 1 and np.sqrt(rr) < tol, (dtype, iters, o_iters, rr)
+    got = x.download_block(0)
+    assert np.max(np.abs(got[r0:r1].astype(np.float64) - o_x[r0:r1])) < 10 * tol
+    all_iters = comm.max(float(iters))
+    assert all_iters == iters   # every rank took the same decision
+comm.barrier()
+print("RANK %%d OK" %% rank)
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_ranks_on_one_device_through_the_mock(gpu, mock_so, world):
+    uid = ("smh_mock_t_%s" % secrets.token_hex(8)).encode().ljust(128, b"\0").hex()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, LD_PRELOAD=mock_so, SMH_T_RANK=str(rank), SMH_T_WORLD=str(world), SMH_T_UID=uid)
+        procs.append(subprocess.Popen([sys.executable, "-c", RANK % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for rank, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK %d OK" % rank) in out, "rank %d of %d:\n%s\n%s" % (rank, world, out[-1500:], err[-3000:])
+
+
+def test_bench_under_the_launcher_with_three_ranks(gpu, mock_so):
+    """bench.py exactly as the driver starts it for N > 1 (torch.distributed.run, one process per rank), three ranks sharing the
+    device through the mock: the file rendezvous of the communicator id, smh_par_create_rank, the window exchange, the max over
+    ranks, the exchange self-check and the all-gather leg -- the line says the exchange delivered."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29643",
+           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rows", "300000", "--steps", "3", "--warmup", "1"]
+    env = dict(os.environ, LD_PRELOAD=mock_so, SMH_BENCH_SHARE_DEVICES="1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["config"]["exchange"] == "window" and d["config"]["exchange_backend"] == "rccl"
+    assert d["config"]["launch"].startswith("torch.distributed.run")
+    assert d["exchange_check"]["ok"] is True and d["exchange_check"]["rows_per_rank"] in (64, 128)
+    assert d["allgather_leg"]["exchange_check"]["ok"] is True
