@@ -147,3 +147,50 @@ def test_bench_under_the_launcher_with_three_ranks(gpu, mock_so):
     assert d["config"]["launch"].startswith("torch.distributed.run")
     assert d["exchange_check"]["ok"] is True and d["exchange_check"]["rows_per_rank"] in (64, 128)
     assert d["allgather_leg"]["exchange_check"]["ok"] is True
+
+
+NEGATIVE = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %(root)r)
+import sparsemat_amd as sm
+from sparsemat_amd import _lib, synth
+rank, case = int(os.environ["SMH_T_RANK"]), os.environ["SMH_T_CASE"]
+_lib.check(sm.lib().smh_set_device(0))
+mock = C.CDLL(os.environ["LD_PRELOAD"])
+class Uid(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+uid = Uid()
+uid.internal = bytes.fromhex(os.environ["SMH_T_UID"]).rstrip(b"\0")
+mock.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+for f in (mock.ncclSend, mock.ncclRecv):
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+comm = C.c_void_p()
+assert mock.ncclCommInitRank(C.byref(comm), 2, uid, rank) == 0
+buf = synth.DeviceBuffer(4096)
+F32 = 7
+assert mock.ncclGroupStart() == 0
+if case == "recv_without_send":
+    if rank == 0:
+        assert mock.ncclRecv(buf.ptr, 16, F32, 1, comm, None) == 0
+else:  # counts disagree
+    if rank == 0:
+        assert mock.ncclRecv(buf.ptr, 16, F32, 1, comm, None) == 0
+    else:
+        assert mock.ncclSend(buf.ptr, 8, F32, 0, comm, None) == 0
+rc = mock.ncclGroupEnd()
+print("RANK %%d rc %%d" %% (rank, rc))
+"""
+
+
+@pytest.mark.parametrize("case,needle", [("recv_without_send", "without a matching send"), ("count_mismatch", "disagree on the count")])
+def test_the_mock_fails_where_rccl_would_hang(gpu, mock_so, case, needle):
+    """The checker checked: a receive that no peer sends to, and a send / receive pair with different counts, are reported by
+    the stand-in (real RCCL would hang or corrupt) -- so a green run above means the library's pairing really matched."""
+    uid = ("smh_mock_n_%s" % secrets.token_hex(8)).encode().ljust(128, b"\0").hex()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, LD_PRELOAD=mock_so, SMH_T_RANK=str(rank), SMH_T_UID=uid, SMH_T_CASE=case)
+        procs.append(subprocess.Popen([sys.executable, "-c", NEGATIVE % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=200) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert "RANK 0 rc 0" not in outs[0][0] and needle in outs[0][1], outs[0]
