@@ -11,11 +11,14 @@
 //   P  k_tb_part  the same tiles again, in chunks of 4096 entries: a chunk is ordered by bucket in LDS, reserves a run in each
 //                 of its buckets (one global atomic per pair) and writes its entries there as (source row, target row inside
 //                 the bucket, value) -- contiguous runs, in no particular order inside the bucket
-//   S  k_tb_sort  one block per bucket, the bucket in LDS: entries per result row (-> offset_rows of the result, no separate
-//                 counting pass), grouped by result row, and inside a row ranked by source row DESCENDING -- the order `set`
-//                 leaves behind, since SparseMatCRS::push prepends (sparsemat_crs.rs:85-87) and the source rows arrive
-//                 ascending.  Two entries of a result row with the same source row are a repeated (row, column) pair of
-//                 the source: the caller then takes the general route, which knows what `set` does with repeats.
+//   S  k_tb_sort  one block per bucket, a thread keeps its <= 19 entries in registers from the single read to the final stores:
+//                 entries per result row (-> offset_rows of the result, no separate counting pass), the source rows grouped
+//                 by result row in LDS, and every entry ranked inside its row by counting the LARGER source rows -- descending
+//                 source row is the order `set` leaves behind, since SparseMatCRS::push prepends (sparsemat_crs.rs:85-87) and
+//                 the source rows arrive ascending.  Two entries on one position (same result row, same source row) are a
+//                 repeated (row, column) pair of the source: the caller then takes the general route, which knows what `set`
+//                 does with repeats.  The column lists of ColumnIter (column_lists_bucketed) are the same passes with the
+//                 entry index as key, ascending, without values.
 // The order in which tiles reserve their runs is arbitrary; pass S orders every bucket completely, so the result is
 // deterministic and bit for bit what the general route gives (tests/test_transpose_gpu.py runs both on every shape).
 // A first attempt walked per-target-tile source windows with LDS cursors and scattered the entries straight to their rows
@@ -37,7 +40,6 @@ constexpr uint32_t kTbHash = 1024;        // slots of a tile's bucket table
 constexpr uint32_t kTbMaxDistinct = 640;  // buckets a tile may reach
 constexpr uint32_t kTbCap = 9728;         // entries of a bucket at most (76 KiB of LDS in pass S: two blocks per CU)
 constexpr uint32_t kTbSortThreads = 512;
-constexpr uint32_t kTbGroup = 32;         // lanes that rank one result row
 constexpr uint32_t kTbEmpty = 0xFFFFFFFFu;
 constexpr int kTbUnroll = 8;              // loads a thread keeps in flight
 
@@ -66,12 +68,6 @@ __device__ __forceinline__ uint32_t tb_insert(uint32_t *keys, uint32_t *n_used, 
         }
     }
     return kTbEmpty;
-}
-
-__device__ __forceinline__ uint32_t tb_find(const uint32_t *keys, uint32_t b) {
-    uint32_t h = tb_hash(b);
-    while (keys[h] != b) h = (h + 1) & (kTbHash - 1);  // (present: inserted by the counting sweep)
-    return h;
 }
 
 // H: bucket totals

@@ -145,7 +145,7 @@ ncclResult_t run_round(ncclComm *c, std::vector<Op> &ops) {
     if (!barrier(c)) return ncclSystemError;
     // consume: the k-th collective of this round meets the k-th collective message of every rank; the k-th receive from peer p
     // meets p's k-th send addressed to this rank
-    std::vector<uint32_t> coll_seen(c->n, 0), p2p_seen(c->n, 0);
+    std::vector<uint32_t> p2p_seen(c->n, 0);
     auto nth = [&](int r, int kind, int to, uint32_t k) -> const Msg * {
         const RankBox &b = c->sh->box[r];
         uint32_t seen = 0;
