@@ -66,3 +66,12 @@ def test_one_rank_under_the_launcher(gpu):
     d = run_bench(["--gpus", "1", "--rows", "500000", "--steps", "4", "--warmup", "1", "--no-traffic", "--no-cpu-baseline"],
                   {"SMH_BENCH_FORCE_PAR": "1", "SMH_PAR_EXCHANGE_SINGLE": "1"}, launcher)
     assert d["n_gpus"] == 1 and d["config"]["launch"].startswith("torch.distributed.run") and d["config"]["exchange_backend"] == "rccl"
+
+
+def test_a_hanging_optional_leg_does_not_cost_the_headline(gpu):
+    """The extras of an N > 1 line (exchange self-check, all-gather leg) run after the headline under a watchdog: with a leg that
+    never returns, the line still comes out, marked, and the process exits with status 0."""
+    env = {"SMH_BENCH_SHARE_DEVICES": "1", "SMH_BENCH_HANG_IN_LEGS": "1", "SMH_BENCH_WATCHDOG_S": "3"}
+    d = run_bench(["--gpus", "2", "--rows", "300000", "--steps", "3", "--warmup", "1"], env)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "gave up after 3 s" in d["optional_legs"]
+    assert "exchange_check" not in d and "allgather_leg" not in d
