@@ -230,6 +230,8 @@ k_tb_part(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, co
         for (uint32_t p = tid; p < n; p += kTbPartThreads) {  // neighbours in p are neighbours in their bucket's run
             const uint32_t h = st_h[p];
             const uint32_t gpos = start[h] + (p - lpre[h]);
+            // (plain stores on purpose: a run is written by many wave-instructions, 4 bytes and 1 byte per lane, and relies on L2
+            // to merge them into lines -- with non-temporal stores the C2 transposition took 27 ms instead of 7)
             bk_src[gpos] = st_src[p];
             bk_t[gpos] = st_t[p];
             if constexpr (!INFO) bk_val[gpos] = st_val[p];
