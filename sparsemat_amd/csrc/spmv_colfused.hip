@@ -202,10 +202,10 @@ k_spmv_colfused(const uint32_t *__restrict__ tile_row, const uint32_t *__restric
             // this lane's RT counts, its total, and where its entries start (exclusive wave scan of the totals)
             uint32_t cw[RT / 4];
             if constexpr (RT == 16) {
-                const u32x4 w = *reinterpret_cast<const u32x4 *>(cnt_t + (uint64_t)b * kWave * RT);
+                const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(cnt_t + (uint64_t)b * kWave * RT));  // (read once: leave L2 to x)
                 cw[0] = w.x; cw[1] = w.y; cw[2] = w.z; cw[3] = w.w;
             } else {
-                const u32x2 w = *reinterpret_cast<const u32x2 *>(cnt_t + (uint64_t)b * kWave * RT);
+                const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(cnt_t + (uint64_t)b * kWave * RT));
                 cw[0] = w.x; cw[1] = w.y;
             }
             uint32_t total = 0;
