@@ -98,6 +98,16 @@ col = ((np.arange(n) // r).clip(0, world - 1) * r)[:, None] + rng.integers(0, r,
 off = (np.arange(n + 1) * 5).astype(np.uint32)
 val = rng.uniform(-1, 1, n * 5).astype(np.float64)
 check_products(n, off, col.astype(np.uint32).ravel(), val, np.float64, "window", "block diagonal")
+# 4b. a rank whose block holds no entry at all (it needs nothing; the others still read its slice of the vector, which is
+#     zero there), random columns elsewhere
+n = 6_000
+r = n // world
+lens = rng.integers(0, 7, n)
+lens[r:2 * r if world > 2 else n] = 0          # rank 1's rows (the last rank's for two ranks) are empty
+off = np.zeros(n + 1, np.uint32); np.cumsum(lens, out=off[1:])
+col = rng.integers(0, n, int(off[-1]), dtype=np.uint32)
+val = rng.uniform(-1, 1, len(col)).astype(np.float64)
+check_products(n, off, col, val, np.float64, "allgather", "one empty block")
 # 5. the solver: ConjugateGradient::solve with M = SparseMatPar, scalars folded across the ranks on the devices
 for dtype, tol in ((np.float64, 1e-10), (np.float32, 1e-4)):
     g = 14
