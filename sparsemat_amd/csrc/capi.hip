@@ -603,6 +603,7 @@ struct StreamCfg {
     const uint8_t *len8 = nullptr;
     const uint32_t *tbase = nullptr;
     bool pipe = false;  // K1s-p: persistent blocks, three tiles in flight
+    bool small = false; // no tile beyond kStreamCapSmall entries: the two-chunk body
 };
 static int stream_cfg(smh_crs *m, StreamCfg *c) {
     *c = StreamCfg();
@@ -629,6 +630,8 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         // K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip) is an experiment kept behind a knob: on the
         // 512^3 Laplacian it measured 1.86 ms against K1s's 1.55 ms (profiles/r02_k1s_pipe_ab.log)
         static const bool pipe_on = getenv("SMH_STREAM_PIPE") && atoi(getenv("SMH_STREAM_PIPE")) == 1;
+        static const bool small_off = getenv("SMH_STREAM_SMALL") && atoi(getenv("SMH_STREAM_SMALL")) == 0;  // tuning knob
+        c->small = !small_off && m->have_stats && m->max_tile_entries <= (uint32_t)kStreamCapSmall;
         c->pipe = pipe_on && c->cwin && c->len8 && c->tbase && m->max_tile_entries <= stream_pipe_cap() && (m->owns || m->nnz % 4 == 0);
     }
     return SMH_OK;
@@ -673,7 +676,7 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
                 return launch_spmv_stream_pipe(m->dtype, m->d_val, x, y, m->n_rows, m->nnz, dot_partials, c.code, c.cwin, c.len8, c.tbase,
                                                dot_lhs, m->device, s);
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt,
-                                      c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s);
+                                      c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small);
         }
         case SMH_SPMV_COLSPLIT: {
             SMH_TRY(ensure_split(m));

@@ -42,6 +42,7 @@ constexpr int kRingEntries = 16384;    // K1r: columns of x the LDS ring holds (
 constexpr int kRingEntriesWide = 32768;  // ... f32 only, for rows that need it: 128 KiB, one 1024-thread block per CU
 constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
 constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
+constexpr int kStreamCapSmall = 2045;  // K1s: ... when no tile holds more (two 16-byte chunks per thread from an aligned start)
 constexpr int kStreamXWin = 3072;      // K1s-w: x entries of a tile's column intervals staged in LDS
 constexpr int kStreamCodeWidth = 16384;  // K1s 16-bit column codes: columns per interval (14 bits) x 4 intervals
 
@@ -65,7 +66,7 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
                        const uint16_t *code, const uint32_t *cwin /* optional: 16-bit column codes + their interval table */,
                        const uint8_t *len8, const uint32_t *tbase /* optional (with codes): byte row lengths + tile starts */,
                        const void *dot_lhs /* with dot_partials: the vector dotted with y (NULL: x); y may then be NULL */,
-                       hipStream_t s);
+                       hipStream_t s, bool small_tiles = false /* no tile holds more than kStreamCapSmall entries */);
 int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
 // K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip)
 uint32_t stream_pipe_cap();

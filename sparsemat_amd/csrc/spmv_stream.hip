@@ -277,7 +277,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     // thread: ALL of a thread's chunk loads are issued before the first gather (they sit in the memory queue
     // together), then all gathers.  A row that straddles passes keeps its accumulator: the order of the adds is
     // the storage order whatever the number of passes.
-    constexpr int NIT = CAP / (4 * kBlock) + 1;
+    constexpr int NIT = (CAP + 3 + 4 * kBlock - 1) / (4 * kBlock);  // chunks per thread that cover CAP entries from an aligned start
     uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;  // C16: starts of the tile's column intervals (tile-uniform)
     if constexpr (C16) {
         const uint32_t *w = cwin + 8 * tile;  // scalar loads
@@ -425,7 +425,7 @@ template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
                            size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
                            const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs,
-                           hipStream_t s) {
+                           hipStream_t s, bool small_tiles) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
@@ -448,6 +448,18 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     } while (0)
     if (win) SMH_ST_PICK(true, 1, false);  // the window table describes 256-row tiles
     else if (rpt == 2) SMH_ST_PICK(false, 2, false);
+    else if (code && cwin && len8 && tbase && single_pass && small_tiles) {
+        // ... and no tile beyond kStreamCapSmall entries (stencils: 7 x 256 = 1792): two chunk slots per thread instead of five.
+        // 32-34 VGPRs instead of 67-70 (f32), 46-50 instead of ~106 (f64: 4 -> 8 waves per SIMD).  Measured, one box: 400^3 f64
+        // 1.412 -> 1.330 ms; 512^3 f32 unchanged (1.503 / 1.515 ms) -- neither registers nor instruction count bound the f32
+        // kernel: rocprofv3 shows the texture addresser busy 70 % of the time (8 gather instructions per thread and tile)
+        if (dot_partials)
+            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+        else
+            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+    }
     else if (code && cwin && len8 && tbase && single_pass) {  // column codes + byte row lengths
         if (dot_partials)
             hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
@@ -515,15 +527,15 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
                        void *dot_partials, const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase,
-                       const void *dot_lhs, hipStream_t s) {
+                       const void *dot_lhs, hipStream_t s, bool small_tiles) {
     if (n_rows == 0) return SMH_OK;
     if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
     if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
     if (dtype == SMH_F64)
         return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
-                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s);
+                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s, small_tiles);
     return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
-                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s);
+                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s, small_tiles);
 }
 
 // row lengths as bytes (rows padded to whole 256-row tiles with zeros) and the tiles' first entries (n_tiles + 1 values);

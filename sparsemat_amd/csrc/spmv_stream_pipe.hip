@@ -129,28 +129,31 @@ k_spmv_stream_pipe(const T *__restrict__ val, const T *__restrict__ x, T *__rest
         const uint64_t tl = t1 - 1;  // tiles beyond the run are clamped to its last one (loaded, never consumed)
         fill();
         __syncthreads();
-        PipeTile<T> A, B, C;
+        PipeTile<T> S0, S1, S2, S3, S4;  // tiles t .. t + 4: consumed / gathered / gather issued now / loaded / loading
 #define SMH_PIPE_LOAD(SET, TT)                                                                                       \
     do {                                                                                                              \
         const uint64_t tc = (TT) < t1 ? (TT) : tl;                                                                    \
         pipe_load<T, DOT>(SET, tc, (uint32_t)(tc - t0), (uint32_t)(tc - wf), s_tb, n_rows, len8, code, val, dot_lhs, last_chunk, tid);     \
     } while (0)
-        SMH_PIPE_LOAD(A, t0);
-        SMH_PIPE_LOAD(B, t0 + 1);
-        SMH_PIPE_LOAD(C, t0 + 2);
-        pipe_gather<T>(A, x, s_cw, 0u, tid);
+        SMH_PIPE_LOAD(S0, t0);
+        SMH_PIPE_LOAD(S1, t0 + 1);
+        SMH_PIPE_LOAD(S2, t0 + 2);
+        SMH_PIPE_LOAD(S3, t0 + 3);
+        SMH_PIPE_LOAD(S4, t0 + 4);
+        pipe_gather<T>(S0, x, s_cw, 0u, tid);
+        pipe_gather<T>(S1, x, s_cw, 0u, tid);
         uint32_t buf = 0;
         // one step: gathers of the NEXT tile, then products / fold / store of the CURRENT one, then the chunk loads of the
         // tile three ahead into the set just freed.  Unrolled by three so that the sets keep static names.
-#define SMH_PIPE_STEP(CUR, NXT, T_CUR)                                                                                \
+#define SMH_PIPE_STEP(CUR, GSET, T_CUR)                                                                               \
     do {                                                                                                              \
-        if ((T_CUR) + 4 > wf + kPipeWin) { /* the window runs out: refill it from the current tile on (block-uniform) */    \
+        if ((T_CUR) + 7 > wf + kPipeWin) { /* the window runs out: refill it from the current tile on (block-uniform) */    \
             __syncthreads();                                                                                          \
             wf = (T_CUR);                                                                                             \
             fill();                                                                                                   \
             __syncthreads();                                                                                          \
         }                                                                                                             \
-        pipe_gather<T>(NXT, x, s_cw, (uint32_t)(wf - t0), tid);                                                                         \
+        pipe_gather<T>(GSET, x, s_cw, (uint32_t)(wf - t0), tid);                                                                         \
         {                                                                                                             \
             T *stage = s_prod[buf];                                                                                   \
             const uint32_t lo = CUR.k0 & 3u, hi = CUR.k1 - (CUR.k0 & ~3u);                                           \
@@ -184,14 +187,18 @@ k_spmv_stream_pipe(const T *__restrict__ val, const T *__restrict__ x, T *__rest
             }                                                                                                         \
             buf ^= 1u;                                                                                                \
         }                                                                                                             \
-        SMH_PIPE_LOAD(CUR, (T_CUR) + 3);                                                                              \
+        SMH_PIPE_LOAD(CUR, (T_CUR) + 5);                                                                              \
     } while (0)
         for (uint64_t t = t0;;) {
-            SMH_PIPE_STEP(A, B, t);
+            SMH_PIPE_STEP(S0, S2, t);
             if (++t >= t1) break;
-            SMH_PIPE_STEP(B, C, t);
+            SMH_PIPE_STEP(S1, S3, t);
             if (++t >= t1) break;
-            SMH_PIPE_STEP(C, A, t);
+            SMH_PIPE_STEP(S2, S4, t);
+            if (++t >= t1) break;
+            SMH_PIPE_STEP(S3, S0, t);
+            if (++t >= t1) break;
+            SMH_PIPE_STEP(S4, S1, t);
             if (++t >= t1) break;
         }
 #undef SMH_PIPE_STEP
