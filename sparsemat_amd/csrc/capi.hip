@@ -627,8 +627,8 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         c->cwin = m->d_stream_code ? m->d_stream_cwin : nullptr;
         static const bool l8_off = getenv("SMH_STREAM_L8") && atoi(getenv("SMH_STREAM_L8")) == 0;  // tuning knob
         if (c->cwin && !l8_off) { c->len8 = m->d_stream_len8; c->tbase = m->d_stream_tbase; }
-        // K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip) is an experiment kept behind a knob: on the
-        // 512^3 Laplacian it measured 1.86 ms against K1s's 1.55 ms (profiles/r02_k1s_pipe_ab.log)
+        // K1s-p (persistent blocks, several tiles in flight; spmv_stream_pipe.hip) is an experiment kept behind a knob: on the
+        // 512^3 Laplacian it measured 1.86-2.01 ms against K1s's 1.50-1.55 ms (profiles/r02_k1s_pipe_ab.log)
         static const bool pipe_on = getenv("SMH_STREAM_PIPE") && atoi(getenv("SMH_STREAM_PIPE")) == 1;
         static const bool small_off = getenv("SMH_STREAM_SMALL") && atoi(getenv("SMH_STREAM_SMALL")) == 0;  // tuning knob
         c->small = !small_off && m->have_stats && m->max_tile_entries <= (uint32_t)kStreamCapSmall;

@@ -1,21 +1,23 @@
-// spmv_stream_pipe.hip -- K1s-p: the CSR-stream kernel for stencil-like matrices on PERSISTENT blocks with a three-deep
-// software pipeline (gfx950).
+// spmv_stream_pipe.hip -- K1s-p: the CSR-stream kernel for stencil-like matrices on PERSISTENT blocks with a software pipeline
+// over tiles (gfx950).  AN EXPERIMENT THAT LOST, kept behind SMH_STREAM_PIPE=1 ("K1s-p").
 //
 // Same product, same arithmetic, same order as K1s (spmv_stream.hip) -- the rounded products of a 256-row tile parked in
 // LDS, thread r folding row r sequentially in storage order: bit-exact against the reference loop
 // (sparsematrix.rs:146-158) -- for the case K1s serves with 16-bit column codes and byte row lengths (every tile's columns
-// in <= 4 intervals, no row above 255 entries) and at most 2048 entries per tile (5-, 7-point stencils; 256 rows x 8).
-// Why: K1s is latency-bound, not stream-bound (profiles/r01_k1s_blocks_per_cu.log: every block taken away costs) -- a
-// block walks tile start -> chunk loads -> gathers -> LDS -> fold with three dependent trips to memory and nothing of its
-// own in flight meanwhile; on the 512^3 Laplacian it moves 7.2 GB at 4.6 TB/s.  Here a block owns a contiguous run of
-// tiles and keeps three of them in flight, each step of the loop doing, in program order (vmcnt retires in order, so the
-// compiler's counted waits leave the younger loads in flight):
-//     gathers of tile t+1   (its chunks were requested two steps ago)
-//     products of tile t    (its gathers were requested one step ago) -> LDS, barrier, fold, store
-//     chunk loads of tile t+3 into the registers tile t just freed
+// in <= 4 intervals, no row above 255 entries) and at most 2045 entries per tile (5-, 7-point stencils).
+// The idea: a K1s block walks tile start -> chunk loads -> gathers -> LDS -> fold with three dependent trips to memory and
+// nothing of its own in flight meanwhile.  Here a block owns a contiguous run of tiles and keeps five of them in flight,
+// each step of the loop doing, in program order (vmcnt retires in order, so the compiler's counted waits leave the younger
+// loads in flight):
+//     gathers of tile t+2   (its chunks were requested three steps ago)
+//     products of tile t    (its gathers were requested two steps ago) -> LDS, barrier, fold, store
+//     chunk loads of tile t+5 into the registers tile t just freed
 // All loads are unconditional (addresses clamped, entries masked afterwards) so the loop body is straight-line code.  The
 // LDS stage is double-buffered: one barrier per tile.  With the p.Ap / inner_prod epilogue every thread accumulates
 // lhs[row] * y[row] over its tiles and the block leaves ONE partial sum (fixed order: bitwise reproducible).
+// Measured on the 512^3 Laplacian: 1.86 ms with three sets (97 VGPRs), 2.01 ms with these five (132 VGPRs), K1s 1.50-1.55 ms;
+// the time per tile and CU does not change with the number of resident blocks -- the texture addresser, busy 70 % under K1s
+// already, is the bound, and it has the same eight gather instructions per thread and tile to process here.
 #include "internal.hpp"
 
 namespace smh {
@@ -143,8 +145,8 @@ k_spmv_stream_pipe(const T *__restrict__ val, const T *__restrict__ x, T *__rest
         pipe_gather<T>(S0, x, s_cw, 0u, tid);
         pipe_gather<T>(S1, x, s_cw, 0u, tid);
         uint32_t buf = 0;
-        // one step: gathers of the NEXT tile, then products / fold / store of the CURRENT one, then the chunk loads of the
-        // tile three ahead into the set just freed.  Unrolled by three so that the sets keep static names.
+        // one step: gathers of the tile two ahead, then products / fold / store of the CURRENT one, then the chunk loads of the
+        // tile five ahead into the set just freed.  Unrolled by five so that the sets keep static names.
 #define SMH_PIPE_STEP(CUR, GSET, T_CUR)                                                                               \
     do {                                                                                                              \
         if ((T_CUR) + 7 > wf + kPipeWin) { /* the window runs out: refill it from the current tile on (block-uniform) */    \
