@@ -537,6 +537,17 @@ static int ensure_stream_codes(smh_crs *m) {
         SMH_HIP(hipMalloc((void **)&m->d_stream_len8, n_tiles * kStreamRows));
         SMH_HIP(hipMalloc((void **)&m->d_stream_tbase, (n_tiles + 1) * sizeof(uint32_t)));
         SMH_TRY(launch_stream_len8(m->d_off, m->n_rows, m->d_stream_len8, m->d_stream_tbase, m->stream));
+        // how much of x a tile's intervals span (decides whether the body that stages x in LDS applies)
+        uint32_t *d_xs = nullptr, h_xs[2] = {0xFFFFFFFFu, 0};
+        SMH_HIP(hipMalloc((void **)&d_xs, 2 * sizeof(uint32_t)));
+        int rc2 = launch_stream_xs_stats(m->d_stream_cwin, n_tiles, d_xs, m->stream);
+        hipError_t e2 = rc2 == SMH_OK ? hipMemcpyAsync(h_xs, d_xs, sizeof h_xs, hipMemcpyDeviceToHost, m->stream) : hipSuccess;
+        if (rc2 == SMH_OK && e2 == hipSuccess) e2 = hipStreamSynchronize(m->stream);
+        (void)hipFree(d_xs);
+        SMH_TRY(rc2);
+        if (e2 != hipSuccess) return hip_fail(e2, "stream window statistics", __FILE__, __LINE__);
+        m->stream_xs_chunks = h_xs[0];
+        m->stream_xs_end = h_xs[1];
     }
     SMH_HIP(hipStreamSynchronize(m->stream));
     return SMH_OK;
@@ -604,6 +615,7 @@ struct StreamCfg {
     const uint32_t *tbase = nullptr;
     bool pipe = false;  // K1s-p: persistent blocks, three tiles in flight
     bool small = false; // no tile beyond kStreamCapSmall entries: the two-chunk body
+    bool xs = false;    // ... and every tile's column intervals fit the LDS stage of x
 };
 static int stream_cfg(smh_crs *m, StreamCfg *c) {
     *c = StreamCfg();
@@ -632,6 +644,8 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         static const bool pipe_on = getenv("SMH_STREAM_PIPE") && atoi(getenv("SMH_STREAM_PIPE")) == 1;
         static const bool small_off = getenv("SMH_STREAM_SMALL") && atoi(getenv("SMH_STREAM_SMALL")) == 0;  // tuning knob
         c->small = !small_off && m->have_stats && m->max_tile_entries <= (uint32_t)kStreamCapSmall;
+        static const bool xs_off = getenv("SMH_STREAM_XS") && atoi(getenv("SMH_STREAM_XS")) == 0;  // tuning knob
+        c->xs = !xs_off && c->small && c->len8 && m->stream_xs_chunks <= (uint32_t)(kStreamXsPer * kBlock);
         c->pipe = pipe_on && c->cwin && c->len8 && c->tbase && m->max_tile_entries <= stream_pipe_cap() && (m->owns || m->nnz % 4 == 0);
     }
     return SMH_OK;
@@ -676,7 +690,8 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
                 return launch_spmv_stream_pipe(m->dtype, m->d_val, x, y, m->n_rows, m->nnz, dot_partials, c.code, c.cwin, c.len8, c.tbase,
                                                dot_lhs, m->device, s);
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt,
-                                      c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small);
+                                      c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
+                                      c.xs && x_len >= (size_t)m->stream_xs_end && (reinterpret_cast<uintptr_t>(x) & 15u) == 0);
         }
         case SMH_SPMV_COLSPLIT: {
             SMH_TRY(ensure_split(m));

@@ -191,7 +191,8 @@ __device__ __forceinline__ uint32_t decode_col(uint32_t cd, uint32_t b0, uint32_
 // one u32 per tile (where its entries start) instead of the u32 offset_rows stream -- 1 instead of 4 bytes per row from HBM
 // (512^3 Laplacian: 537 -> 136 MB of the 7.2 GB a product moves).  The in-tile prefix sum of the lengths is a wave scan
 // whose cross-wave part rides on the barrier the kernel has anyway.
-template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false, bool L8 = false>
+template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false, bool L8 = false,
+          bool XS = false>
 __global__ void SMH_STREAM_BOUNDS
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
@@ -200,6 +201,11 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
               const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs) {
     static_assert(!C16 || (RPT == 1 && !XWIN), "the code table describes 256-row tiles");
     static_assert(!L8 || (C16 && !MULTI), "row lengths as bytes: single-pass 256-row tiles with column codes");
+    static_assert(!XS || (L8 && !XWIN), "x staged in LDS: the coded single-pass body");
+    // XS: the tile's column intervals of x (the code table's <= 4 intervals, <= kStreamXsCap entries in 16-byte chunks) are
+    // copied to LDS with 16-byte loads issued BEFORE the tile's chunk loads, and the gathers become LDS reads: two vector-memory
+    // instructions per thread instead of eight, and no second, dependent trip to memory.
+    __shared__ __attribute__((aligned(16))) T s_xs[XS ? kStreamXsCap : 4];
     __shared__ uint32_t s_wtot[L8 ? kBlock / kWave : 1];
     __shared__ T s_prod[CAP + CAP / 32 + 8];
     __shared__ T s_x[XWIN ? kStreamXWin : 1];
@@ -283,6 +289,37 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         const uint32_t *w = cwin + 8 * tile;  // scalar loads
         cb0 = w[0]; cb1 = w[2]; cb2 = w[4]; cb3 = w[6];
     }
+    uint32_t sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;  // XS: where column cb_q sits in s_xs
+    T xr[XS ? kStreamXsPer : 1][4];
+    uint32_t xs_tot = 0;
+    if constexpr (XS) {
+        const uint32_t *w = cwin + 8 * tile;  // scalar loads (the starts are cb0..cb3 already)
+        const uint32_t e0 = w[1], e1 = w[3], e2 = w[5], e3 = w[7];
+        const uint32_t al0 = cb0 & ~3u, al1 = cb1 & ~3u, al2 = cb2 & ~3u, al3 = cb3 & ~3u;
+        const uint32_t n0 = e0 > cb0 ? (e0 - al0 + 3u) >> 2 : 0u, n1 = e1 > cb1 ? (e1 - al1 + 3u) >> 2 : 0u;
+        const uint32_t n2 = e2 > cb2 ? (e2 - al2 + 3u) >> 2 : 0u, n3 = e3 > cb3 ? (e3 - al3 + 3u) >> 2 : 0u;
+        const uint32_t p1 = n0, p2 = p1 + n1, p3 = p2 + n2;
+        xs_tot = p3 + n3;  // (<= kStreamXsPer * kBlock chunks and inside x: checked by the host, smh_crs::stream_xs_*)
+        sb0 = cb0 & 3u; sb1 = 4u * p1 + (cb1 & 3u); sb2 = 4u * p2 + (cb2 & 3u); sb3 = 4u * p3 + (cb3 & 3u);
+#pragma unroll
+        for (int u = 0; u < kStreamXsPer; ++u) {
+            const uint32_t j = tid + (uint32_t)u * kBlock;
+            xr[u][0] = xr[u][1] = xr[u][2] = xr[u][3] = T(0);
+            if (j < xs_tot) {
+                const uint32_t q = (uint32_t)(j >= p1) + (uint32_t)(j >= p2) + (uint32_t)(j >= p3);
+                const uint32_t pq = q == 0u ? 0u : q == 1u ? p1 : q == 2u ? p2 : p3;
+                const uint32_t al = q == 0u ? al0 : q == 1u ? al1 : q == 2u ? al2 : al3;
+                const T *g = x + ((uint64_t)al + 4u * (j - pq));
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(g);
+                    xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = a.z; xr[u][3] = a.w;
+                } else {
+                    const f64x2 a = *reinterpret_cast<const f64x2 *>(g), b = *reinterpret_cast<const f64x2 *>(g + 2);
+                    xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = b.x; xr[u][3] = b.y;
+                }
+            }
+        }
+    }
     uint32_t ps = k0;
     do {
         const uint32_t pe = MULTI && k1 - ps > (uint32_t)CAP ? ps + (uint32_t)CAP : k1;
@@ -330,6 +367,17 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
                 }
             }
         }
+        if constexpr (XS) {  // (the x chunks were requested before the tile's own: they are here first)
+#pragma unroll
+            for (int u = 0; u < kStreamXsPer; ++u) {
+                const uint32_t j = tid + (uint32_t)u * kBlock;
+                if (j < xs_tot) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s_xs[4u * j + e] = xr[u][e];
+                }
+            }
+            __syncthreads();
+        }
         T xv[NIT][4];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -345,7 +393,8 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
                         xv[it][e] = s_x[cc - sh];
                     } else if constexpr (C16) {
                         const uint32_t cd = (e & 1) ? (c[it][e >> 1] >> 16) : (c[it][e >> 1] & 0xFFFFu);
-                        xv[it][e] = x[decode_col(cd, cb0, cb1, cb2, cb3)];
+                        if constexpr (XS) xv[it][e] = s_xs[decode_col(cd, sb0, sb1, sb2, sb3)];
+                        else xv[it][e] = x[decode_col(cd, cb0, cb1, cb2, cb3)];
                     } else {
                         xv[it][e] = x[c[it][e]];
                     }
@@ -425,7 +474,7 @@ template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
                            size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
                            const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs,
-                           hipStream_t s, bool small_tiles) {
+                           hipStream_t s, bool small_tiles, bool xs) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
@@ -448,6 +497,14 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     } while (0)
     if (win) SMH_ST_PICK(true, 1, false);  // the window table describes 256-row tiles
     else if (rpt == 2) SMH_ST_PICK(false, 2, false);
+    else if (code && cwin && len8 && tbase && single_pass && small_tiles && xs) {  // ... and x staged in LDS
+        if (dot_partials)
+            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCapSmall, true, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+        else
+            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCapSmall, true, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+    }
     else if (code && cwin && len8 && tbase && single_pass && small_tiles) {
         // ... and no tile beyond kStreamCapSmall entries (stencils: 7 x 256 = 1792): two chunk slots per thread instead of five.
         // 32-34 VGPRs instead of 67-70 (f32), 46-50 instead of ~106 (f64: 4 -> 8 waves per SIMD).  Measured, one box: 400^3 f64
@@ -527,15 +584,15 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
                        void *dot_partials, const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase,
-                       const void *dot_lhs, hipStream_t s, bool small_tiles) {
+                       const void *dot_lhs, hipStream_t s, bool small_tiles, bool xs) {
     if (n_rows == 0) return SMH_OK;
     if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
     if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
     if (dtype == SMH_F64)
         return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
-                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s, small_tiles);
+                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s, small_tiles, xs);
     return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
-                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s, small_tiles);
+                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s, small_tiles, xs);
 }
 
 // row lengths as bytes (rows padded to whole 256-row tiles with zeros) and the tiles' first entries (n_tiles + 1 values);
@@ -620,6 +677,43 @@ int launch_stream_codes(const uint32_t *off, const uint32_t *col, const uint32_t
     if (n_tiles == 0) return SMH_OK;
     const uint64_t blocks = n_tiles < 16384 ? n_tiles : 16384;
     hipLaunchKernelGGL(k_stream_codes, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, win, (uint64_t)n_rows, n_tiles, code);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+// XS eligibility: out[0] = most 16-byte chunks any tile's column intervals need (from aligned starts), out[1] = the largest
+// x index + 1 those chunks touch
+__global__ void __launch_bounds__(kBlock)
+k_stream_xs_stats(const uint32_t *__restrict__ win, uint64_t n_tiles, uint32_t *__restrict__ out) {
+    uint32_t mc = 0, me = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t *w = win + 8 * t;
+        uint32_t chunks = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t a = w[2 * q], e = w[2 * q + 1];
+            if (e > a) {
+                const uint32_t al = a & ~3u, n = (e - al + 3u) >> 2;
+                chunks += n;
+                me = max(me, al + 4u * n);
+            }
+        }
+        mc = max(mc, chunks);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mc = max(mc, (uint32_t)__shfl_down(mc, o, kWave));
+        me = max(me, (uint32_t)__shfl_down(me, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicMax(&out[0], mc); atomicMax(&out[1], me); }
+}
+
+int launch_stream_xs_stats(const uint32_t *win, size_t n_tiles, uint32_t *d_out2, hipStream_t s) {
+    SMH_HIP(hipMemsetAsync(d_out2, 0, 2 * sizeof(uint32_t), s));
+    if (n_tiles == 0) return SMH_OK;
+    uint64_t blocks = (n_tiles + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_stream_xs_stats, dim3((unsigned)blocks), dim3(kBlock), 0, s, win, (uint64_t)n_tiles, d_out2);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
