@@ -378,9 +378,28 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             }
             __syncthreads();
         }
+        if constexpr (XS) {
+            // branch-free: every slot reads some x from the LDS stage (codes of slots outside the tile decode to a clamped index)
+            // and writes its product -- to its place in the stage, or to a dump slot past the stage's end.  (The guarded form
+            // below costs a compare pair, an exec save / restore and a branch per slot; this body is VALU-bound.)
+            constexpr uint32_t kDump = (uint32_t)(CAP + CAP / 32 + 7);
+            const uint32_t span = hi - lo;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t cd = (e & 1) ? (c[it][e >> 1] >> 16) : (c[it][e >> 1] & 0xFFFFu);
+                    const uint32_t idx = decode_col(cd, sb0, sb1, sb2, sb3);
+                    const T xe = s_xs[idx < (uint32_t)kStreamXsCap ? idx : 0u];
+                    const uint32_t rel = j + (uint32_t)e - lo;  // (wraps below lo: fails the test too)
+                    s_prod[rel < span ? skew(rel) : kDump] = st_mul(xe, v[it][e]);
+                }
+            }
+        }
         T xv[NIT][4];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; !XS && it < NIT; ++it) {
             const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -402,7 +421,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             }
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; !XS && it < NIT; ++it) {
             const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ / LDS counters of K1s against K1s-p on the 512^3 Laplacian (one pass per counter group and kernel choice; no tracing)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for P in 0 1; do
+for P in 0; do
   i=0
   for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES" \
            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM" \
@@ -14,7 +14,7 @@ for P in 0 1; do
 done
 python3 - <<'PY' > gpurun_out/pmc_pipe_summary.txt
 import csv, glob, collections
-for P in (0, 1):
+for P in (0,):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("gpurun_out/pp_%d_*/**/*counter_collection.csv" % P, recursive=True):
         for r in csv.DictReader(open(f)):
