@@ -384,14 +384,17 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             // below costs a compare pair, an exec save / restore and a branch per slot; this body is VALU-bound.)
             constexpr uint32_t kDump = (uint32_t)(CAP + CAP / 32 + 7);
             const uint32_t span = hi - lo;
+            // the four interval offsets (< 2^12 each) in one 64-bit word: one shift selects where a compare / select chain of six did
+            const uint64_t sbp = (uint64_t)sb0 | ((uint64_t)sb1 << 16) | ((uint64_t)sb2 << 32) | ((uint64_t)sb3 << 48);
+            static_assert((kStreamXsCap & (kStreamXsCap - 1)) == 0, "the stage index is clamped with a mask");
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t cd = (e & 1) ? (c[it][e >> 1] >> 16) : (c[it][e >> 1] & 0xFFFFu);
-                    const uint32_t idx = decode_col(cd, sb0, sb1, sb2, sb3);
-                    const T xe = s_xs[idx < (uint32_t)kStreamXsCap ? idx : 0u];
+                    const uint32_t idx = ((uint32_t)(sbp >> ((cd >> 14) << 4)) & 0xFFFFu) + (cd & 16383u);
+                    const T xe = s_xs[idx & (uint32_t)(kStreamXsCap - 1)];  // (slots outside the tile carry other tiles' codes)
                     const uint32_t rel = j + (uint32_t)e - lo;  // (wraps below lo: fails the test too)
                     s_prod[rel < span ? skew(rel) : kDump] = st_mul(xe, v[it][e]);
                 }
