@@ -615,7 +615,7 @@ struct StreamCfg {
     const uint32_t *tbase = nullptr;
     bool pipe = false;  // K1s-p: persistent blocks, three tiles in flight
     bool small = false; // no tile beyond kStreamCapSmall entries: the two-chunk body
-    bool xs = false;    // ... and every tile's column intervals fit the LDS stage of x
+    int xs = 0;         // ... and every tile's column intervals fit an LDS stage of x: 16-byte chunks per thread (2 or 4), 0 = no
 };
 static int stream_cfg(smh_crs *m, StreamCfg *c) {
     *c = StreamCfg();
@@ -645,7 +645,13 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         static const bool small_off = getenv("SMH_STREAM_SMALL") && atoi(getenv("SMH_STREAM_SMALL")) == 0;  // tuning knob
         c->small = !small_off && m->have_stats && m->max_tile_entries <= (uint32_t)kStreamCapSmall;
         static const bool xs_off = getenv("SMH_STREAM_XS") && atoi(getenv("SMH_STREAM_XS")) == 0;  // tuning knob
-        c->xs = !xs_off && c->small && c->len8 && m->stream_xs_chunks <= (uint32_t)(kStreamXsPer * kBlock);
+        // worth it once x is beyond the L2s (the 1000^2 Laplacian, x = 4 MB, loses 5-20 % to the extra barrier); the 4096-entry
+        // stage pays on f32 only (grid planes 1024 wide: 1.618 -> 1.564 ms; f64, LDS-limited to three blocks per CU, 1.399 -> 1.549)
+        const bool forced = m->use_stream_xs == 1;
+        const bool x_large = forced || m->n_cols * dtype_size(m->dtype) >= ((size_t)32 << 20);
+        c->xs = (xs_off || m->use_stream_xs == 0 || !c->small || !c->len8 || !x_large) ? 0
+                : m->stream_xs_chunks <= 2u * kBlock ? 2
+                : (m->stream_xs_chunks <= 4u * kBlock && (forced || m->dtype == SMH_F32)) ? 4 : 0;
         c->pipe = pipe_on && c->cwin && c->len8 && c->tbase && m->max_tile_entries <= stream_pipe_cap() && (m->owns || m->nnz % 4 == 0);
     }
     return SMH_OK;
@@ -691,7 +697,7 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
                                                dot_lhs, m->device, s);
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt,
                                       c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
-                                      c.xs && x_len >= (size_t)m->stream_xs_end && (reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+                                      (x_len >= (size_t)m->stream_xs_end && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0);
         }
         case SMH_SPMV_COLSPLIT: {
             SMH_TRY(ensure_split(m));
@@ -1294,6 +1300,24 @@ int smh_crs_stream_windows(smh_crs *m, double *fraction_out, uint32_t *table_out
     const size_t n_tiles = (m->n_rows + kStreamRows - 1) / kStreamRows;
     if (table_out && n_tiles)
         SMH_HIP(hipMemcpy(table_out, m->d_stream_win, n_tiles * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SMH_OK;
+}
+
+int smh_crs_set_stream_xs(smh_crs *m, int mode) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic), 0 (never) or 1 (whenever the tiles allow)");
+    m->use_stream_xs = mode;
+    return SMH_OK;
+}
+
+int smh_crs_stream_layout(smh_crs *m, int *coded_out, int *byte_lengths_out, int *small_tiles_out, int *xs_chunks_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    StreamCfg c;
+    SMH_TRY(stream_cfg(m, &c));
+    if (coded_out) *coded_out = c.code && c.cwin;
+    if (byte_lengths_out) *byte_lengths_out = c.len8 && c.tbase;
+    if (small_tiles_out) *small_tiles_out = c.small;
+    if (xs_chunks_out) *xs_chunks_out = c.xs;
     return SMH_OK;
 }
 

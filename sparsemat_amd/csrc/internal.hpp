@@ -42,8 +42,6 @@ constexpr int kRingEntries = 16384;    // K1r: columns of x the LDS ring holds (
 constexpr int kRingEntriesWide = 32768;  // ... f32 only, for rows that need it: 128 KiB, one 1024-thread block per CU
 constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
 constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
-constexpr int kStreamXsPer = 2;         // K1s XS: 16-byte chunks of x per thread and tile
-constexpr int kStreamXsCap = kStreamXsPer * kBlock * 4;  // ... = entries of x staged in LDS (2048)
 constexpr int kStreamCapSmall = 2045;  // K1s: ... when no tile holds more (two 16-byte chunks per thread from an aligned start)
 constexpr int kStreamXWin = 3072;      // K1s-w: x entries of a tile's column intervals staged in LDS
 constexpr int kStreamCodeWidth = 16384;  // K1s 16-bit column codes: columns per interval (14 bits) x 4 intervals
@@ -69,7 +67,7 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
                        const uint8_t *len8, const uint32_t *tbase /* optional (with codes): byte row lengths + tile starts */,
                        const void *dot_lhs /* with dot_partials: the vector dotted with y (NULL: x); y may then be NULL */,
                        hipStream_t s, bool small_tiles = false /* no tile holds more than kStreamCapSmall entries */,
-                       bool xs = false /* ... and the tiles' column intervals fit the LDS stage of x (stream_xs_* checked by the caller) */);
+                       int xs = 0 /* ... and the tiles' column intervals fit an LDS stage of x of xs * 1024 entries (2 or 4; stream_xs_* checked by the caller) */);
 int launch_stream_xs_stats(const uint32_t *win, size_t n_tiles, uint32_t *d_out2, hipStream_t s);
 int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
 // K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip)
@@ -247,6 +245,7 @@ struct smh_crs {
     uint32_t *d_phase_ptr = nullptr;
     smh::RingPhase *d_phases = nullptr;
     int use_ring = -1;  // -1 automatic, 0 never, 1 always (when lanes <= 8), 2 always with the first K1r body
+    int use_stream_xs = -1;  // K1s XS: -1 automatic (x beyond the L2s; the 4096-entry stage on f32 only), 0 never, 1 whenever the tiles allow
     uint32_t stream_xs_chunks = 0xFFFFFFFFu, stream_xs_end = 0;  // K1s XS: most x chunks a tile needs; largest x index + 1 they touch
     uint16_t *d_col16 = nullptr;  // K1r: 16-bit column array for the ring phases (lazy; null: not used)
     int use_col16 = -1;           // -1 automatic (when at least a quarter of the rows are ring rows), 0 never, 1 always

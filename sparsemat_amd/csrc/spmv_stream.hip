@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t decode_col(uint32_t cd, uint32_t b0, uint32_
 // (512^3 Laplacian: 537 -> 136 MB of the 7.2 GB a product moves).  The in-tile prefix sum of the lengths is a wave scan
 // whose cross-wave part rides on the barrier the kernel has anyway.
 template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false, bool L8 = false,
-          bool XS = false>
+          int XS = 0 /* 16-byte chunks of x per thread staged in LDS: 0 (none), 2 or 4 */>
 __global__ void SMH_STREAM_BOUNDS
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
@@ -202,10 +202,11 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     static_assert(!C16 || (RPT == 1 && !XWIN), "the code table describes 256-row tiles");
     static_assert(!L8 || (C16 && !MULTI), "row lengths as bytes: single-pass 256-row tiles with column codes");
     static_assert(!XS || (L8 && !XWIN), "x staged in LDS: the coded single-pass body");
-    // XS: the tile's column intervals of x (the code table's <= 4 intervals, <= kStreamXsCap entries in 16-byte chunks) are
+    // XS: the tile's column intervals of x (the code table's <= 4 intervals, <= 2048 or 4096 entries in 16-byte chunks) are
     // copied to LDS with 16-byte loads issued BEFORE the tile's chunk loads, and the gathers become LDS reads: two vector-memory
     // instructions per thread instead of eight, and no second, dependent trip to memory.
-    __shared__ __attribute__((aligned(16))) T s_xs[XS ? kStreamXsCap : 4];
+    constexpr int kXsCap = XS ? XS * kBlock * 4 : 4;  // entries of x the stage holds (2048 / 4096)
+    __shared__ __attribute__((aligned(16))) T s_xs[kXsCap];
     __shared__ uint32_t s_wtot[L8 ? kBlock / kWave : 1];
     __shared__ T s_prod[CAP + CAP / 32 + 8];
     __shared__ T s_x[XWIN ? kStreamXWin : 1];
@@ -290,7 +291,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         cb0 = w[0]; cb1 = w[2]; cb2 = w[4]; cb3 = w[6];
     }
     uint32_t sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;  // XS: where column cb_q sits in s_xs
-    T xr[XS ? kStreamXsPer : 1][4];
+    T xr[XS ? XS : 1][4];
     uint32_t xs_tot = 0;
     if constexpr (XS) {
         const uint32_t *w = cwin + 8 * tile;  // scalar loads (the starts are cb0..cb3 already)
@@ -299,10 +300,10 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         const uint32_t n0 = e0 > cb0 ? (e0 - al0 + 3u) >> 2 : 0u, n1 = e1 > cb1 ? (e1 - al1 + 3u) >> 2 : 0u;
         const uint32_t n2 = e2 > cb2 ? (e2 - al2 + 3u) >> 2 : 0u, n3 = e3 > cb3 ? (e3 - al3 + 3u) >> 2 : 0u;
         const uint32_t p1 = n0, p2 = p1 + n1, p3 = p2 + n2;
-        xs_tot = p3 + n3;  // (<= kStreamXsPer * kBlock chunks and inside x: checked by the host, smh_crs::stream_xs_*)
+        xs_tot = p3 + n3;  // (<= XS * kBlock chunks and inside x: checked by the host, smh_crs::stream_xs_*)
         sb0 = cb0 & 3u; sb1 = 4u * p1 + (cb1 & 3u); sb2 = 4u * p2 + (cb2 & 3u); sb3 = 4u * p3 + (cb3 & 3u);
 #pragma unroll
-        for (int u = 0; u < kStreamXsPer; ++u) {
+        for (int u = 0; u < XS; ++u) {
             const uint32_t j = tid + (uint32_t)u * kBlock;
             xr[u][0] = xr[u][1] = xr[u][2] = xr[u][3] = T(0);
             if (j < xs_tot) {
@@ -369,7 +370,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         }
         if constexpr (XS) {  // (the x chunks were requested before the tile's own: they are here first)
 #pragma unroll
-            for (int u = 0; u < kStreamXsPer; ++u) {
+            for (int u = 0; u < XS; ++u) {
                 const uint32_t j = tid + (uint32_t)u * kBlock;
                 if (j < xs_tot) {
 #pragma unroll
@@ -386,7 +387,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             const uint32_t span = hi - lo;
             // the four interval offsets (< 2^12 each) in one 64-bit word: one shift selects where a compare / select chain of six did
             const uint64_t sbp = (uint64_t)sb0 | ((uint64_t)sb1 << 16) | ((uint64_t)sb2 << 32) | ((uint64_t)sb3 << 48);
-            static_assert((kStreamXsCap & (kStreamXsCap - 1)) == 0, "the stage index is clamped with a mask");
+            static_assert((kXsCap & (kXsCap - 1)) == 0, "the stage index is clamped with a mask");
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
@@ -394,7 +395,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t cd = (e & 1) ? (c[it][e >> 1] >> 16) : (c[it][e >> 1] & 0xFFFFu);
                     const uint32_t idx = ((uint32_t)(sbp >> ((cd >> 14) << 4)) & 0xFFFFu) + (cd & 16383u);
-                    const T xe = s_xs[idx & (uint32_t)(kStreamXsCap - 1)];  // (slots outside the tile carry other tiles' codes)
+                    const T xe = s_xs[idx & (uint32_t)(kXsCap - 1)];  // (slots outside the tile carry other tiles' codes)
                     const uint32_t rel = j + (uint32_t)e - lo;  // (wraps below lo: fails the test too)
                     s_prod[rel < span ? skew(rel) : kDump] = st_mul(xe, v[it][e]);
                 }
@@ -496,7 +497,7 @@ template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
                            size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
                            const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs,
-                           hipStream_t s, bool small_tiles, bool xs) {
+                           hipStream_t s, bool small_tiles, int xs) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
     const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
@@ -519,14 +520,16 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     } while (0)
     if (win) SMH_ST_PICK(true, 1, false);  // the window table describes 256-row tiles
     else if (rpt == 2) SMH_ST_PICK(false, 2, false);
-    else if (code && cwin && len8 && tbase && single_pass && small_tiles && xs) {  // ... and x staged in LDS
-        if (dot_partials)
-            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCapSmall, true, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
-        else
-            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCapSmall, true, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+#define SMH_ST_XS(D, P)                                                                                                                     \
+    hipLaunchKernelGGL((k_spmv_stream<T, false, 1, D, false, false, kStreamCapSmall, true, true, P>), grid, block, lds_pad, s, off, col, val, x, y, \
+                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs)
+    else if (code && cwin && len8 && tbase && single_pass && small_tiles && xs == 2) {  // ... and x staged in LDS (2048 entries)
+        if (dot_partials) SMH_ST_XS(true, 2); else SMH_ST_XS(false, 2);
     }
+    else if (code && cwin && len8 && tbase && single_pass && small_tiles && xs == 4) {  // ... (4096 entries: wider grids)
+        if (dot_partials) SMH_ST_XS(true, 4); else SMH_ST_XS(false, 4);
+    }
+#undef SMH_ST_XS
     else if (code && cwin && len8 && tbase && single_pass && small_tiles) {
         // ... and no tile beyond kStreamCapSmall entries (stencils: 7 x 256 = 1792): two chunk slots per thread instead of five.
         // 32-34 VGPRs instead of 67-70 (f32), 46-50 instead of ~106 (f64: 4 -> 8 waves per SIMD).  Measured, one box: 400^3 f64
@@ -606,7 +609,7 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
                        void *dot_partials, const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase,
-                       const void *dot_lhs, hipStream_t s, bool small_tiles, bool xs) {
+                       const void *dot_lhs, hipStream_t s, bool small_tiles, int xs) {
     if (n_rows == 0) return SMH_OK;
     if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
     if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");

@@ -276,6 +276,16 @@ class SparseMatCRS:
         """K1s-w (x intervals of a tile staged in LDS): -1 automatic, 0 off, 1 on."""
         check(lib().smh_crs_set_stream_windows(self._h, mode))
 
+    def set_stream_xs(self, mode):
+        """K1s XS (the tile's column intervals of x staged in LDS): -1 automatic, 0 never, 1 whenever the tiles allow."""
+        check(lib().smh_crs_set_stream_xs(self._h, mode))
+
+    def stream_layout(self):
+        """What a STREAM launch of this matrix uses: dict(coded, byte_lengths, small_tiles, xs_chunks)."""
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().smh_crs_stream_layout(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"coded": bool(a.value), "byte_lengths": bool(b.value), "small_tiles": bool(c.value), "xs_chunks": d.value}
+
     def stream_windows(self):
         """(fraction of tiles with a window, table[n_tiles, 4, 2] of [lo, hi) intervals)."""
         frac = C.c_double()

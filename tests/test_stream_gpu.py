@@ -204,3 +204,57 @@ def test_stream_16bit_column_codes_bit_exact(gpu, dtype):
     off, col, val = m.raw_parts()
     x = oracle.gen_x(synth.SEED_X, 11 * 7 * 5, np.float32)
     assert np.array_equal(bits(_with_codes("1", lambda: m.mvp(x, variant="stream"))), bits(oracle.spmv(off, col, val, x)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_stream_x_staged_in_lds_bit_exact(gpu, dtype):
+    """K1s XS: for coded single-pass tiles with byte row lengths whose column intervals span <= 2048 (or 4096) entries of x, the
+    intervals are copied to LDS with 16-byte loads and the gathers become LDS reads.  AUTO keeps that for x beyond the L2s, so
+    the small cases force it (set_stream_xs(1)); same bits as the oracle, as the kernel without the stage, and through the dot
+    epilogue; x that is too short for the last aligned chunk or not 16-byte aligned falls back to gathers from memory."""
+    rng = np.random.default_rng(99)
+    cases = []
+    for g in ((40, 40, 40), (300, 300, 1), (1000, 30, 3), (7, 5, 3), (257, 1, 1)):   # 3-D, 2-D, wide planes (4096-entry stage), tiny, 1-D
+        off, col, val = oracle.laplace3d(*g, dtype)
+        cases.append(("laplace %dx%dx%d" % g, g[0] * g[1] * g[2], off, col, val))
+    n = 50_001   # a narrow band stored in storage order with duplicates and empty rows
+    lens = rng.integers(0, 8, n)
+    lens[1000:1300] = 0
+    off = np.zeros(n + 1, np.uint32); np.cumsum(lens, out=off[1:])
+    centers = np.repeat(np.arange(n), lens)
+    col = np.clip(centers + rng.integers(-300, 300, len(centers)), 0, n - 1).astype(np.uint32)
+    cases.append(("band", n, off, col, rng.uniform(-1, 1, len(col)).astype(dtype)))
+    seen = set()
+    for name, n, off, col, val in cases:
+        x = rng.uniform(-1, 1, n).astype(dtype)
+        y_ref = oracle.spmv(off, col, val, x)
+        m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+        assert m.stream_layout()["xs_chunks"] == 0, name          # AUTO: x is far below 32 MB here
+        y_plain = m.mvp(x, variant="stream")
+        m.set_stream_xs(1)
+        lay = m.stream_layout()
+        assert lay["coded"] and lay["byte_lengths"] and lay["small_tiles"] and lay["xs_chunks"] in (2, 4), (name, lay)
+        seen.add(lay["xs_chunks"])
+        y_xs = m.mvp(x, variant="stream")
+        assert np.array_equal(bits(y_xs), bits(y_ref)) and np.array_equal(bits(y_plain), bits(y_ref)), name
+        # lhs^T A x through the epilogue of the staged kernel = through the plain one (same partial sums, same fold)
+        lhs = rng.uniform(-1, 1, n).astype(dtype)
+        ip_xs = m.inner_prod(lhs, x, variant="stream")
+        m.set_stream_xs(0)
+        assert m.stream_layout()["xs_chunks"] == 0 and m.inner_prod(lhs, x, variant="stream") == ip_xs, name
+        m.set_stream_xs(1)
+        # device vectors: x one entry longer than the matrix needs (aligned end inside), and a pointer that is not 16-byte aligned
+        xbuf = synth.DeviceBuffer((n + 9) * x.itemsize)
+        xbuf.upload(np.concatenate([np.zeros(1, dtype), x, np.zeros(8, dtype)]))
+        ybuf = synth.DeviceBuffer(n * x.itemsize)
+        m.mvp_dev(xbuf.ptr + x.itemsize, n, ybuf.ptr, "stream")   # misaligned x: the fallback
+        sm.lib().smh_device_synchronize()
+        assert np.array_equal(bits(ybuf.download(dtype, n)), bits(y_ref)), name
+    assert seen == {2, 4}   # both stage sizes ran
+    # a matrix whose tiles' intervals do not fit any stage keeps the gathers from memory
+    off, col, val = oracle.laplace3d(3000, 40, 1, dtype)   # rows 3000 apart: window 256 + 6000
+    m = sm.SparseMatCRS.from_raw_parts(120_000, 120_000, off, col, val)
+    m.set_stream_xs(1)
+    assert m.stream_layout()["xs_chunks"] == 0
+    x = rng.uniform(-1, 1, 120_000).astype(dtype)
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
