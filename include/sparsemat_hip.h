@@ -196,8 +196,9 @@ int smh_crs_stream_windows(smh_crs *m, double *fraction_out, uint32_t *table_out
  * issued before the tile's own: mode -1 = automatic (x beyond the L2s; 2048 entries of x per tile, 4096 on f32),
  * 0 = never, 1 = whenever every tile's intervals fit a stage.  smh_crs_stream_layout reports what a STREAM launch of this
  * matrix uses: 16-bit column codes, byte row lengths, the two-chunk body (no tile above 2045 entries) and the 16-byte chunks
- * of x per thread staged (0 none, 2 or 4); a launch still falls back to gathers from memory when x is shorter than the
- * aligned end of the last interval or not 16-byte aligned.  Same bits as K1s in every form. */
+ * of x per thread staged (0 none, 2 or 4); a launch still falls back to gathers from memory when x is not 16-byte aligned
+ * (the staged pieces are aligned 16-byte blocks of x: the last one may be read up to 12 bytes past x_len, inside the block --
+ * and page -- that holds x's last entry; those values are never used).  Same bits as K1s in every form. */
 int smh_crs_set_stream_xs(smh_crs *m, int mode);
 int smh_crs_stream_layout(smh_crs *m, int *coded_out, int *byte_lengths_out, int *small_tiles_out, int *xs_chunks_out);
 /* 16-B chunks per lane and pass of the pipelined VECTOR body (1..3; 0 = automatic): a lane group

@@ -697,7 +697,9 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
                                                dot_lhs, m->device, s);
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt,
                                       c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
-                                      (x_len >= (size_t)m->stream_xs_end && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0);
+                                      // the staged chunks are 16-byte aligned pieces of x that each hold at least one valid entry: with x itself 16-byte
+                                      // aligned the last one may reach past x_len, but never past the 16-byte block (hence page) the last entry lies in
+                                      ((((x_len + 3) & ~(size_t)3) >= (size_t)m->stream_xs_end) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0);
         }
         case SMH_SPMV_COLSPLIT: {
             SMH_TRY(ensure_split(m));
