@@ -645,13 +645,15 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         static const bool small_off = getenv("SMH_STREAM_SMALL") && atoi(getenv("SMH_STREAM_SMALL")) == 0;  // tuning knob
         c->small = !small_off && m->have_stats && m->max_tile_entries <= (uint32_t)kStreamCapSmall;
         static const bool xs_off = getenv("SMH_STREAM_XS") && atoi(getenv("SMH_STREAM_XS")) == 0;  // tuning knob
-        // worth it once x is beyond the L2s (the 1000^2 Laplacian, x = 4 MB, loses 5-20 % to the extra barrier); the 4096-entry
-        // stage pays on f32 only (grid planes 1024 wide: 1.618 -> 1.564 ms; f64, LDS-limited to three blocks per CU, 1.399 -> 1.549)
+        // worth it once x is beyond one L2 (the 1000^2 Laplacian, x = 4 MB, loses 5-20 % to the extra barrier with the 4096-entry
+        // stage); that stage pays on f32 only (grid planes 1024 wide: 1.618 -> 1.564 ms; f64, LDS-limited to three blocks per CU, 1.399 -> 1.549)
+        // (tools/dev/xs_threshold.py, cubes of 100..320: nothing at 4 MB of x -- launch-bound --, -9 .. -20 % from 8 MB on, both dtypes)
         const bool forced = m->use_stream_xs == 1;
-        const bool x_large = forced || m->n_cols * dtype_size(m->dtype) >= ((size_t)32 << 20);
-        c->xs = (xs_off || m->use_stream_xs == 0 || !c->small || !c->len8 || !x_large) ? 0
-                : m->stream_xs_chunks <= 2u * kBlock ? 2
-                : (m->stream_xs_chunks <= 4u * kBlock && (forced || m->dtype == SMH_F32)) ? 4 : 0;
+        const size_t x_bytes = m->n_cols * dtype_size(m->dtype);
+        const bool on2 = forced || x_bytes >= ((size_t)8 << 20), on4 = forced || (x_bytes >= ((size_t)32 << 20) && m->dtype == SMH_F32);
+        c->xs = (xs_off || m->use_stream_xs == 0 || !c->small || !c->len8) ? 0
+                : (m->stream_xs_chunks <= 2u * kBlock && on2) ? 2
+                : (m->stream_xs_chunks <= 4u * kBlock && on4) ? 4 : 0;
         c->pipe = pipe_on && c->cwin && c->len8 && c->tbase && m->max_tile_entries <= stream_pipe_cap() && (m->owns || m->nnz % 4 == 0);
     }
     return SMH_OK;

@@ -209,7 +209,7 @@ def test_stream_16bit_column_codes_bit_exact(gpu, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 def test_stream_x_staged_in_lds_bit_exact(gpu, dtype):
     """K1s XS: for coded single-pass tiles with byte row lengths whose column intervals span <= 2048 (or 4096) entries of x, the
-    intervals are copied to LDS with 16-byte loads and the gathers become LDS reads.  AUTO keeps that for x beyond the L2s, so
+    intervals are copied to LDS with 16-byte loads and the gathers become LDS reads.  AUTO keeps that for x of 8 MB and more, so
     the small cases force it (set_stream_xs(1)); same bits as the oracle, as the kernel without the stage, and through the dot
     epilogue; x that is too short for the last aligned chunk or not 16-byte aligned falls back to gathers from memory."""
     rng = np.random.default_rng(99)
@@ -229,7 +229,7 @@ def test_stream_x_staged_in_lds_bit_exact(gpu, dtype):
         x = rng.uniform(-1, 1, n).astype(dtype)
         y_ref = oracle.spmv(off, col, val, x)
         m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
-        assert m.stream_layout()["xs_chunks"] == 0, name          # AUTO: x is far below 32 MB here
+        assert m.stream_layout()["xs_chunks"] == 0, name          # AUTO: x is far below 8 MB here
         y_plain = m.mvp(x, variant="stream")
         m.set_stream_xs(1)
         lay = m.stream_layout()
