@@ -145,13 +145,13 @@ k_pcg_update(const PcgScalars<T> *__restrict__ sc, T *__restrict__ r, const T *_
     T s_rr = T(0), s_rz = T(0);
     const uint64_t nv = n / V, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = tid; q < nv; q += nthreads) {
-        VT rv = reinterpret_cast<const VT *>(r)[q];
-        const VT dv = reinterpret_cast<const VT *>(d)[q];
+        VT rv = __builtin_nontemporal_load(reinterpret_cast<const VT *>(r) + q);
+        const VT dv = __builtin_nontemporal_load(reinterpret_cast<const VT *>(d) + q);
         if (UPDATE) {
-            const VT av = reinterpret_cast<const VT *>(ap)[q];
+            const VT av = __builtin_nontemporal_load(reinterpret_cast<const VT *>(ap) + q);
 #pragma unroll
             for (int e = 0; e < V; ++e) rv[e] = p_add(rv[e], -p_mul(av[e], alpha));
-            reinterpret_cast<VT *>(r)[q] = rv;
+            __builtin_nontemporal_store(rv, reinterpret_cast<VT *>(r) + q);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -214,20 +214,20 @@ k_pcg_p(const PcgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__rest
     for (uint64_t q = tid; q < nv; q += nthreads) {
         VT pv;
         if (!FIRST) {
-            pv = reinterpret_cast<const VT *>(p)[q];
-            VT xv = reinterpret_cast<const VT *>(x)[q];
+            pv = __builtin_nontemporal_load(reinterpret_cast<const VT *>(p) + q);
+            VT xv = __builtin_nontemporal_load(reinterpret_cast<const VT *>(x) + q);
 #pragma unroll
             for (int e = 0; e < V; ++e) xv[e] = p_add(xv[e], p_mul(pv[e], alpha));
-            reinterpret_cast<VT *>(x)[q] = xv;
+            __builtin_nontemporal_store(xv, reinterpret_cast<VT *>(x) + q);
         }
         if (rebuild) {
-            const VT rv = reinterpret_cast<const VT *>(r)[q], dv = reinterpret_cast<const VT *>(d)[q];
+            const VT rv = __builtin_nontemporal_load(reinterpret_cast<const VT *>(r) + q), dv = __builtin_nontemporal_load(reinterpret_cast<const VT *>(d) + q);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const T z = p_div(rv[e], dv[e]);
                 pv[e] = FIRST ? z : p_add(p_mul(pv[e], beta), z);
             }
-            reinterpret_cast<VT *>(p)[q] = pv;
+            __builtin_nontemporal_store(pv, reinterpret_cast<VT *>(p) + q);
         }
     }
     for (uint64_t i = nv * V + tid; i < n; i += nthreads) {
