@@ -80,6 +80,8 @@ struct ParBlock {
     void *d_x = nullptr, *d_y = nullptr;
     // CG state (first solve)
     void *d_r = nullptr, *d_ap = nullptr, *d_partials = nullptr, *d_sc = nullptr;
+    void *d_dotp = nullptr;  // the SpMV's p.Ap partials (one per 256-row tile), folded by launch_fold2 through d_partials
+    size_t dotp_cap = 0;
     void *d_redv = nullptr;       // RCCL backend: 2 x n_blocks values (fold slots)
 };
 
@@ -401,6 +403,8 @@ int ensure_cg_state(smh_par *p) {
         SMH_HIP(hipMalloc(&blk.d_r, (n_loc ? n_loc : 1) * vs));
         SMH_HIP(hipMalloc(&blk.d_ap, (n_loc ? n_loc : 1) * vs));
         SMH_HIP(hipMalloc(&blk.d_partials, ((size_t)kReducePartials + 8) * vs));
+        blk.dotp_cap = (n_loc + 255) / 256 + 8;
+        SMH_HIP(hipMalloc(&blk.d_dotp, blk.dotp_cap * vs));
         SMH_HIP(hipMalloc(&blk.d_redv, 2 * p->n_blocks * vs));
         SMH_HIP(hipMemset(blk.d_redv, 0, 2 * p->n_blocks * vs));
         SMH_HIP(hipMalloc(&blk.d_sc, cg_scalars_bytes(p->dtype)));
@@ -747,7 +751,7 @@ int smh_par_destroy(smh_par *p) {
         if (blk.ev_red[1]) (void)hipEventDestroy(blk.ev_red[1]);
         if (blk.owns_m) (void)smh_crs_destroy(blk.m);
         (void)hipFree(blk.d_x); (void)hipFree(blk.d_y); (void)hipFree(blk.d_r); (void)hipFree(blk.d_ap);
-        (void)hipFree(blk.d_partials); (void)hipFree(blk.d_sc); (void)hipFree(blk.d_redv);
+        (void)hipFree(blk.d_partials); (void)hipFree(blk.d_dotp); (void)hipFree(blk.d_sc); (void)hipFree(blk.d_redv);
     }
     if (p->h_red) (void)hipHostFree(p->h_red);
     if (p->h_sc) (void)hipHostFree(p->h_sc);
@@ -1031,9 +1035,17 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
                 for (size_t k = 0; k < p->b.size(); ++k) {
                     ParBlock &blk = p->b[k];
                     SMH_TRY(use(blk));
-                    SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));                                   // :43
-                    SMH_TRY(launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, blk.r1 - blk.r0, blk.d_partials,
-                                       red_mine(p, blk, 0), blk.s));                                                            // :45
+                    // :43 and :45 -- with the CSR-stream kernel p.Ap rides the product's epilogue (one partial per tile, lhs = this
+                    // block's slice of p) as in the single-matrix solver: no second pass over p and Ap
+                    const size_t n_dot = spmv_fused_dot_partials(blk.m, n, variant, true);
+                    if (n_dot && n_dot <= blk.dotp_cap) {
+                        SMH_TRY(spmv_enqueue(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, blk.d_dotp, (const char *)pv->d[k] + blk.r0 * vs));
+                        SMH_TRY(launch_fold2(dt, blk.d_dotp, n_dot, blk.d_partials, red_mine(p, blk, 0), blk.s));
+                    } else {
+                        SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));
+                        SMH_TRY(launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, blk.r1 - blk.r0, blk.d_partials,
+                                           red_mine(p, blk, 0), blk.s));
+                    }
                 }
                 SMH_TRY(combine(p, 0));
                 for (size_t k = 0; k < p->b.size(); ++k) {
