@@ -67,9 +67,12 @@ typedef enum {
                          /* sums of its rows in registers while all waves walk the column   */
                          /* blocks together (AUTO's choice when the rows are of similar     */
                          /* length; runs K2c when a (row, block) pair exceeds 255 entries)  */
-    SMH_SPMV_COLSPLIT = 7 /* K2s: skewed rows without column locality (BASELINE C3): the rows */
+    SMH_SPMV_COLSPLIT = 7, /* K2s: skewed rows without column locality (BASELINE C3): the rows */
                          /* of >= 64 entries as a compacted matrix through K2c, the rest     */
                          /* through K2f, y assembled from both (K2c when not worth it)      */
+    SMH_SPMV_TILED = 8   /* K2t: columns without locality, two streaming passes over a 2-D   */
+                         /* tiled copy: products against slices of x held in LDS, then one  */
+                         /* wavefront per block of rows folds them (no gather leaves a CU)  */
 } smh_spmv_variant;
 
 typedef struct smh_crs smh_crs; /* device-resident SparseMatCRS<T,u32>  (sparsemat_crs.rs:9-17) */
@@ -253,6 +256,17 @@ int smh_crs_colblock(smh_crs *m, uint32_t *shift_out, size_t *n_blocks_out, int 
 int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_blocks_out, uint32_t *rows_per_lane_out,
                      size_t *n_tiles_out, uint32_t *tile_rows_out, uint32_t *segments_out, uint8_t *counts_out,
                      uint32_t *columns_out, void *values_out);
+
+/* K2t, the 2-D tiled copy (built on first use of SMH_SPMV_TILED; spmv_tiled.hip): the entries by column slice of
+ * *slice_columns_out (16384) columns, within a slice by (row, storage order), each slice padded to a multiple of 8 entries
+ * (*copy_entries_out in total); the rows in blocks of *rows_per_block_out, chosen so that one (slice, row block) tile holds
+ * about 48 entries.  y = A x then takes two streaming passes: products against the slice of x held in LDS, and one
+ * wavefront per row block folding its tiles slice by slice.  The sum of a row is therefore taken per slice (storage order
+ * inside, slices ascending): within the parity bound, bitwise reproducible, not bit-identical to the reference's order.
+ * Memory: the copy (sizeof(T) + 4 bytes per entry), the products of the last launch (sizeof(T) per entry) and a table of
+ * (n_row_blocks + 1) x n_slices u32 (beyond 4 GiB: SMH_ERR_INVALID).  Any out pointer may be NULL. */
+int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_columns_out, uint32_t *rows_per_block_out,
+                         uint32_t *n_row_blocks_out, size_t *copy_entries_out);
 
 /* K2s, the row-length split (built on first use): *split_out == 1 when the handle keeps its rows of >= *min_long_out
  * entries as a compacted sub-matrix (row i of it = row long_rows_out[i], n_long of them; global columns) and all rows

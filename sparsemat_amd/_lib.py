@@ -20,9 +20,9 @@ EXCHANGE_NAMES = {EXCHANGE_NONE: "none", EXCHANGE_ALLGATHER: "allgather", EXCHAN
 PAR_BACKEND_AUTO, PAR_BACKEND_PEER, PAR_BACKEND_RCCL = 0, 1, 2
 PAR_BACKENDS = {"auto": PAR_BACKEND_AUTO, "peer": PAR_BACKEND_PEER, "rccl": PAR_BACKEND_RCCL}
 COMM_ID_BYTES = 128
-SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ, SPMV_STREAM, SPMV_COLBLOCK, SPMV_COLFUSED, SPMV_COLSPLIT = 0, 1, 2, 3, 4, 5, 6, 7
+SPMV_AUTO, SPMV_VECTOR, SPMV_MERGE, SPMV_SEQ, SPMV_STREAM, SPMV_COLBLOCK, SPMV_COLFUSED, SPMV_COLSPLIT, SPMV_TILED = 0, 1, 2, 3, 4, 5, 6, 7, 8
 VARIANTS = {"auto": SPMV_AUTO, "vector": SPMV_VECTOR, "merge": SPMV_MERGE, "seq": SPMV_SEQ, "stream": SPMV_STREAM,
-            "colblock": SPMV_COLBLOCK, "colfused": SPMV_COLFUSED, "colsplit": SPMV_COLSPLIT}
+            "colblock": SPMV_COLBLOCK, "colfused": SPMV_COLFUSED, "colsplit": SPMV_COLSPLIT, "tiled": SPMV_TILED}
 
 _sz = C.c_size_t
 _vp = C.c_void_p
@@ -71,6 +71,7 @@ SIGNATURES = {
     "smh_crs_ring_bands": (_int, [_vp, _u32p, _vp]),
     "smh_crs_ring_plan": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(C.c_double), C.POINTER(_int), _vp, _vp]),
     "smh_crs_set_colblock_shift": (_int, [_vp, C.c_uint32]),
+    "smh_crs_tiled_layout": (_int, [_vp, _u32p, _u32p, _u32p, _u32p, C.POINTER(_sz)]),
     "smh_crs_colblock": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(_int), C.POINTER(C.c_double), _vp, _vp, _vp]),
     "smh_crs_colfused": (_int, [_vp, C.POINTER(_int), _u32p, C.POINTER(_sz), _u32p, C.POINTER(_sz), _vp, _vp, _vp, _vp, _vp]),
     "smh_crs_colsplit": (_int, [_vp, C.POINTER(_int), _u32p, C.POINTER(_sz), _vp, C.POINTER(_vp), C.POINTER(_vp)]),

@@ -143,6 +143,7 @@ static size_t cb_blocks_for(const smh_crs *m) {
 }
 // values changed (update_values / scale): the blocked copy is rebuilt on its next use
 static void drop_colblock(smh_crs *m) {
+    tiled_free(m);
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);
     m->d_cb_off = m->d_cb_col = nullptr;
     m->d_cb_val = nullptr;
@@ -742,6 +743,9 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
                                                  m->n_rows, m->nnz, m->cb_rpt, m->cb_single_pass, b > 0, s));
             return SMH_OK;
         }
+        case SMH_SPMV_TILED:
+            SMH_TRY(tiled_build(m));
+            return launch_spmv_tiled(m, x, x_len, y, s);
         case SMH_SPMV_MERGE:
             SMH_TRY(ensure_merge_ws(m));
             return launch_spmv_merge(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->n_tiles,
@@ -1170,6 +1174,7 @@ int smh_crs_destroy(smh_crs *m) {
     (void)hipFree(m->d_cf_tile_row); (void)hipFree(m->d_cf_progress);
     (void)smh_crs_destroy(m->split_long); (void)smh_crs_destroy(m->split_short);
     (void)hipFree(m->d_split_rows); (void)hipFree(m->d_split_y);
+    tiled_free(m);
     (void)hipFree(m->d_x); (void)hipFree(m->d_y);
     (void)hipGetLastError();
     delete m;
@@ -1216,11 +1221,25 @@ int smh_crs_scale(smh_crs *m, double a) {
     SMH_TRY(launch_scale_values(m->dtype, m->d_val, m->nnz, a, m->stream));
     if (m->cb_built) SMH_TRY(launch_scale_values(m->dtype, m->d_cb_val, m->nnz, a, m->stream));
     if (m->cf_built && m->cf_ok) SMH_TRY(launch_scale_values(m->dtype, m->d_cf_val, m->nnz, a, m->stream));
+    if (m->t2_built && m->t2_ok) SMH_TRY(launch_scale_values(m->dtype, m->d_t2_val, (size_t)m->t2_tot, a, m->stream));
     if (m->split_built && m->split_ok) {
         SMH_TRY(smh_crs_scale(m->split_long, a));
         SMH_TRY(smh_crs_scale(m->split_short, a));
     }
     SMH_HIP(hipStreamSynchronize(m->stream));
+    return SMH_OK;
+}
+
+int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_columns_out, uint32_t *rows_per_block_out, uint32_t *n_row_blocks_out,
+                         size_t *copy_entries_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(tiled_build(m));
+    if (!m->t2_ok) return fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
+    if (n_slices_out) *n_slices_out = m->t2_n_cb;
+    if (slice_columns_out) *slice_columns_out = 16384u;
+    if (rows_per_block_out) *rows_per_block_out = m->t2_R;
+    if (n_row_blocks_out) *n_row_blocks_out = m->t2_n_rb;
+    if (copy_entries_out) *copy_entries_out = (size_t)m->t2_tot;
     return SMH_OK;
 }
 
@@ -1398,6 +1417,7 @@ int smh_crs_prepare(smh_crs *m, int variant) {
             SMH_TRY(smh_crs_prepare(m->split_short, SMH_SPMV_AUTO));
             return smh_crs_prepare(m->split_long, SMH_SPMV_AUTO);
         case SMH_SPMV_STREAM: return m->use_stream_win == 1 ? ensure_stream_windows(m) : ensure_stream_codes(m);
+        case SMH_SPMV_TILED: return tiled_build(m);
         case SMH_SPMV_SEQ: return SMH_OK;
         default: return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);
     }

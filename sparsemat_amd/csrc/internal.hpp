@@ -157,6 +157,11 @@ int launch_crs_stats(const uint32_t *off, const uint32_t *col, size_t n_rows, si
                      hipStream_t s);
 // y = A x on stream s with the handle's kernel (capi.hip).  dot_partials (optional): when spmv_fused_dot_partials() > 0 the
 // kernel also leaves that many partial sums of x.y there (K1s epilogue; square matrices) -- CG's / PCG's p.Ap for free
+// K2t (spmv_tiled.hip)
+void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *rows_per_block, uint32_t *n_rb);
+int tiled_build(::smh_crs *m);   // lazy; sets t2_ok
+void tiled_free(::smh_crs *m);
+int launch_spmv_tiled(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s);
 size_t spmv_fused_dot_partials(::smh_crs *m, size_t x_len, int variant, bool any_lhs = false);
 int spmv_enqueue(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, void *dot_partials = nullptr,
                  const void *dot_lhs = nullptr);
@@ -233,6 +238,14 @@ struct smh_crs {
     uint32_t *d_cf_seg = nullptr, *d_cf_col = nullptr, *d_cf_tile_row = nullptr, *d_cf_progress = nullptr;
     uint8_t *d_cf_cnt = nullptr;
     void *d_cf_val = nullptr;
+    // K2t 2-D tiled copy (lazy; spmv_tiled.hip): entries by column slice, within a slice by row
+    bool t2_built = false, t2_ok = false;  // built: the build was attempted
+    uint32_t t2_n_cb = 0, t2_n_rb = 0, t2_R = 0;  // column slices, row blocks, rows per block
+    uint64_t t2_tot = 0;                   // entries of the copy (slices padded to 8)
+    void *d_t2_val = nullptr, *d_t2_prod = nullptr;  // values in copy order; the products of the last launch
+    uint16_t *d_t2_code = nullptr, *d_t2_row = nullptr;  // column within the slice; row within the row block
+    uint64_t *d_t2_cbptr = nullptr;        // first entry of each slice (n_cb + 1)
+    uint32_t *d_t2_tstart = nullptr;       // (n_rb + 1) x n_cb tile starts, relative to the slice
     // K1r plan (lazy)
     bool ring_planned = false;
     unsigned ring_blocks = 0;

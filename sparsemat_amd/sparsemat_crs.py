@@ -201,11 +201,18 @@ class SparseMatCRS:
     def resolved_variant(self):
         v, lanes = C.c_int(), C.c_int()
         check(lib().smh_crs_resolved_variant(self._h, C.byref(v), C.byref(lanes)))
-        return {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused", 7: "colsplit"}[v.value], lanes.value
+        return {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused", 7: "colsplit", 8: "tiled"}[v.value], lanes.value
 
     def set_colblock_shift(self, shift):
         """K2c: column blocks of 2**shift columns (0: automatic, 2 MiB of x)."""
         check(lib().smh_crs_set_colblock_shift(self._h, shift))
+
+    def tiled_layout(self):
+        """K2t (``smh_crs_tiled_layout``; builds the 2-D tiled copy on first use): dict with n_slices, slice_columns,
+        rows_per_block, n_row_blocks, copy_entries."""
+        a, b, c, d, e = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_size_t()
+        check(lib().smh_crs_tiled_layout(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        return {"n_slices": a.value, "slice_columns": b.value, "rows_per_block": c.value, "n_row_blocks": d.value, "copy_entries": e.value}
 
     def colsplit_flag(self):
         """True when the handle keeps a row-length split (builds it on first use)."""
@@ -231,7 +238,7 @@ class SparseMatCRS:
                 var, lanes = C.c_int(), C.c_int()
                 check(lib().smh_crs_resolved_variant(h, C.byref(var), C.byref(lanes)))
                 out[name] = (nr, off, col, val)
-                out[name + "_variant"] = {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused", 7: "colsplit"}[var.value]
+                out[name + "_variant"] = {1: "vector", 2: "merge", 3: "seq", 4: "stream", 5: "colblock", 6: "colfused", 7: "colsplit", 8: "tiled"}[var.value]
         return out
 
     def colfused(self, arrays=True):
