@@ -199,7 +199,22 @@ static int resolve_variant(const smh_crs *m, int variant) {
         // best through K2f -- 0.82 / 1.15 ms against K2c's 0.97 / 1.26; up to 255 entries K2c wins, 1.61 against 1.79)
         const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
         const double similar = 2.0 * mean + 8.0 > 128.0 ? 2.0 * mean + 8.0 : 128.0;
-        if ((double)m->max_row_len <= similar) return SMH_SPMV_COLFUSED;
+        if ((double)m->max_row_len <= similar) {
+            // rows dense enough for ~48 entries per (slice, row block) tile: the two streaming passes of K2t, whose gathers stay
+            // in LDS.  f32 (16 B per entry against CSR's 8): ahead of K2f on every shape measured, 9-40 % (C2-uniform 1.33 ms
+            // against 1.90).  f64 (28 B against 12) only while a wavefront's row block stays small -- its sums are LDS, and
+            // LDS is the occupancy: 1M rows x 16 / x 32 0.19 / 0.34 ms against 0.25 / 0.62, 10M x 64 4.6 against 6.4, but
+            // 4M x 32 (367 rows per block) 1.11 against 0.95 (profiles/r02_tiled_crossover.log)
+            static const bool tiled_off = getenv("SMH_TILED") && atoi(getenv("SMH_TILED")) == 0;  // tuning knob
+            if (!tiled_off && !(m->t2_built && !m->t2_ok)) {
+                uint32_t n_cb = 0, R = 0, n_rb = 0;
+                tiled_geometry(m->n_rows, m->n_cols, m->nnz, m->dtype, &n_cb, &R, &n_rb);
+                const double tile = (double)m->nnz / (double)n_cb / (double)n_rb;
+                const bool small_blocks = m->dtype == SMH_F32 || R <= 192 || (mean >= 48.0 && R <= 512);
+                if (small_blocks && tile >= 32.0 && (double)(n_rb + 1) * (double)n_cb * 4.0 <= (double)(1u << 30)) return SMH_SPMV_TILED;
+            }
+            return SMH_SPMV_COLFUSED;
+        }
         // ... and a matrix with a minority of long rows is taken apart by row length (K2s)
         static const bool split_off = getenv("SMH_COLBLOCK_SPLIT") && atoi(getenv("SMH_COLBLOCK_SPLIT")) == 0;  // tuning knob
         // ... when K2c's sweeps (per column block and row: one offset, y read and written) weigh as much as the entries

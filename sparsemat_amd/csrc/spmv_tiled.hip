@@ -361,6 +361,8 @@ static int build_t(::smh_crs *m) {
     hipLaunchKernelGGL(k_t2_table, dim3(grid), dim3(kBlock), 0, s, row_full, d_start, m->d_t2_cbptr, n_cb, n_rb, R, m->d_t2_tstart);
     SMH_HIP(hipGetLastError());
     SMH_HIP(hipStreamSynchronize(s));
+    // 128 KiB of dynamic LDS (f64) need the attribute on every device the kernel runs on: set with each build, on the matrix's device
+    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
     m->t2_n_cb = n_cb;
     m->t2_n_rb = n_rb;
     m->t2_R = R;
@@ -394,14 +396,7 @@ int tiled_build(::smh_crs *m) {
 
 template <typename T>
 static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
-    static bool attr_done[64][2] = {};
-    const int dev = m->device >= 0 && m->device < 64 ? m->device : 0;
-    const int ti = sizeof(T) == 8;
     const size_t lds1 = (size_t)kT2Slice * sizeof(T), lds2 = (size_t)kT2Waves * m->t2_R * sizeof(T);
-    if (!attr_done[dev][ti]) {
-        SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        attr_done[dev][ti] = true;
-    }
     uint32_t parts = (2500 + m->t2_n_cb - 1) / m->t2_n_cb;
     parts = parts < 1 ? 1 : (parts > 32 ? 32 : parts);
     hipLaunchKernelGGL(k_t2_expand<T>, dim3(m->t2_n_cb * parts), dim3(kT2ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val,

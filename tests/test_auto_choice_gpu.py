@@ -53,7 +53,7 @@ def test_auto_is_close_to_the_best_family(gpu, shape):
     _lib.check(sm.lib().smh_stream_create(C.byref(s)))
     families = ["vector", "merge", "stream"]
     if n * np.dtype(dtype).itemsize >= 4 << 20:
-        families += ["colblock", "colfused"]
+        families += ["colblock", "colfused", "tiled"]
     times = {}
     for v in families + ["auto"]:
         m.prepare(v)

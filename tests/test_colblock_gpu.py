@@ -115,13 +115,15 @@ def test_auto_picks_colblock_only_without_column_locality(gpu):
     """x of 12 MB (f32): uniform columns -> column-blocked (K2f); banded columns -> K1r as before.  Parity on both."""
     rows, n, k = 200_000, 3_000_000, 16
     m_u = synth.crs_fixed(synth.SEED_MATRIX, 1, n, k, np.float32, 0, rows)
-    assert m_u.resolved_variant()[0] == "colfused"  # the one-sweep form of the blocking (K2f)
+    assert m_u.resolved_variant()[0] == "tiled"  # f32, ~48 entries per (slice, row block) tile: the 2-D tiled passes (K2t) ...
+    y_f = m_u.mvp(oracle.gen_x(synth.SEED_X, n, np.float32), variant="colfused")  # ... the one-sweep blocking (K2f) otherwise
     cb = m_u.colblock(arrays=False)
     assert cb["n_blocks"] == 6 and cb["span_fraction"] > 0.9 and m_u.colfused(arrays=False)["n_blocks"] == 12
     off, col, val = m_u.raw_parts()
     x = oracle.gen_x(synth.SEED_X, n, np.float32)
     y = m_u.mvp(x)
-    assert_spmv_close(y, off, col, val, x, "auto colblock")
+    assert_spmv_close(y, off, col, val, x, "auto tiled")
+    assert_spmv_close(y_f, off, col, val, x, "colfused")
     for pattern in (0, 2):  # banded: K1r as before
         m_b = synth.crs_fixed(synth.SEED_MATRIX, pattern, n, k, np.float32, 1_000_000, 1_000_000 + rows)
         assert m_b.resolved_variant()[0] == "vector", pattern

@@ -12,7 +12,7 @@ from util import assert_spmv_close, random_crs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", ["vector", "merge", "stream", "colblock", "colfused", "colsplit", "seq"])
+@pytest.mark.parametrize("variant", ["vector", "merge", "stream", "colblock", "colfused", "colsplit", "tiled", "seq"])
 def test_spmv_dev_replays_from_a_captured_graph(gpu, variant):
     rng = np.random.default_rng(31)
     n_rows, n_cols = 20_011, 17_003
@@ -43,9 +43,9 @@ def test_spmv_dev_replays_from_a_captured_graph(gpu, variant):
 
 
 def test_prepare_on_the_headline_shapes(gpu):
-    for pattern, expect in ((synth.PATTERN_BANDED, "vector"), (synth.PATTERN_UNIFORM, "colfused")):
+    for pattern, expect in ((synth.PATTERN_BANDED, "vector"), (synth.PATTERN_UNIFORM, "tiled")):
         m = synth.crs_fixed(synth.SEED_MATRIX, pattern, 2_000_000, 16, np.float32)
         assert m.resolved_variant()[0] == expect
         m.prepare()
-        if expect == "colfused":
-            assert m.colfused(arrays=False)["n_blocks"] == 8
+        if expect == "tiled":  # f32 rows dense enough for ~48 entries per tile: the two streaming passes (K2t)
+            assert m.tiled_layout()["n_slices"] == 123 and m.colfused(arrays=False)["n_blocks"] == 8

@@ -40,7 +40,7 @@ def _exercise(rng, kind):
     m = sm.SparseMatCRS.from_raw_parts(n, n_cols, off, col, val)
     x = rng.uniform(-1, 1, n_cols).astype(val.dtype)
     m.set_colblock_shift(12)  # at most 39 column blocks for these sizes
-    for variant in ("auto", "vector", "merge", "stream", "colblock", "colfused", "colsplit", "seq"):
+    for variant in ("auto", "vector", "merge", "stream", "colblock", "colfused", "colsplit", "tiled", "seq"):
         m.mvp(x, variant=variant)
     m.set_stream_windows(1)
     m.mvp(x, variant="stream")

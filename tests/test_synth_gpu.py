@@ -186,18 +186,22 @@ def test_entry_count_just_below_u32_max(gpu):
 
 
 def test_full_size_c2_uniform_colblock_properties(gpu):
-    """C2 stress variant (10M rows x 32 uniform columns, f32) at full size: AUTO = column-blocked K2c; sampled row
+    """C2 stress variant (10M rows x 32 uniform columns, f32) at full size: AUTO = the 2-D tiled passes (K2t); sampled row
     blocks against the oracle (rows regenerated independently), the bit-exact K1s/SEQ pair agrees with it on the
-    samples bit for bit, K2c agrees with K1s on every row within the parity bound, linearity under x -> 2x."""
+    samples bit for bit, K2t and K2f agree with K1s on every row within the parity bound, linearity under x -> 2x."""
     n, k = 10_000_000, 32
     m = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_UNIFORM, n, k, np.float32)
-    assert m.resolved_variant()[0] == "colfused"  # column-blocked, one sweep over y (K2f)
+    assert m.resolved_variant()[0] == "tiled"  # two streaming passes over the 2-D tiled copy (K2t); before it: K2f
+    lay = m.tiled_layout()
+    assert lay["n_slices"] == 611 and 40 <= n * k / lay["n_slices"] / lay["n_row_blocks"] <= 56
     cf = m.colfused(arrays=False)
     assert cf["fits"] and cf["n_blocks"] == 39 and cf["shift"] == 18
     xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
     x = xbuf.download(np.float32, n)
     y_cb = _run(m, xptr, n, "auto", np.float32)
     y_st = _run(m, xptr, n, "stream", np.float32)
+    y_k2f = _run(m, xptr, n, "colfused", np.float32)
+    assert np.abs(y_k2f.astype(np.float64) - y_st).max() < 5e-5
     for rb in (0, 2047, 5_000_000, n - 2500):
         re = min(n, rb + 2500)
         off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_UNIFORM, n, k, np.float32, rb, re)
@@ -225,7 +229,8 @@ def test_full_size_c3_powerlaw_properties(gpu):
     y_st = _run(m, xptr, n, "stream", np.float64)
     y_k2f = _run(m, xptr, n, "colfused", np.float64)  # the one-sweep form and the per-block launches must agree too
     y_k2c = _run(m, xptr, n, "colblock", np.float64)
-    assert np.abs(y_k2f - y_st).max() < 2.1e-9 and np.abs(y_k2c - y_st).max() < 2.1e-9
+    y_k2t = _run(m, xptr, n, "tiled", np.float64)  # rows of up to 2048 entries: tiles of more than 64 entries take several rounds
+    assert np.abs(y_k2f - y_st).max() < 2.1e-9 and np.abs(y_k2c - y_st).max() < 2.1e-9 and np.abs(y_k2t - y_st).max() < 2.1e-9
     # |row| <= 2048 entries of magnitude < 1: sum|a x| <= 2048; bound 1e-12 * 2048 covers every row
     assert np.abs(y_cb - y_st).max() < 2.1e-9 and np.abs(y_mg - y_st).max() < 2.1e-9
     off_all = synth.powerlaw_offsets(synth.SEED_MATRIX, n)

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--lanes", default="4,8,16")
     ap.add_argument("--only-blocked", action="store_true", help="time only the column-blocked variants (K2c / K2f) and AUTO")
     ap.add_argument("--cb-shifts", default="", help="K2c column-block widths to time (log2 columns), e.g. 18,19,20")
+    ap.add_argument("--tiled", default="uniform,powerlaw", help="cases that also time the 2-D tiled variant (K2t)")
     args = ap.parse_args()
     torch.cuda.init()
     n = args.rows
@@ -108,6 +109,14 @@ def main():
         if args.cb_shifts and m.colsplit_flag():
             med, mn = time_variant(m, xptr, nr, ybuf.ptr, "colsplit", reps=8)
             report("colsplit (long rows K2c + short rows K2f)", B, med, mn)
+        if args.tiled and case in args.tiled.split(","):
+            import time
+            t0 = time.perf_counter()
+            lay = m.tiled_layout()
+            t_plan = time.perf_counter() - t0
+            med, mn = time_variant(m, xptr, nr, ybuf.ptr, "tiled", reps=8)
+            report("tiled (K2t) %d slices x %d row blocks of %d (copy built in %.0f ms)" % (
+                lay["n_slices"], lay["n_row_blocks"], lay["rows_per_block"], t_plan * 1e3), B, med, mn)
         med, mn = time_variant(m, xptr, nr, ybuf.ptr, "auto")
         report("auto", B, med, mn)
         del m, xbuf, ybuf
