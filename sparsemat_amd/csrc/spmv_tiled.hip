@@ -151,41 +151,45 @@ __global__ __launch_bounds__(kT2Waves * 64) void k_t2_reduce(const T *__restrict
             B.rv[d] = rowc[B.bs[d] + idx];
         }
     };
+    // one round = up to 64 consecutive entries of a tile, one per lane (p, r: this lane's product and row; r = ~0 past the end)
+    auto round = [&](uint64_t bs, uint32_t len, uint32_t t0, T p, uint32_t r, uint32_t prev0) {
+        const uint32_t t = t0 + lane;
+        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)r, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        if (lane == 0) prev = prev0;
+        const bool valid = t < len;
+        const bool head = valid && prev != r;
+        // run lengths from two ballots: m = heads whose run is longer than k; the k-th neighbour's product arrives by k one-lane shifts
+        const uint64_t nh = __ballot(valid && !head);
+        uint64_t m = __ballot(head);
+        T s = p, q = p;
+        for (uint32_t k = 1;; ++k) {
+            m &= nh >> k;
+            if (!m) break;
+            q = t2_shl1(q);
+            if ((m >> lane) & 1) s += q;
+        }
+        const uint32_t r63 = (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
+        if (head) {
+            const uint32_t nx = t0 + 64;  // the run may go on past this round (tiles of more than 64 entries only)
+            if (r63 == r && nx < len)
+                for (uint32_t k = nx; k < len && rowc[bs + k] == r; ++k) s += prod[bs + k];
+            acc[r] += s;
+        }
+    };
+    // the first round of every tile works on the prefetched registers and issues no load, so the wait in front of it can leave
+    // the next batch's loads in flight (a load inside the common path would force vmcnt(0): they return in order)
     auto fold = [&](T2Batch<T> &B) {
 #pragma unroll
         for (int d = 0; d < kT2Batch; ++d) {
             const uint32_t len = B.ln[d];
             const uint64_t bs = B.bs[d];
-            uint32_t t = lane;
-            T p = lane < len ? B.pv[d] : T(0);
-            uint32_t r = lane < len ? B.rv[d] : 0xFFFFFFFFu;
-            for (;;) {
-                uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)r, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-                if (lane == 0) prev = t == 0 ? 0xFFFFFFFFu : rowc[bs + t - 1];
-                const bool valid = t < len;
-                const bool head = valid && prev != r;
-                // run lengths from two ballots: m = heads whose run is longer than k; the k-th neighbour's product arrives by k one-lane shifts
-                const uint64_t nh = __ballot(valid && !head);
-                uint64_t m = __ballot(head);
-                T s = p, q = p;
-                for (uint32_t k = 1;; ++k) {
-                    m &= nh >> k;
-                    if (!m) break;
-                    q = t2_shl1(q);
-                    if ((m >> lane) & 1) s += q;
-                }
-                const uint32_t r63 = (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
-                if (head) {
-                    const uint32_t nx = t - lane + 64;  // the run may go on past this round (tiles of more than 64 entries only)
-                    if (r63 == r && nx < len)
-                        for (uint32_t k = nx; k < len && rowc[bs + k] == r; ++k) s += prod[bs + k];
-                    acc[r] += s;
-                }
-                t += 64;
-                if (__builtin_amdgcn_readfirstlane(t - lane) >= len) break;
-                p = T(0);
-                r = 0xFFFFFFFFu;
+            round(bs, len, 0, lane < len ? B.pv[d] : T(0), lane < len ? B.rv[d] : 0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (uint32_t t0 = 64; t0 < len; t0 += 64) {  // rare: a tile of more than 64 entries
+                const uint32_t t = t0 + lane;
+                T p = T(0);
+                uint32_t r = 0xFFFFFFFFu;
                 if (t < len) { p = prod[bs + t]; r = rowc[bs + t]; }
+                round(bs, len, t0, p, r, (uint32_t)rowc[bs + t0 - 1]);
             }
         }
     };
