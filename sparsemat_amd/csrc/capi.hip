@@ -200,18 +200,18 @@ static int resolve_variant(const smh_crs *m, int variant) {
         const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
         const double similar = 2.0 * mean + 8.0 > 128.0 ? 2.0 * mean + 8.0 : 128.0;
         if ((double)m->max_row_len <= similar) {
-            // rows dense enough for ~48 entries per (slice, row block) tile: the two streaming passes of K2t, whose gathers stay
-            // in LDS.  f32 (16 B per entry against CSR's 8): ahead of K2f on every shape measured, 9-40 % (C2-uniform 1.33 ms
-            // against 1.90).  f64 (28 B against 12) only while a wavefront's row block stays small -- its sums are LDS, and
-            // LDS is the occupancy: 1M rows x 16 / x 32 0.19 / 0.34 ms against 0.25 / 0.62, 10M x 64 4.6 against 6.4, but
-            // 4M x 32 (367 rows per block) 1.11 against 0.95 (profiles/r02_tiled_crossover.log)
+            // rows dense enough for >= 32 entries per (slice, row block) tile: the two streaming passes of K2t, whose gathers stay
+            // in LDS.  f32 (16 B per entry against CSR's 8): ahead of K2f on every shape measured, by 19-44 % (C2-uniform 1.21 ms
+            // against 1.90).  f64 (28 B against 12) where K2f is weak -- many column blocks to sweep (10 M columns, 39 blocks:
+            // 1.40 / 2.26 / 4.50 ms against 1.63 / 3.13 / 6.36 for rows of 16 / 32 / 64) or very few (1 M columns: 0.17 / 0.31
+            // against 0.25 / 0.61) -- but not in between (4 M columns x 16: 0.61 against 0.50) -- profiles/r02_tiled_crossover.log
             static const bool tiled_off = getenv("SMH_TILED") && atoi(getenv("SMH_TILED")) == 0;  // tuning knob
             if (!tiled_off && !(m->t2_built && !m->t2_ok)) {
                 uint32_t n_cb = 0, R = 0, n_rb = 0;
                 tiled_geometry(m->n_rows, m->n_cols, m->nnz, m->dtype, &n_cb, &R, &n_rb);
                 const double tile = (double)m->nnz / (double)n_cb / (double)n_rb;
-                const bool small_blocks = m->dtype == SMH_F32 || R <= 192 || (mean >= 48.0 && R <= 512);
-                if (small_blocks && tile >= 32.0 && (double)(n_rb + 1) * (double)n_cb * 4.0 <= (double)(1u << 30)) return SMH_SPMV_TILED;
+                const bool pays = m->dtype == SMH_F32 || cf_blocks_for(m) >= 24 || cf_blocks_for(m) <= 4;
+                if (pays && tile >= 32.0 && (double)(n_rb + 1) * (double)n_cb * 4.0 <= (double)(1u << 30)) return SMH_SPMV_TILED;
             }
             return SMH_SPMV_COLFUSED;
         }
