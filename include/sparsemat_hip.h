@@ -259,8 +259,8 @@ int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_b
 
 /* K2t, the 2-D tiled copy (built on first use of SMH_SPMV_TILED; spmv_tiled.hip): the entries by column slice of
  * *slice_columns_out (16384) columns, within a slice by (row, storage order), each slice padded to a multiple of 8 entries
- * (*copy_entries_out in total); the rows in blocks of *rows_per_block_out, chosen so that one (slice, row block) tile holds
- * about 48 entries.  y = A x then takes two streaming passes: products against the slice of x held in LDS, and one
+ * (*copy_entries_out in total); the rows in *n_row_blocks_out blocks of consecutive rows cut so that each holds the same
+ * number of entries -- about 48 per (slice, row block) tile -- and at most *rows_per_block_out rows (the largest block).  y = A x then takes two streaming passes: products against the slice of x held in LDS, and one
  * wavefront per row block folding its tiles slice by slice.  The sum of a row is therefore taken per slice (storage order
  * inside, slices ascending): within the parity bound, bitwise reproducible, not bit-identical to the reference's order.
  * Memory: the copy (sizeof(T) + 4 bytes per entry), the products of the last launch (sizeof(T) per entry) and a table of

@@ -185,6 +185,16 @@ static bool wants_colblock(const smh_crs *m) {
     return m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes && m->span_fraction > 0.25 && b >= 2 && b <= 128;
 }
 
+// K2t is an option: not switched off, its copy was not refused, >= 32 entries per (slice, row block) tile, a tile table of <= 1 GiB
+static bool tiled_fits(const smh_crs *m) {
+    static const bool tiled_off = getenv("SMH_TILED") && atoi(getenv("SMH_TILED")) == 0;  // tuning knob
+    if (tiled_off || (m->t2_built && !m->t2_ok)) return false;
+    uint32_t n_cb = 0, R = 0, n_rb = 0;
+    tiled_geometry(m->n_rows, m->n_cols, m->nnz, m->dtype, &n_cb, &R, &n_rb);
+    const double tile = (double)m->nnz / (double)n_cb / (double)n_rb;
+    return tile >= 32.0 && (double)(n_rb + 1) * (double)n_cb * 4.0 <= (double)(1u << 30);
+}
+
 static int resolve_variant(const smh_crs *m, int variant) {
     if (variant != SMH_SPMV_AUTO) return variant;
     if (wants_colblock(m)) {
@@ -205,16 +215,12 @@ static int resolve_variant(const smh_crs *m, int variant) {
             // against 1.90).  f64 (28 B against 12) where K2f is weak -- many column blocks to sweep (10 M columns, 39 blocks:
             // 1.40 / 2.26 / 4.50 ms against 1.63 / 3.13 / 6.36 for rows of 16 / 32 / 64) or very few (1 M columns: 0.17 / 0.31
             // against 0.25 / 0.61) -- but not in between (4 M columns x 16: 0.61 against 0.50) -- profiles/r02_tiled_crossover.log
-            static const bool tiled_off = getenv("SMH_TILED") && atoi(getenv("SMH_TILED")) == 0;  // tuning knob
-            if (!tiled_off && !(m->t2_built && !m->t2_ok)) {
-                uint32_t n_cb = 0, R = 0, n_rb = 0;
-                tiled_geometry(m->n_rows, m->n_cols, m->nnz, m->dtype, &n_cb, &R, &n_rb);
-                const double tile = (double)m->nnz / (double)n_cb / (double)n_rb;
-                const bool pays = m->dtype == SMH_F32 || cf_blocks_for(m) >= 24 || cf_blocks_for(m) <= 4;
-                if (pays && tile >= 32.0 && (double)(n_rb + 1) * (double)n_cb * 4.0 <= (double)(1u << 30)) return SMH_SPMV_TILED;
-            }
+            if (tiled_fits(m) && (m->dtype == SMH_F32 || cf_blocks_for(m) >= 24 || cf_blocks_for(m) <= 4)) return SMH_SPMV_TILED;
             return SMH_SPMV_COLFUSED;
         }
+        // skewed rows: K2t cuts its row blocks by entries, so long rows cost it nothing special -- on f64 with many column blocks
+        // (C3: 2.57 ms against K2s's 2.76 and K2c's 3.25) it is ahead; a 3M-row f32 power law (12 blocks) ties with K2c (0.61 both)
+        if (m->dtype == SMH_F64 && cf_blocks_for(m) >= 24 && !m->no_split && tiled_fits(m)) return SMH_SPMV_TILED;  // (the parts of a K2s split stay as measured)
         // ... and a matrix with a minority of long rows is taken apart by row length (K2s)
         static const bool split_off = getenv("SMH_COLBLOCK_SPLIT") && atoi(getenv("SMH_COLBLOCK_SPLIT")) == 0;  // tuning knob
         // ... when K2c's sweeps (per column block and row: one offset, y read and written) weigh as much as the entries

@@ -240,12 +240,13 @@ struct smh_crs {
     void *d_cf_val = nullptr;
     // K2t 2-D tiled copy (lazy; spmv_tiled.hip): entries by column slice, within a slice by row
     bool t2_built = false, t2_ok = false;  // built: the build was attempted
-    uint32_t t2_n_cb = 0, t2_n_rb = 0, t2_R = 0;  // column slices, row blocks, rows per block
+    uint32_t t2_n_cb = 0, t2_n_rb = 0, t2_R = 0;  // column slices, row blocks, rows of the largest block
     uint64_t t2_tot = 0;                   // entries of the copy (slices padded to 8)
     void *d_t2_val = nullptr, *d_t2_prod = nullptr;  // values in copy order; the products of the last launch
     uint16_t *d_t2_code = nullptr, *d_t2_row = nullptr;  // column within the slice; row within the row block
     uint64_t *d_t2_cbptr = nullptr;        // first entry of each slice (n_cb + 1)
     uint32_t *d_t2_tstart = nullptr;       // (n_rb + 1) x n_cb tile starts, relative to the slice
+    uint32_t *d_t2_rbstart = nullptr;      // first row of each row block (n_rb + 1); blocks hold equal entry counts
     // K1r plan (lazy)
     bool ring_planned = false;
     unsigned ring_blocks = 0;

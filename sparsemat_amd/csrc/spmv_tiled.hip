@@ -9,9 +9,10 @@
 //   pass 1 "expand":  the entries are stored by column slice (C = 16384 columns); a workgroup stages its slice of x in
 //                     LDS and computes prod[i] = val[i] * x_lds[code[i]] for its part of the slice's entries -- a pure
 //                     streaming map (16-bit column codes; 16-byte loads and stores), the gathers hit LDS.
-//   pass 2 "reduce":  within a slice the entries are ordered by row, so the entries of rows [rb*R, (rb+1)*R) form one
-//                     contiguous TILE per slice.  One wavefront per block of R rows walks its tiles slice by slice (R is
-//                     chosen so that a tile holds ~48 entries: one entry per lane), adds runs of equal rows with two
+//   pass 2 "reduce":  within a slice the entries are ordered by row, so the entries of a block of consecutive rows form
+//                     one contiguous TILE per slice.  The row blocks are cut so that each holds the same number of entries
+//                     (~48 per tile: one entry per lane; skewed matrices get short blocks around their long rows).  One
+//                     wavefront per row block walks its tiles slice by slice, adds runs of equal rows with two
 //                     ballots and one-lane DPP shifts, and accumulates into R wave-private sums in LDS: no atomics,
 //                     no barriers, a fixed order -- bitwise reproducible.  The loads of the next 8 tiles are in flight
 //                     while 8 are folded.
@@ -19,6 +20,7 @@
 // against CSR's 8 / 12, all of it streaming.  Memory: the copy (sizeof(T)+4 per entry) plus the product buffer.
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <vector>
 
 #include "internal.hpp"
@@ -103,17 +105,19 @@ struct T2Batch {
 };
 
 // tstart[rb * n_cb + cb] = first entry of tile (cb, rb) relative to cb_ptr[cb]; row n_rb of the table holds the ends of the
-// last row block's tiles.  rowc: the entry's row relative to its row block.  LDS: kT2Waves * R sums.
+// last row block's tiles.  Row block rb = rows [rb_start[rb], rb_start[rb+1]); rowc: the entry's row relative to its block.
+// LDS: kT2Waves * R sums.
 template <typename T>
 __global__ __launch_bounds__(kT2Waves * 64) void k_t2_reduce(const T *__restrict__ prod, const uint16_t *__restrict__ rowc,
                                                               const uint64_t *__restrict__ cb_ptr, const uint32_t *__restrict__ tstart, uint32_t n_cb,
-                                                              uint32_t n_rb, uint32_t R, T *__restrict__ y, uint64_t n_rows) {
+                                                              uint32_t n_rb, const uint32_t *__restrict__ rb_start, uint32_t R, T *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char t2_smem[];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t rb = blockIdx.x * kT2Waves + w;
     if (rb >= n_rb) return;  // whole wavefronts; no barrier below
-    T *acc = (T *)t2_smem + (size_t)w * R;
-    for (uint32_t i = lane; i < R; i += 64) acc[i] = T(0);
+    T *acc = (T *)t2_smem + (size_t)w * R;  // R = the largest row block
+    const uint32_t r0 = rb_start[rb], rows = rb_start[rb + 1] - r0;
+    for (uint32_t i = lane; i < rows; i += 64) acc[i] = T(0);
     const uint32_t *ts0 = tstart + (size_t)rb * n_cb, *ts1 = ts0 + n_cb;
     auto table = [&](uint32_t g, uint64_t &base, uint32_t &len) {  // lane l: tile g + l
         const uint32_t cbl = g + lane;
@@ -201,9 +205,7 @@ __global__ __launch_bounds__(kT2Waves * 64) void k_t2_reduce(const T *__restrict
         issue(A, j0 + 2 * kT2Batch);
         fold(B);
     }
-    const uint64_t r0 = (uint64_t)rb * R;
-    for (uint32_t i = lane; i < R; i += 64)
-        if (r0 + i < n_rows) y[r0 + i] = acc[i];
+    for (uint32_t i = lane; i < rows; i += 64) y[(uint64_t)r0 + i] = acc[i];
 }
 
 // ---- plan -----------------------------------------------------------------------------------------------------------
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(kBlock) void k_t2_bounds(const uint32_t *__restrict
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_t2_fill(const uint32_t *__restrict__ off, uint64_t n_rows, const uint32_t *__restrict__ col,
                                                      const T *__restrict__ val, const uint32_t *__restrict__ key_s, const uint32_t *__restrict__ perm,
-                                                     uint64_t nnz, const uint64_t *__restrict__ start, const uint64_t *__restrict__ cb_ptr, uint32_t R,
+                                                     uint64_t nnz, const uint64_t *__restrict__ start, const uint64_t *__restrict__ cb_ptr,
+                                                     const uint32_t *__restrict__ rb_start, uint32_t n_rb,
                                                      T *__restrict__ val_a, uint16_t *__restrict__ code_a, uint16_t *__restrict__ row_a,
                                                      uint32_t *__restrict__ row_full) {
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nnz; q += (uint64_t)gridDim.x * kBlock) {
@@ -244,19 +247,24 @@ __global__ __launch_bounds__(kBlock) void k_t2_fill(const uint32_t *__restrict__
         const uint32_t row = (uint32_t)lo;
         val_a[p] = val[i];
         code_a[p] = (uint16_t)(col[i] - cb * kT2Slice);
-        row_a[p] = (uint16_t)(row % R);
+        uint32_t bl = 0, bh = n_rb;  // the row block: the last one with rb_start[b] <= row
+        while (bl + 1 < bh) {
+            const uint32_t mid = (bl + bh) / 2;
+            if (rb_start[mid] <= row) bl = mid; else bh = mid;
+        }
+        row_a[p] = (uint16_t)(row - rb_start[bl]);
         row_full[p] = row;
     }
 }
 
-// tstart[rb * n_cb + cb], rb = 0 .. n_rb: first entry of slice cb (relative) whose row is >= rb * R
+// tstart[rb * n_cb + cb], rb = 0 .. n_rb: first entry of slice cb (relative) whose row is >= rb_start[rb] (= n_rows for rb = n_rb)
 __global__ __launch_bounds__(kBlock) void k_t2_table(const uint32_t *__restrict__ row_full, const uint64_t *__restrict__ start,
-                                                      const uint64_t *__restrict__ cb_ptr, uint32_t n_cb, uint32_t n_rb, uint32_t R,
-                                                      uint32_t *__restrict__ tstart) {
+                                                      const uint64_t *__restrict__ cb_ptr, uint32_t n_cb, uint32_t n_rb,
+                                                      const uint32_t *__restrict__ rb_start, uint32_t *__restrict__ tstart) {
     const uint64_t total = (uint64_t)(n_rb + 1) * n_cb;
     for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kBlock) {
         const uint32_t rb = (uint32_t)(t / n_cb), cb = (uint32_t)(t % n_cb);
-        const uint64_t cnt = start[cb + 1] - start[cb], first_row = (uint64_t)rb * R;
+        const uint64_t cnt = start[cb + 1] - start[cb], first_row = rb_start[rb];
         const uint32_t *seg = row_full + cb_ptr[cb];
         uint64_t lo = 0, hi = cnt;
         while (lo < hi) {
@@ -284,16 +292,17 @@ struct T2Scratch {
     ~T2Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
 };
 
+// the geometry for rows of equal length (AUTO's estimate; the build cuts the row blocks by entries, see row_blocks())
 void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *R, uint32_t *n_rb) {
     const uint64_t cb = ((uint64_t)n_cols + kT2Slice - 1) / kT2Slice;
     *n_cb = (uint32_t)(cb ? cb : 1);
     // rows per block: a tile (one slice x one row block) should hold ~kT2TileTarget entries; the sums of kT2Waves blocks
     // share 48 KiB of LDS
     const double per_row_and_slice = n_rows ? (double)nnz / (double)n_rows / (double)*n_cb : 0.0;
-    const uint32_t cap = (uint32_t)(48u * 1024u / kT2Waves / dtype_size(dtype));
+    const uint32_t cap = dtype == SMH_F64 ? 1280u : 3072u;  // rows whose sums one wavefront keeps in LDS (see build_t)
     double r = per_row_and_slice > 0.0 ? kT2TileTarget / per_row_and_slice : (double)cap;
     if (r > (double)cap) r = (double)cap;
-    if (r < 64.0) r = 64.0;
+    if (r < 1.0) r = 1.0;
     *R = (uint32_t)r;
     const uint64_t rb = ((uint64_t)n_rows + *R - 1) / *R;
     *n_rb = (uint32_t)(rb ? rb : 1);
@@ -305,6 +314,39 @@ static int build_t(::smh_crs *m) {
     const uint64_t nnz = m->nnz;
     uint32_t n_cb, R, n_rb;
     tiled_geometry(m->n_rows, m->n_cols, m->nnz, m->dtype, &n_cb, &R, &n_rb);
+    // row blocks of equal ENTRY counts (a tile = one slice of a block: ~kT2TileTarget entries whatever the row lengths), at most
+    // `cap` rows each (their sums share the LDS); greedy over the row offsets, on the host
+    std::vector<uint32_t> rb_start;
+    {
+        // f32: 3072 rows (12 KiB of sums per wavefront); f64: 1280 (10 KiB: 16 wavefronts per CU) -- C3 2.70 / 2.57 / 2.54 / 2.58 ms
+        // with 1536 / 1280 / 1024 / 768, 10 M x 16 uniform 1.35 / 1.29 / 1.39 / 1.49 (profiles/r02_tiled_cap.log)
+        uint32_t cap = sizeof(T) == 8 ? 1280u : 3072u;
+        if (const char *e = getenv("SMH_TILED_CAP")) {  // tuning knob: most rows of a row block
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8192) cap = (uint32_t)v;
+        }
+        const uint64_t per_block = (uint64_t)(kT2TileTarget * (double)n_cb);
+        std::vector<uint32_t> h_off(m->n_rows + 1);
+        SMH_HIP(hipMemcpyAsync(h_off.data(), m->d_off, h_off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        SMH_HIP(hipStreamSynchronize(s));
+        rb_start.reserve((size_t)n_rb + 16);
+        size_t r = 0;
+        while (r < m->n_rows) {
+            rb_start.push_back((uint32_t)r);
+            const size_t hi = r + cap < m->n_rows ? r + cap : m->n_rows;
+            // the first row boundary in (r, hi] at which the block holds per_block entries or more
+            const uint64_t want = (uint64_t)h_off[r] + per_block;
+            size_t e = (size_t)(std::lower_bound(h_off.begin() + r + 1, h_off.begin() + hi + 1, want,
+                                                 [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - h_off.begin());
+            if (e > hi) e = hi;
+            r = e;
+        }
+        if (rb_start.empty()) rb_start.push_back(0);
+        rb_start.push_back((uint32_t)m->n_rows);
+        n_rb = (uint32_t)(rb_start.size() - 1);
+        R = 1;
+        for (uint32_t b = 0; b < n_rb; ++b) R = std::max(R, rb_start[b + 1] - rb_start[b]);
+    }
     const uint64_t table_entries = (uint64_t)(n_rb + 1) * n_cb;
     if (table_entries * 4 > (4ull << 30))
         return fail(SMH_ERR_INVALID, "tiled variant: %u column slices x %u row blocks need a tile table beyond 4 GiB", n_cb, n_rb);
@@ -352,6 +394,8 @@ static int build_t(::smh_crs *m) {
     SMH_HIP(hipMalloc((void **)&m->d_t2_row, (tot + 8) * sizeof(uint16_t)));
     SMH_HIP(hipMalloc((void **)&m->d_t2_cbptr, ((size_t)n_cb + 1) * sizeof(uint64_t)));
     SMH_HIP(hipMalloc((void **)&m->d_t2_tstart, table_entries * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_t2_rbstart, rb_start.size() * sizeof(uint32_t)));
+    SMH_HIP(hipMemcpyAsync(m->d_t2_rbstart, rb_start.data(), rb_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     SMH_HIP(hipMemsetAsync(m->d_t2_val, 0, (tot + 8) * sizeof(T), s));
     SMH_HIP(hipMemsetAsync(m->d_t2_prod, 0, (tot + 8) * sizeof(T), s));
     SMH_HIP(hipMemsetAsync(m->d_t2_code, 0, (tot + 8) * sizeof(uint16_t), s));
@@ -359,10 +403,10 @@ static int build_t(::smh_crs *m) {
     SMH_HIP(hipMemcpyAsync(m->d_t2_cbptr, cb_ptr.data(), cb_ptr.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     if (nnz) {
         hipLaunchKernelGGL(k_t2_fill<T>, dim3(grid), dim3(kBlock), 0, s, m->d_off, (uint64_t)m->n_rows, m->d_col, (const T *)m->d_val, key_s, perm, nnz,
-                           d_start, m->d_t2_cbptr, R, (T *)m->d_t2_val, m->d_t2_code, m->d_t2_row, row_full);
+                           d_start, m->d_t2_cbptr, m->d_t2_rbstart, n_rb, (T *)m->d_t2_val, m->d_t2_code, m->d_t2_row, row_full);
         SMH_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_t2_table, dim3(grid), dim3(kBlock), 0, s, row_full, d_start, m->d_t2_cbptr, n_cb, n_rb, R, m->d_t2_tstart);
+    hipLaunchKernelGGL(k_t2_table, dim3(grid), dim3(kBlock), 0, s, row_full, d_start, m->d_t2_cbptr, n_cb, n_rb, m->d_t2_rbstart, m->d_t2_tstart);
     SMH_HIP(hipGetLastError());
     SMH_HIP(hipStreamSynchronize(s));
     // 128 KiB of dynamic LDS (f64) need the attribute on every device the kernel runs on: set with each build, on the matrix's device
@@ -376,11 +420,11 @@ static int build_t(::smh_crs *m) {
 
 void tiled_free(::smh_crs *m) {
     (void)hipFree(m->d_t2_val); (void)hipFree(m->d_t2_prod); (void)hipFree(m->d_t2_code); (void)hipFree(m->d_t2_row);
-    (void)hipFree(m->d_t2_cbptr); (void)hipFree(m->d_t2_tstart);
+    (void)hipFree(m->d_t2_cbptr); (void)hipFree(m->d_t2_tstart); (void)hipFree(m->d_t2_rbstart);
     m->d_t2_val = m->d_t2_prod = nullptr;
     m->d_t2_code = m->d_t2_row = nullptr;
     m->d_t2_cbptr = nullptr;
-    m->d_t2_tstart = nullptr;
+    m->d_t2_tstart = m->d_t2_rbstart = nullptr;
     m->t2_built = m->t2_ok = false;
 }
 
@@ -407,7 +451,7 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
                        m->d_t2_code, m->d_t2_cbptr, (T *)m->d_t2_prod, parts);
     SMH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_t2_reduce<T>, dim3((m->t2_n_rb + kT2Waves - 1) / kT2Waves), dim3(kT2Waves * 64), lds2, s, (const T *)m->d_t2_prod, m->d_t2_row,
-                       m->d_t2_cbptr, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb, m->t2_R, (T *)y, (uint64_t)m->n_rows);
+                       m->d_t2_cbptr, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb, m->d_t2_rbstart, m->t2_R, (T *)y);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }

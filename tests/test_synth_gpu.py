@@ -215,11 +215,14 @@ def test_full_size_c2_uniform_colblock_properties(gpu):
 
 
 def test_full_size_c3_powerlaw_properties(gpu):
-    """BASELINE C3 (f64, 10M rows, power-law lengths 1..2048, uniform columns) at full size: K2c (AUTO), merge-path K2
-    and the bit-exact K1s agree on every row to 1e-12 of the row's scale; sampled rows against the oracle."""
+    """BASELINE C3 (f64, 10M rows, power-law lengths 1..2048, uniform columns) at full size: K2t (AUTO), the column-blocked
+    K2c / K2f / K2s, merge-path K2 and the bit-exact K1s agree on every row to 1e-12 of the row's scale; sampled rows against
+    the oracle."""
     n = 10_000_000
     m = synth.crs_powerlaw(synth.SEED_MATRIX, n, n, np.float64)
-    assert m.resolved_variant()[0] == "colsplit" and m.max_row_len() == 2048  # skewed rows: taken apart by row length (K2s)
+    assert m.resolved_variant()[0] == "tiled" and m.max_row_len() == 2048  # K2t: row blocks cut by entries; before it K2s, below
+    lay = m.tiled_layout()
+    assert lay["n_slices"] == 611 and lay["rows_per_block"] <= 1280 and 36 <= m.n_non_zero_entries() / 611 / lay["n_row_blocks"] <= 50
     cs_flag = m.colsplit()
     assert cs_flag["split"] and 700_000 < cs_flag["n_long"] < 800_000 and cs_flag["long_variant"] == "colblock" and cs_flag["short_variant"] == "colfused"
     xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float64)
@@ -229,8 +232,8 @@ def test_full_size_c3_powerlaw_properties(gpu):
     y_st = _run(m, xptr, n, "stream", np.float64)
     y_k2f = _run(m, xptr, n, "colfused", np.float64)  # the one-sweep form and the per-block launches must agree too
     y_k2c = _run(m, xptr, n, "colblock", np.float64)
-    y_k2t = _run(m, xptr, n, "tiled", np.float64)  # rows of up to 2048 entries: tiles of more than 64 entries take several rounds
-    assert np.abs(y_k2f - y_st).max() < 2.1e-9 and np.abs(y_k2c - y_st).max() < 2.1e-9 and np.abs(y_k2t - y_st).max() < 2.1e-9
+    y_k2s = _run(m, xptr, n, "colsplit", np.float64)  # taken apart by row length (AUTO's choice before K2t)
+    assert np.abs(y_k2f - y_st).max() < 2.1e-9 and np.abs(y_k2c - y_st).max() < 2.1e-9 and np.abs(y_k2s - y_st).max() < 2.1e-9
     # |row| <= 2048 entries of magnitude < 1: sum|a x| <= 2048; bound 1e-12 * 2048 covers every row
     assert np.abs(y_cb - y_st).max() < 2.1e-9 and np.abs(y_mg - y_st).max() < 2.1e-9
     off_all = synth.powerlaw_offsets(synth.SEED_MATRIX, n)

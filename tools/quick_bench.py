@@ -53,8 +53,8 @@ def main():
     torch.cuda.init()
     n = args.rows
     for case in args.cases.split(","):
-        if case == "powerlaw":
-            dtype = np.float64
+        if case in ("powerlaw", "powerlaw32"):
+            dtype = np.float64 if case == "powerlaw" else np.float32
             m = synth.crs_powerlaw(synth.SEED_MATRIX, n, n, dtype)
         elif case.startswith("lap"):
             dtype = np.float32
