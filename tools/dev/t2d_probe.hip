@@ -10,6 +10,9 @@
 #ifndef NT_EXP
 #define NT_EXP 1
 #endif
+#ifndef EXP_PIPE
+#define EXP_PIPE 0
+#endif
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -62,6 +65,38 @@ __global__ __launch_bounds__(1024) void k_expand(const T *__restrict__ x, uint64
         *(W *)(prod + e + 4) = p1;
 #endif
     };
+#if EXP_PIPE
+    // software pipelined: the loads of the next two groups are issued before the current two are multiplied and stored
+    struct G2 { nu4 c0, c1; W a0, a1, b0, b1; };
+    auto ld = [&](uint64_t g, G2 &o) {
+        const uint64_t e = a0 + g * 8;
+        const bool two = g + 1024 < g1;
+        const uint64_t f = two ? e + 8192 : e;
+        o.c0 = __builtin_nontemporal_load((const nu4 *)(code + e));
+        o.a0 = __builtin_nontemporal_load((const W *)(val + e));
+        o.a1 = __builtin_nontemporal_load((const W *)(val + e + 4));
+        o.c1 = __builtin_nontemporal_load((const nu4 *)(code + f));
+        o.b0 = __builtin_nontemporal_load((const W *)(val + f));
+        o.b1 = __builtin_nontemporal_load((const W *)(val + f + 4));
+    };
+    uint64_t g = g0 + threadIdx.x;
+    if (g < g1) {
+        G2 cur, nxt;
+        ld(g, cur);
+        for (;;) {
+            const uint64_t gn = g + 2048;
+            const bool more = gn < g1;
+            if (more) ld(gn, nxt);
+            const uint64_t e = a0 + g * 8;
+            mul(cur.c0, cur.a0, cur.a1, e);
+            if (g + 1024 < g1) mul(cur.c1, cur.b0, cur.b1, e + 8192);
+            if (!more) break;
+            cur = nxt;
+            g = gn;
+        }
+    }
+}
+#else
     uint64_t g = g0 + threadIdx.x;
     for (; g + 1024 < g1; g += 2048) {
         const uint64_t e = a0 + g * 8, f = e + 8192;
@@ -82,6 +117,7 @@ __global__ __launch_bounds__(1024) void k_expand(const T *__restrict__ x, uint64
         mul(cd, v0, v1, e);
     }
 }
+#endif
 
 // phase 2: one wavefront per block of R rows; tstart[(rb) * n_cb + cb] = first entry of tile (cb, rb), relative to cb_ptr[cb];
 // row n_rb of the table holds the ends of the last row block's tiles.  block = NW wavefronts, LDS = NW * R * sizeof(T).
