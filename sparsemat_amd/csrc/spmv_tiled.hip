@@ -34,15 +34,38 @@ constexpr int kT2Batch = 8;            // tiles whose loads are in flight togeth
 constexpr double kT2TileTarget = 48.0; // mean entries per tile (one per lane; a longer tile takes a slow second round)
 
 typedef float t2_f4 __attribute__((ext_vector_type(4)));
-typedef double t2_d4 __attribute__((ext_vector_type(4)));
-typedef uint32_t t2_u4 __attribute__((ext_vector_type(4)));
-template <typename T> struct T2V4;
-template <> struct T2V4<float> { using t = t2_f4; };
-template <> struct T2V4<double> { using t = t2_d4; };
+typedef double t2_d2 __attribute__((ext_vector_type(2)));
+typedef uint32_t t2_u2 __attribute__((ext_vector_type(2)));
+// one lane's 16 bytes of values and the 16-bit codes that go with them
+template <typename T> struct T2Lane;
+template <> struct T2Lane<float> {
+    using V = t2_f4;
+    using C = t2_u2;
+    static constexpr int kEntries = 4, kUnroll = 4;
+    static __device__ __forceinline__ V mul(V v, C c, const float *xs) {
+        V p;
+        p.x = v.x * xs[c.x & 0xFFFF]; p.y = v.y * xs[c.x >> 16];
+        p.z = v.z * xs[c.y & 0xFFFF]; p.w = v.w * xs[c.y >> 16];
+        return p;
+    }
+};
+template <> struct T2Lane<double> {
+    using V = t2_d2;
+    using C = uint32_t;
+    static constexpr int kEntries = 2, kUnroll = 8;
+    static __device__ __forceinline__ V mul(V v, C c, const double *xs) {
+        V p;
+        p.x = v.x * xs[c & 0xFFFF]; p.y = v.y * xs[c >> 16];
+        return p;
+    }
+};
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------------
 // grid = slices * parts; cb_ptr[b] = first entry of slice b in the copy (multiples of 8 entries: segments are padded with
-// zero-valued entries of code 0)
+// zero-valued entries of code 0).  Every load and store instruction of a wavefront covers ONE contiguous kilobyte (a lane
+// takes 16 bytes of values -- 4 f32 / 2 f64 entries -- and their codes, the next lane the next 16): with a lane owning 8
+// consecutive entries instead, a 16-byte load used a quarter (f64) or half (f32) of every line it touched and the read
+// side alone ran at 3.6 TB/s on f64 (profiles/r02_t2d_probe.log)
 template <typename T>
 __global__ __launch_bounds__(kT2ExpandThreads) void k_t2_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
                                                                  const uint16_t *__restrict__ code, const uint64_t *__restrict__ cb_ptr,
@@ -53,39 +76,33 @@ __global__ __launch_bounds__(kT2ExpandThreads) void k_t2_expand(const T *__restr
     const uint64_t c0 = (uint64_t)cb * kT2Slice;
     for (uint32_t i = threadIdx.x; i < kT2Slice; i += kT2ExpandThreads) xs[i] = c0 + i < x_len ? x[c0 + i] : T(0);
     __syncthreads();
+    using L = T2Lane<T>;
+    using V = typename L::V;
+    using C = typename L::C;
+    constexpr int E = L::kEntries, U = L::kUnroll;
     const uint64_t a0 = cb_ptr[cb], a1 = cb_ptr[cb + 1];
-    const uint64_t groups = (a1 - a0) / 8;
-    const uint64_t per = (groups + parts - 1) / parts;
-    const uint64_t g0 = (uint64_t)part * per, g1 = g0 + per < groups ? g0 + per : groups;
-    using W = typename T2V4<T>::t;
-    auto mul = [&](const t2_u4 cd, const W v0, const W v1, uint64_t e) {
-        W p0, p1;
-        p0.x = v0.x * xs[cd.x & 0xFFFF]; p0.y = v0.y * xs[cd.x >> 16];
-        p0.z = v0.z * xs[cd.y & 0xFFFF]; p0.w = v0.w * xs[cd.y >> 16];
-        p1.x = v1.x * xs[cd.z & 0xFFFF]; p1.y = v1.y * xs[cd.z >> 16];
-        p1.z = v1.z * xs[cd.w & 0xFFFF]; p1.w = v1.w * xs[cd.w >> 16];
-        // plain stores: non-temporal ones cost 30 % here on f64 (profiles/r02_t2d_probe.log)
-        *(W *)(prod + e) = p0;
-        *(W *)(prod + e + 4) = p1;
-    };
-    uint64_t g = g0 + threadIdx.x;
-    for (; g + kT2ExpandThreads < g1; g += 2 * kT2ExpandThreads) {  // two groups of 8 entries per thread in flight
-        const uint64_t e = a0 + g * 8, f = e + 8ull * kT2ExpandThreads;
-        const t2_u4 cd = __builtin_nontemporal_load((const t2_u4 *)(code + e));
-        const W v0 = __builtin_nontemporal_load((const W *)(val + e));
-        const W v1 = __builtin_nontemporal_load((const W *)(val + e + 4));
-        const t2_u4 ce = __builtin_nontemporal_load((const t2_u4 *)(code + f));
-        const W w0 = __builtin_nontemporal_load((const W *)(val + f));
-        const W w1 = __builtin_nontemporal_load((const W *)(val + f + 4));
-        mul(cd, v0, v1, e);
-        mul(ce, w0, w1, f);
-    }
-    if (g < g1) {
-        const uint64_t e = a0 + g * 8;
-        const t2_u4 cd = __builtin_nontemporal_load((const t2_u4 *)(code + e));
-        const W v0 = __builtin_nontemporal_load((const W *)(val + e));
-        const W v1 = __builtin_nontemporal_load((const W *)(val + e + 4));
-        mul(cd, v0, v1, e);
+    const uint64_t chunks = (a1 - a0) / E;  // 16-byte pieces of the slice's values
+    const uint64_t per = (chunks + parts - 1) / parts;
+    const uint64_t k0 = (uint64_t)part * per, k1 = k0 + per < chunks ? k0 + per : chunks;
+    const V *vv = (const V *)(val + a0);
+    const C *cc = (const C *)(code + a0);
+    V *pp = (V *)(prod + a0);
+    for (uint64_t k = k0 + threadIdx.x; k < k1; k += (uint64_t)kT2ExpandThreads * U) {
+        V v[U];
+        C c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // unconditional loads from a clamped index; the store decides
+            const uint64_t q = k + (uint64_t)u * kT2ExpandThreads;
+            const uint64_t qe = q < k1 ? q : k1 - 1;
+            v[u] = __builtin_nontemporal_load(vv + qe);
+            c[u] = __builtin_nontemporal_load(cc + qe);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t q = k + (uint64_t)u * kT2ExpandThreads;
+            // plain stores: non-temporal ones cost 30 % here on f64 (profiles/r02_t2d_probe.log)
+            if (q < k1) pp[q] = L::mul(v[u], c[u], xs);
+        }
     }
 }
 

@@ -13,6 +13,9 @@
 #ifndef EXP_PIPE
 #define EXP_PIPE 0
 #endif
+#ifndef EXP_DIAG
+#define EXP_DIAG 0
+#endif
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -53,10 +56,22 @@ __global__ __launch_bounds__(1024) void k_expand(const T *__restrict__ x, uint64
     using W = typename V4<T>::t;
     auto mul = [&](const nu4 cd, const W v0, const W v1, uint64_t e) {
         W p0, p1;
+#if EXP_DIAG == 1  // timing only: conflict-free LDS reads instead of the gathers
+        const uint32_t q = (threadIdx.x * 8u + (uint32_t)(cd.x & 7u) * 0u) & (C - 1);
+        p0.x = v0.x * xs[q]; p0.y = v0.y * xs[q + 1]; p0.z = v0.z * xs[q + 2]; p0.w = v0.w * xs[q + 3];
+        p1.x = v1.x * xs[q + 4]; p1.y = v1.y * xs[q + 5]; p1.z = v1.z * xs[q + 6]; p1.w = v1.w * xs[q + 7 + (cd.w & 0u)];
+        *(W *)(prod + e) = p0;
+        *(W *)(prod + e + 4) = p1;
+        return;
+#endif
         p0.x = v0.x * xs[cd.x & 0xFFFF]; p0.y = v0.y * xs[cd.x >> 16];
         p0.z = v0.z * xs[cd.y & 0xFFFF]; p0.w = v0.w * xs[cd.y >> 16];
         p1.x = v1.x * xs[cd.z & 0xFFFF]; p1.y = v1.y * xs[cd.z >> 16];
         p1.z = v1.z * xs[cd.w & 0xFFFF]; p1.w = v1.w * xs[cd.w >> 16];
+#if EXP_DIAG == 2  // timing only: no stores (one conditional store keeps the products alive)
+        if (p0.x + p0.y + p0.z + p0.w + p1.x + p1.y + p1.z + p1.w == (T)12345.678) *(W *)(prod + e) = p0;
+        return;
+#endif
 #if NT_EXP
         __builtin_nontemporal_store(p0, (W *)(prod + e));
         __builtin_nontemporal_store(p1, (W *)(prod + e + 4));
