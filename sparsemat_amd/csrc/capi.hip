@@ -185,14 +185,14 @@ static bool wants_colblock(const smh_crs *m) {
     return m->n_cols * dtype_size(m->dtype) >= kColblockMinXBytes && m->span_fraction > 0.25 && b >= 2 && b <= 128;
 }
 
-// K2t is an option: not switched off, its copy was not refused, >= 32 entries per (slice, row block) tile, a tile table of <= 1 GiB
-static bool tiled_fits(const smh_crs *m) {
+// K2t is an option: not switched off, its copy was not refused, >= min_tile entries per (slice, row block) tile, a tile table of <= 1 GiB
+static bool tiled_fits(const smh_crs *m, double min_tile = 32.0) {
     static const bool tiled_off = getenv("SMH_TILED") && atoi(getenv("SMH_TILED")) == 0;  // tuning knob
     if (tiled_off || (m->t2_built && !m->t2_ok)) return false;
     uint32_t n_cb = 0, R = 0, n_rb = 0;
     tiled_geometry(m->n_rows, m->n_cols, m->nnz, m->dtype, &n_cb, &R, &n_rb);
     const double tile = (double)m->nnz / (double)n_cb / (double)n_rb;
-    return tile >= 32.0 && (double)(n_rb + 1) * (double)n_cb * 4.0 <= (double)(1u << 30);
+    return tile >= min_tile && (double)(n_rb + 1) * (double)n_cb * 4.0 <= (double)(1u << 30);
 }
 
 static int resolve_variant(const smh_crs *m, int variant) {
@@ -210,12 +210,18 @@ static int resolve_variant(const smh_crs *m, int variant) {
         const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
         const double similar = 2.0 * mean + 8.0 > 128.0 ? 2.0 * mean + 8.0 : 128.0;
         if ((double)m->max_row_len <= similar) {
-            // rows dense enough for >= 32 entries per (slice, row block) tile: the two streaming passes of K2t, whose gathers stay
-            // in LDS.  f32 (16 B per entry against CSR's 8): ahead of K2f on every shape measured, by 19-44 % (C2-uniform 1.21 ms
-            // against 1.90).  f64 (28 B against 12) where K2f is weak -- many column blocks to sweep (10 M columns, 39 blocks:
-            // 1.40 / 2.26 / 4.50 ms against 1.63 / 3.13 / 6.36 for rows of 16 / 32 / 64) or very few (1 M columns: 0.17 / 0.31
-            // against 0.25 / 0.61) -- but not in between (4 M columns x 16: 0.61 against 0.50) -- profiles/r02_tiled_crossover.log
-            if (tiled_fits(m) && (m->dtype == SMH_F32 || cf_blocks_for(m) >= 24 || cf_blocks_for(m) <= 4)) return SMH_SPMV_TILED;
+            // the two streaming passes of K2t, whose gathers stay in LDS (profiles/r02_tiled_crossover.log, 1-10 M rows x 8-64):
+            // f32 (16 B per entry against CSR's 8): ahead of K2f on every shape measured, by 22-63 % (C2-uniform 1.19 ms against
+            // 1.90).  f64 (28 B against 12): ahead wherever K2f has many column blocks to sweep (10 M columns = 39 blocks, rows
+            // of 8 / 16 / 32 / 64: 0.77 / 1.08 / 1.99 / 4.01 ms against 0.99 / 1.63 / 3.13 / 6.36) or very few (1 M columns: 0.14 /
+            // 0.26 against 0.25 / 0.62); in between ahead or level for rows of >= 16 (4 M x 32: 0.81 against 0.95; 2 M / 4 M x 16
+            // level) and behind for rows of 8 (4 M: 0.31 against 0.28)
+            const size_t blocks = cf_blocks_for(m);
+            const bool pays = m->dtype == SMH_F32 ? tiled_fits(m)
+                              : m->no_split       ? false  // (the parts of a K2s split stay as measured)
+                              : blocks >= 24      ? tiled_fits(m, 12.0)
+                                                  : (blocks <= 4 || mean >= 12.0) && tiled_fits(m);
+            if (pays) return SMH_SPMV_TILED;
             return SMH_SPMV_COLFUSED;
         }
         // skewed rows: K2t cuts its row blocks by entries, so long rows cost it nothing special -- on f64 with many column blocks
