@@ -32,6 +32,14 @@ constexpr int kT2ExpandThreads = 1024;
 constexpr int kT2Waves = 4;            // wavefronts (row blocks) per workgroup of the reduce pass
 constexpr int kT2Batch = 8;            // tiles whose loads are in flight together
 constexpr double kT2TileTarget = 48.0; // mean entries per tile (one per lane; a longer tile takes a slow second round)
+// tuning knob SMH_TILED_TILE: another target (16..64)
+static double t2_tile_target() {
+    if (const char *e = getenv("SMH_TILED_TILE")) {
+        const double v = atof(e);
+        if (v >= 16.0 && v <= 64.0) return v;
+    }
+    return kT2TileTarget;
+}
 
 typedef float t2_f4 __attribute__((ext_vector_type(4)));
 typedef double t2_d2 __attribute__((ext_vector_type(2)));
@@ -317,7 +325,7 @@ void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_
     // share 48 KiB of LDS
     const double per_row_and_slice = n_rows ? (double)nnz / (double)n_rows / (double)*n_cb : 0.0;
     const uint32_t cap = dtype == SMH_F64 ? 1280u : 3072u;  // rows whose sums one wavefront keeps in LDS (see build_t)
-    double r = per_row_and_slice > 0.0 ? kT2TileTarget / per_row_and_slice : (double)cap;
+    double r = per_row_and_slice > 0.0 ? t2_tile_target() / per_row_and_slice : (double)cap;
     if (r > (double)cap) r = (double)cap;
     if (r < 1.0) r = 1.0;
     *R = (uint32_t)r;
@@ -342,7 +350,7 @@ static int build_t(::smh_crs *m) {
             const int v = atoi(e);
             if (v >= 1 && v <= 8192) cap = (uint32_t)v;
         }
-        const uint64_t per_block = (uint64_t)(kT2TileTarget * (double)n_cb);
+        const uint64_t per_block = (uint64_t)(t2_tile_target() * (double)n_cb);
         std::vector<uint32_t> h_off(m->n_rows + 1);
         SMH_HIP(hipMemcpyAsync(h_off.data(), m->d_off, h_off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         SMH_HIP(hipStreamSynchronize(s));
