@@ -49,7 +49,7 @@ template <typename T> struct T2Lane;
 template <> struct T2Lane<float> {
     using V = t2_f4;
     using C = t2_u2;
-    static constexpr int kEntries = 4, kUnroll = 4;
+    static constexpr int kEntries = 4, kUnroll = 2;
     static __device__ __forceinline__ V mul(V v, C c, const float *xs) {
         V p;
         p.x = v.x * xs[c.x & 0xFFFF]; p.y = v.y * xs[c.x >> 16];
@@ -60,7 +60,7 @@ template <> struct T2Lane<float> {
 template <> struct T2Lane<double> {
     using V = t2_d2;
     using C = uint32_t;
-    static constexpr int kEntries = 2, kUnroll = 8;
+    static constexpr int kEntries = 2, kUnroll = 2;
     static __device__ __forceinline__ V mul(V v, C c, const double *xs) {
         V p;
         p.x = v.x * xs[c & 0xFFFF]; p.y = v.y * xs[c >> 16];
@@ -71,10 +71,10 @@ template <> struct T2Lane<double> {
 // ---- pass 1 ---------------------------------------------------------------------------------------------------------
 // grid = slices * parts; cb_ptr[b] = first entry of slice b in the copy (multiples of 8 entries: segments are padded with
 // zero-valued entries of code 0).  Every load and store instruction of a wavefront covers ONE contiguous kilobyte (a lane
-// takes 16 bytes of values -- 4 f32 / 2 f64 entries -- and their codes, the next lane the next 16): with a lane owning 8
+// takes 16 bytes of values -- 4 f32 / 2 f64 entries -- and their codes, the next lane the next 16; two such pieces in flight): with a lane owning 8
 // consecutive entries instead, a 16-byte load used a quarter (f64) or half (f32) of every line it touched and the read
 // side alone ran at 3.6 TB/s on f64 (profiles/r02_t2d_probe.log)
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(kT2ExpandThreads) void k_t2_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
                                                                  const uint16_t *__restrict__ code, const uint64_t *__restrict__ cb_ptr,
                                                                  T *__restrict__ prod, uint32_t parts) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kT2ExpandThreads) void k_t2_expand(const T *__restr
     using L = T2Lane<T>;
     using V = typename L::V;
     using C = typename L::C;
-    constexpr int E = L::kEntries, U = L::kUnroll;
+    constexpr int E = L::kEntries;
     const uint64_t a0 = cb_ptr[cb], a1 = cb_ptr[cb + 1];
     const uint64_t chunks = (a1 - a0) / E;  // 16-byte pieces of the slice's values
     const uint64_t per = (chunks + parts - 1) / parts;
@@ -435,7 +435,9 @@ static int build_t(::smh_crs *m) {
     SMH_HIP(hipGetLastError());
     SMH_HIP(hipStreamSynchronize(s));
     // 128 KiB of dynamic LDS (f64) need the attribute on every device the kernel runs on: set with each build, on the matrix's device
-    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
+    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
+    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
+    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
     m->t2_n_cb = n_cb;
     m->t2_n_rb = n_rb;
     m->t2_R = R;
@@ -470,9 +472,15 @@ int tiled_build(::smh_crs *m) {
 template <typename T>
 static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
     const size_t lds1 = (size_t)kT2Slice * sizeof(T), lds2 = (size_t)kT2Waves * m->t2_R * sizeof(T);
-    uint32_t parts = (2500 + m->t2_n_cb - 1) / m->t2_n_cb;
+    // ~4800 workgroups, two 16-byte pieces per thread in flight (profiles/r02_tiled_pass1.log: pieces 2 / 4 / 8 / 16 x parts 3 ... 24 on
+    // C2-uniform and C3 -- fewer pieces and 8 parts per slice win: 1.14 ms / 2.17 ms against 1.22 / 2.32 with 8 pieces and 5 parts)
+    uint32_t parts = (4800 + m->t2_n_cb - 1) / m->t2_n_cb;
+    int unroll = T2Lane<T>::kUnroll;
+    if (const char *e = getenv("SMH_TILED_PARTS")) { const int v = atoi(e); if (v >= 1) parts = (uint32_t)v; }      // tuning knobs
+    if (const char *e = getenv("SMH_TILED_UNROLL")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) unroll = v; }
     parts = parts < 1 ? 1 : (parts > 32 ? 32 : parts);
-    hipLaunchKernelGGL(k_t2_expand<T>, dim3(m->t2_n_cb * parts), dim3(kT2ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val,
+    auto *kern = unroll == 4 ? k_t2_expand<T, 4> : unroll == 8 ? k_t2_expand<T, 8> : k_t2_expand<T, 2>;
+    hipLaunchKernelGGL(kern, dim3(m->t2_n_cb * parts), dim3(kT2ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val,
                        m->d_t2_code, m->d_t2_cbptr, (T *)m->d_t2_prod, parts);
     SMH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_t2_reduce<T>, dim3((m->t2_n_rb + kT2Waves - 1) / kT2Waves), dim3(kT2Waves * 64), lds2, s, (const T *)m->d_t2_prod, m->d_t2_row,
