@@ -210,17 +210,14 @@ static int resolve_variant(const smh_crs *m, int variant) {
         const double mean = m->n_rows ? (double)m->nnz / (double)m->n_rows : 0.0;
         const double similar = 2.0 * mean + 8.0 > 128.0 ? 2.0 * mean + 8.0 : 128.0;
         if ((double)m->max_row_len <= similar) {
-            // the two streaming passes of K2t, whose gathers stay in LDS (profiles/r02_tiled_crossover.log, 1-10 M rows x 8-64):
-            // f32 (16 B per entry against CSR's 8): ahead of K2f on every shape measured, by 22-63 % (C2-uniform 1.19 ms against
-            // 1.90).  f64 (28 B against 12): ahead wherever K2f has many column blocks to sweep (10 M columns = 39 blocks, rows
-            // of 8 / 16 / 32 / 64: 0.77 / 1.08 / 1.99 / 4.01 ms against 0.99 / 1.63 / 3.13 / 6.36) or very few (1 M columns: 0.14 /
-            // 0.26 against 0.25 / 0.62); in between ahead or level for rows of >= 16 (4 M x 32: 0.81 against 0.95; 2 M / 4 M x 16
-            // level) and behind for rows of 8 (4 M: 0.31 against 0.28)
+            // the two streaming passes of K2t, whose gathers stay in LDS: ahead of K2f on every shape measured (1-10 M rows x 8-64
+            // entries, profiles/r02_tiled_crossover.log) -- f32 (16 B per entry against CSR's 8) by 31-66 % (C2-uniform 1.14 ms against
+            // 1.90), f64 (28 B against 12) by 13-66 % (10 M columns, rows of 8 / 16 / 32 / 64: 0.71 / 1.06 / 1.99 / 3.63 ms against 1.00 /
+            // 1.63 / 3.13 / 6.36; 4 M x 16: 0.44 against 0.50).  Needs >= 32 entries per tile (>= 12 measured on f64 with 39 blocks)
             const size_t blocks = cf_blocks_for(m);
             const bool pays = m->dtype == SMH_F32 ? tiled_fits(m)
                               : m->no_split       ? false  // (the parts of a K2s split stay as measured)
-                              : blocks >= 24      ? tiled_fits(m, 12.0)
-                                                  : (blocks <= 4 || mean >= 12.0) && tiled_fits(m);
+                                                  : tiled_fits(m, blocks >= 24 ? 12.0 : 32.0);
             if (pays) return SMH_SPMV_TILED;
             return SMH_SPMV_COLFUSED;
         }

@@ -472,9 +472,11 @@ int tiled_build(::smh_crs *m) {
 template <typename T>
 static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
     const size_t lds1 = (size_t)kT2Slice * sizeof(T), lds2 = (size_t)kT2Waves * m->t2_R * sizeof(T);
-    // ~4800 workgroups, two 16-byte pieces per thread in flight (profiles/r02_tiled_pass1.log: pieces 2 / 4 / 8 / 16 x parts 3 ... 24 on
-    // C2-uniform and C3 -- fewer pieces and 8 parts per slice win: 1.14 ms / 2.17 ms against 1.22 / 2.32 with 8 pieces and 5 parts)
-    uint32_t parts = (4800 + m->t2_n_cb - 1) / m->t2_n_cb;
+    // a workgroup pays for staging its slice of x (16384 entries), so it should multiply several times as many entries: ~65 000 per
+    // workgroup, two 16-byte pieces per thread in flight (profiles/r02_tiled_pass1.log: C2-uniform / C3 with 8 parts per slice 1.14 /
+    // 2.17 ms against 1.22 / 2.32 with 5 parts and 8 pieces; 2 M rows x 16 f64 with 2 / 4 / 8 / 32 parts 0.208 / 0.216 / 0.227 / 0.319)
+    const uint64_t per_slice = m->t2_tot / (m->t2_n_cb ? m->t2_n_cb : 1);
+    uint32_t parts = (uint32_t)((per_slice + 32768) / 65536);
     int unroll = T2Lane<T>::kUnroll;
     if (const char *e = getenv("SMH_TILED_PARTS")) { const int v = atoi(e); if (v >= 1) parts = (uint32_t)v; }      // tuning knobs
     if (const char *e = getenv("SMH_TILED_UNROLL")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) unroll = v; }

@@ -133,7 +133,7 @@ def test_auto_picks_colblock_only_without_column_locality(gpu):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 def test_cg_on_a_matrix_without_locality_runs_colblock(gpu, dtype):
     """A randomly permuted 7-point Laplacian (SPD, 1.33 M rows: 10.6 MB of f64 x, columns all over it) resolves to
-    K2f -- in f32 (5.3 MB of x) to the 2-D tiled passes, K2t; the device-resident CG (hipGraph replay of those launches)
+    the 2-D tiled passes, K2t (before it: K2f); the device-resident CG (hipGraph replay of those launches)
     follows the oracle's iterates (f32: within the drift of 40 unconverged iterations whose sums are ordered differently)."""
     g = 110
     n = g ** 3
@@ -149,10 +149,9 @@ def test_cg_on_a_matrix_without_locality_runs_colblock(gpu, dtype):
     gather = np.repeat(src - off_p[:-1].astype(np.int64), lens_p) + np.arange(int(off_p[-1]))
     col_p, val_p = perm[col[gather]], val[gather]
     m = sm.SparseMatCRS.from_raw_parts(n, n, off_p, col_p, val_p)
+    assert m.resolved_variant()[0] == "tiled" and m.tiled_layout()["n_slices"] == 82  # before K2t: K2f ...
     if dtype == np.float64:
-        assert m.resolved_variant()[0] == "colfused" and m.colfused(arrays=False)["n_blocks"] == 6  # 2^18 columns of f64 each
-    else:
-        assert m.resolved_variant()[0] == "tiled" and m.tiled_layout()["n_slices"] == 82
+        assert m.colfused(arrays=False)["n_blocks"] == 6  # ... over 2^18 columns of f64 each
     b = oracle.spmv(off_p, col_p, val_p, np.ones(n, dtype))
     iters = 40
     x_ref, it_ref, rr_ref = oracle.cg(n, n, off_p, col_p, val_p, b, np.zeros(n, dtype), tol=1e-30, iter_max=iters)
