@@ -343,8 +343,8 @@ static int build_t(::smh_crs *m) {
     // `cap` rows each (their sums share the LDS); greedy over the row offsets, on the host
     std::vector<uint32_t> rb_start;
     {
-        // f32: 3072 rows (12 KiB of sums per wavefront); f64: 1280 (10 KiB: 16 wavefronts per CU) -- C3 2.70 / 2.57 / 2.54 / 2.58 ms
-        // with 1536 / 1280 / 1024 / 768, 10 M x 16 uniform 1.35 / 1.29 / 1.39 / 1.49 (profiles/r02_tiled_cap.log)
+        // f32: 3072 rows (12 KiB of sums per wavefront); f64: 1280 (10 KiB: 16 wavefronts per CU) -- C3 2.31 / 2.15 / 2.19 / 2.18 ms
+        // with 1536 / 1280 / 1024 / 768, 10 M x 16 uniform 1.11 / 1.02 / 1.13 / 1.21 (profiles/r02_tiled_cap.log)
         uint32_t cap = sizeof(T) == 8 ? 1280u : 3072u;
         if (const char *e = getenv("SMH_TILED_CAP")) {  // tuning knob: most rows of a row block
             const int v = atoi(e);
