@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over the resident matrix: y = A.x with A, x, y in HBM.
-  N = 1  BASELINE configs[1]: SparseMatCRS<f32,u32>, 10,000,000 rows, 32 nnz/row, banded-stratified
-         columns (DESIGN.md "Synthetic inputs"), kernel chosen by SMH_SPMV_AUTO (K1r, lanes 8).
+  N = 1  BASELINE configs[1]: SparseMatCRS<f32,u32>, 10,000,000 rows, 32 nnz/row, SURVEY 8d's primary pattern
+         to the letter (--pattern window, the default: 32 distinct columns drawn without replacement from
+         [i-4096, i+4096], stored ascending; DESIGN.md "Synthetic inputs"), kernel chosen by AUTO (K1r,
+         lanes 8).  `other_pattern` carries the kernel time of the stratified subset (one column per 256-wide
+         stratum: what rounds 1-2 put the headline on) measured in the same process.
   N > 1  weak scaling, BASELINE configs[4] shape: block b owns rows [b*10M, (b+1)*10M) of an (N*10M)-row
          matrix with global columns (SparseMatPar), step = local SpMV into the block's slice of y + ONE
          exchange INSIDE libsparsemat_hip.so (csrc/par.hip) that makes y usable as the next x on every GPU:
@@ -28,7 +31,8 @@ the launch stream): `frac` = algorithmic bytes / mean kernel time / 8 TB/s as th
 FETCH_SIZE with the gfx950 factor CALIBRATED in the same pass on an element-wise kernel of known traffic,
 + WRITE_SIZE) / mean kernel time / 8 TB/s -- the physical fraction; the kernel streams 16-bit ring-slot
 columns, so it moves fewer bytes than the CSR arrays hold.  `cold` = the same launch after a 512 MiB
-flush of L2 + Infinity Cache.  `cpu_baseline` is the CPU oracle (oracle/, the reference's algorithm
+flush of L2 + Infinity Cache.  Should an optional N > 1 leg (exchange self-check, all-gather leg) hang, the
+line is still printed, naming the leg, and every rank exits with status 3.  `cpu_baseline` is the CPU oracle (oracle/, the reference's algorithm
 restated in C: the reference is Rust and cannot be built here), ONE thread like the reference, timed on
 this host in this run; `cpu_baseline_all_cores` is the same loop spread over all cores with OpenMP --
 NOT reference behaviour, reported so that the GPU/CPU ratio is not inflated by the reference being serial.
@@ -56,6 +60,7 @@ KERNEL_SUBSTR = "k_spmv_ring"
 CALIB_SUBSTR = "k_ew"       # the element-wise kernel the PMC child pass runs for calibration
 CALIB_N = 1 << 26           # x += y on 2^26 f32: reads 2 x 256 MiB, writes 256 MiB, 16 B per lane
 FLUSH_BYTES = 512 << 20
+WATCHDOG_EXIT = 3           # exit status of every rank when an optional N > 1 leg hung (the headline line is still printed)
 
 
 def algorithmic_bytes(rows, nnz, x_ref):
@@ -76,7 +81,7 @@ def pmc_traffic(args):
             d = tempfile.mkdtemp(prefix="smh_pmc_", dir="/tmp")
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--child", "--steps", "3", "--warmup", "1",
-                   "--rows", str(args.rows)]
+                   "--rows", str(args.rows), "--pattern", args.pattern]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
             vals, cal = [], []
@@ -133,14 +138,14 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(rows, x_host, y_gpu_host):
+def cpu_baseline(rows, x_host, y_gpu_host, pattern):
     """Reference algorithm on one host core (the oracle), same workload, plus the parity gate; and the same loop on all
     cores (OpenMP), which is NOT what the reference does."""
     import numpy as np
     import oracle
     from sparsemat_amd import synth
     t0 = time.time()
-    off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, rows, NNZ_PER_ROW, np.float32)
+    off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, pattern, rows, NNZ_PER_ROW, np.float32)
     gen_s = time.time() - t0
 
     def med5(fn):
@@ -213,7 +218,7 @@ class Events:
         return out
 
 
-def exchange_check(lib, check, synth, np, par, x, y, n, comm):
+def exchange_check(lib, check, synth, np, par, x, y, n, comm, pattern):
     """N > 1, after a step: every local block holds, next to its own slice of y, the entries it RECEIVED in the exchange.
     It can generate any rows of the synthetic matrix and x is complete on every device, so it multiplies the 64 rows on
     either side of its slice itself (bit-exact K1s kernel) and compares them with what arrived.  A missing or stale halo
@@ -226,7 +231,7 @@ def exchange_check(lib, check, synth, np, par, x, y, n, comm):
             for ra, rb in ((max(0, r0 - 64), r0), (r1, min(n, r1 + 64))):
                 if ra >= rb:
                     continue
-                small = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, ra, rb)
+                small = synth.crs_fixed(synth.SEED_MATRIX, pattern, n, NNZ_PER_ROW, np.float32, ra, rb)
                 out = synth.DeviceBuffer((rb - ra) * 4)
                 small.mvp_dev(x.ptr(b), n, out.ptr, "stream")
                 check(lib.smh_device_synchronize())
@@ -296,6 +301,10 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "window", "halo", "allgather"],
                     help="N>1: what a step exchanges after the local SpMV (auto: only the vector entries each "
                          "block references when that is less than half of the vector, else the all-gather)")
+    ap.add_argument("--pattern", default="window", choices=["window", "stratified"],
+                    help="column pattern of the synthetic matrix: 'window' = SURVEY 8d's primary workload to the letter (32 distinct "
+                         "columns drawn without replacement from [i-4096, i+4096], stored ascending); 'stratified' = the easier-to-plan "
+                         "subset of it the rounds before measured (one column per 256-wide stratum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # rocprofv3 --pmc child pass
@@ -335,6 +344,9 @@ def main():
 
     rows = args.rows
     n = rows * n_gpus
+    pattern = synth.PATTERN_WINDOW if args.pattern == "window" else synth.PATTERN_BANDED
+    pattern_text = ("columns drawn without replacement from [i-4096, i+4096], ascending" if args.pattern == "window"
+                    else "banded-stratified columns (one per 256-wide stratum of [i-4096, i+4096))")
     band = min(n, 256 * NNZ_PER_ROW)
     exchange_req = "window" if args.exchange == "halo" else args.exchange
     comm = par = None
@@ -345,7 +357,7 @@ def main():
     force_par = os.environ.get("SMH_BENCH_FORCE_PAR") == "1"
     if n_gpus == 1 and not force_par:
         check(lib.smh_set_device(local_rank if launched else 0))
-        mat = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32)
+        mat = synth.crs_fixed(synth.SEED_MATRIX, pattern, n, NNZ_PER_ROW, np.float32)
         blocks = [mat]
         xbuf, xptr = synth.gen_x(synth.SEED_X, n, np.float32)
         ybuf = synth.DeviceBuffer(n * 4)
@@ -370,13 +382,13 @@ def main():
             check(lib.smh_set_device(local_rank % n_dev.value if share else local_rank))
             uid, rdzv_path = rendezvous_id(rank, sm.Comm.unique_id)
             comm = sm.Comm(uid, world, rank)  # ncclCommInitRank: collective
-            blocks = [synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, rank * rows, (rank + 1) * rows)]
+            blocks = [synth.crs_fixed(synth.SEED_MATRIX, pattern, n, NNZ_PER_ROW, np.float32, rank * rows, (rank + 1) * rows)]
             par = sm.SparseMatParLocal.for_rank(comm, n, blocks[0])
         else:
             blocks = []
             for d in range(n_gpus):
                 check(lib.smh_set_device(d % n_dev.value))
-                blocks.append(synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, NNZ_PER_ROW, np.float32, d * rows, (d + 1) * rows))
+                blocks.append(synth.crs_fixed(synth.SEED_MATRIX, pattern, n, NNZ_PER_ROW, np.float32, d * rows, (d + 1) * rows))
             check(lib.smh_set_device(0))
             par = sm.SparseMatParLocal.adopt(blocks, n)
         mat = blocks[0]
@@ -451,26 +463,51 @@ def main():
         cold = stats(cev.times_ms())
         del flush
 
+    # rides along (N = 1, plain path): the other column pattern on the same box in the same process -- the rounds before this
+    # one put the headline on the stratified subset of SURVEY 8d's window matrices; both numbers stay visible
+    other = None
+    if n_gpus == 1 and par is None and os.environ.get("SMH_BENCH_NO_OTHER_PATTERN") != "1":
+        o_name = "stratified" if args.pattern == "window" else "window"
+        o_mat = synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED if args.pattern == "window" else synth.PATTERN_WINDOW,
+                                n, NNZ_PER_ROW, np.float32)
+        for _ in range(3):
+            o_mat.mvp_dev(xptr, n, yptr, args.variant, stream=stream)
+        oev = Events(lib, check, 20)
+        for i in range(20):
+            oev.start(i, stream)
+            o_mat.mvp_dev(xptr, n, yptr, args.variant, stream=stream)
+            oev.stop(i, stream)
+        sync()
+        o = stats(oev.times_ms())
+        other = {"pattern": o_name, "kernel_ms": o["mean"], "kernel_ms_median": o["median"], "kernel_ms_min": o["min"],
+                 "kernel_ms_max": o["max"], "launches": o["launches"],
+                 "frac": bytes_gpu / (o["mean"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "kernel": "%s lanes=%d" % o_mat.resolved_variant()}
+        del o_mat
+        if not args.no_cpu_baseline:  # y of the headline matrix for the parity gate below
+            spmv()
+            sync()
+
     ms_per_step = elapsed / args.steps * 1e3
     value = bytes_gpu * n_gpus / (elapsed / args.steps) / 1e9
     kernel_ms = kernel["mean"]
     achieved = bytes_gpu / (kernel_ms * 1e-3) / 1e9
     traffic_rate = (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None
     if n_gpus == 1:
-        workload = "f32 CSR SpMV, %d rows x %d nnz/row, banded-stratified columns, 1xMI355X" % (rows, NNZ_PER_ROW)
+        workload = "f32 CSR SpMV, %d rows x %d nnz/row, %s, 1xMI355X" % (rows, NNZ_PER_ROW, pattern_text)
         parallelism = "single GPU"
     else:
         how = "one process per GPU (ncclCommInitRank)" if launched else "one process, %d devices (%s)" % (
             n_gpus, "ncclCommInitAll" if backend == "rccl" else "peer reads")
-        workload = ("f32 CSR SpMV, %d rows (%d per GPU) x %d nnz/row, banded-stratified columns, row-partitioned over %d GPUs, "
-                    "exchange of y per step inside libsparsemat_hip.so: %s over %s, %s" % (n, rows, NNZ_PER_ROW, n_gpus, exchange_mode, backend, how))
+        workload = ("f32 CSR SpMV, %d rows (%d per GPU) x %d nnz/row, %s, row-partitioned over %d GPUs, "
+                    "exchange of y per step inside libsparsemat_hip.so: %s over %s, %s" % (n, rows, NNZ_PER_ROW, pattern_text, n_gpus, exchange_mode, backend, how))
         parallelism = "rows/%d + %s exchange (%s)" % (n_gpus, exchange_mode, backend)
     result = {
         "metric": "csr_spmv_effective_hbm_GBps", "value": value, "unit": "GB/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": workload, "rows_per_gpu": rows, "nnz_per_gpu": nnz, "index": "u32",
+            "workload": workload, "pattern": args.pattern, "rows_per_gpu": rows, "nnz_per_gpu": nnz, "index": "u32",
             "kernel": "%s lanes=%d ring=%s (ring rows %.3f)" % (variant, lanes, ring_active, ring_frac),
             "parallelism": parallelism, "exchange": exchange_mode, "exchange_backend": backend,
             "launch": "torch.distributed.run, one process per GPU" if launched else ("one process" if n_gpus > 1 else "single process"),
@@ -506,21 +543,30 @@ def main():
             "layout": "f32 values + 16-bit ring-slot columns for LDS-ring phases (u32 columns kept for the rest)",
         },
     }
+    if other is not None:
+        result["other_pattern"] = other
     # The optional legs of an N > 1 run come AFTER the headline is complete, under a watchdog: should one of them hang (it is
-    # the first time this code meets a real multi-GPU node), every rank gives up after 180 s (SMH_BENCH_WATCHDOG_S), rank 0 prints the line without
-    # them and all exit with status 0 -- the measured headline is never lost to an extra.
+    # the first time this code meets a real multi-GPU node), every rank gives up after 180 s (SMH_BENCH_WATCHDOG_S), rank 0 prints the
+    # line without them (naming the leg that hung) and every rank exits with status 3: the measured headline is never lost to an
+    # extra, and a hung collective never looks like success.
     watchdog = None
     if par is not None and n_gpus > 1:
         import threading
 
         patience = float(os.environ.get("SMH_BENCH_WATCHDOG_S", "180"))
 
+        leg = {"name": "exchange_check"}
+
         def give_up():
+            sys.stderr.write("bench.py: rank %d: optional leg '%s' did not finish within %g s -- exit status %d\n" % (
+                rank, leg["name"], patience, WATCHDOG_EXIT))
             if rank == 0:
                 result["cpu_baseline"] = None
-                result["optional_legs"] = "gave up after %g s (exchange_check / allgather_leg did not finish)" % patience
+                result["optional_legs"] = "gave up after %g s in '%s' (a GPU / collective hang: exit status %d)" % (
+                    patience, leg["name"], WATCHDOG_EXIT)
+                result["hung_leg"] = leg["name"]
                 os.write(json_fd, (json.dumps(result) + "\n").encode())
-            os._exit(0)
+            os._exit(WATCHDOG_EXIT)
         watchdog = threading.Timer(patience, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -528,10 +574,11 @@ def main():
     if par is not None and n_gpus > 1:
         if os.environ.get("SMH_BENCH_HANG_IN_LEGS") == "1":  # test knob: what the watchdog is for
             time.sleep(10 ** 6)
-        xcheck = exchange_check(lib, check, synth, np, par, x, y, n, comm)  # (collective: every rank calls it)
+        xcheck = exchange_check(lib, check, synth, np, par, x, y, n, comm, pattern)  # (collective: every rank calls it)
         # BASELINE configs[4] names the all-gather of the dense vector: when AUTO chose the cheaper window exchange, the same
         # K steps are timed once more with the in-place all-gather and reported beside the headline (never instead of it)
         if exchange_mode != "allgather" and os.environ.get("SMH_BENCH_NO_ALLGATHER_LEG") != "1":
+            leg["name"] = "allgather_leg"
             try:
                 for _ in range(min(args.warmup, 2) + 1):
                     spmv()
@@ -548,7 +595,7 @@ def main():
                 allgather_leg = {"exchange": "allgather", "ms_per_step": el / args.steps * 1e3,
                                  "value": bytes_gpu * n_gpus / (el / args.steps) / 1e9, "unit": "GB/s",
                                  "received_bytes_per_gpu_step": (n - rows) * 4,
-                                 "exchange_check": exchange_check(lib, check, synth, np, par, x, y, n, comm)}
+                                 "exchange_check": exchange_check(lib, check, synth, np, par, x, y, n, comm, pattern)}
             except Exception as e:
                 allgather_leg = {"exchange": "allgather", "error": "%s: %s" % (type(e).__name__, e)}
 
@@ -564,7 +611,7 @@ def main():
                 x_host, y_host = xbuf.download(np.float32, n), ybuf.download(np.float32, n)
             else:  # (SMH_BENCH_FORCE_PAR: the partitioned path with one block)
                 x_host, y_host = x.download_block(0), y.download()
-            one, allc = cpu_baseline(rows, x_host, y_host)
+            one, allc = cpu_baseline(rows, x_host, y_host, pattern)
             result["cpu_baseline"], result["cpu_baseline_all_cores"] = one, allc
         else:
             result["cpu_baseline"] = None

@@ -258,15 +258,29 @@ int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_b
                      uint32_t *columns_out, void *values_out);
 
 /* K2t, the 2-D tiled copy (built on first use of SMH_SPMV_TILED; spmv_tiled.hip): the entries by column slice of
- * *slice_columns_out (16384) columns, within a slice by (row, storage order), each slice padded to a multiple of 8 entries
- * (*copy_entries_out in total); the rows in *n_row_blocks_out blocks of consecutive rows cut so that each holds the same
- * number of entries -- about 48 per (slice, row block) tile -- and at most *rows_per_block_out rows (the largest block).  y = A x then takes two streaming passes: products against the slice of x held in LDS, and one
- * wavefront per row block folding its tiles slice by slice.  The sum of a row is therefore taken per slice (storage order
- * inside, slices ascending): within the parity bound, bitwise reproducible, not bit-identical to the reference's order.
- * Memory: the copy (sizeof(T) + 4 bytes per entry), the products of the last launch (sizeof(T) per entry) and a table of
- * (n_row_blocks + 1) x n_slices u32 (beyond 4 GiB: SMH_ERR_INVALID).  Any out pointer may be NULL. */
+ * *slice_columns_out (16384) columns, within a slice by (row, storage order), cut into chunks of at most 64 E entries (E = 4 for
+ * f32, 2 for f64: 16 bytes of values per lane) that start at row boundaries where one lies within 16 entries of the nominal
+ * start; every chunk owns 64 E slots of the copy (*copy_entries_out slots in total, the unused ones zero).  Pass 1 multiplies a
+ * chunk against the slice of x held in LDS and folds the entries of one row into one product sum, so a (row, slice) pair
+ * yields one product (more only where a chunk boundary cuts it): *n_products_out product slots (each chunk's share padded to
+ * 16 bytes).  The rows are cut into *n_row_blocks_out blocks of consecutive rows holding the same number of products -- about
+ * 174 (f32) / 60 (f64) per (slice, row block) tile -- and at most *rows_per_block_out rows (the largest block); pass 2: one
+ * wavefront per row block adds its tiles' products to wave-private row sums, slice by slice.  The sum of a row is therefore
+ * taken per slice (slices ascending; inside a slice the fold order documented at the top of spmv_tiled.hip): within the parity
+ * bound, bitwise reproducible, not bit-identical to the reference's storage-order fold.  A row's result can be -0.0 where the
+ * reference (which starts every row from +0.0, sparsematrix.rs:149) returns +0.0 -- only when every product of the row is -0.0;
+ * equal in value.  Memory: the copy (sizeof(T) + 2 bytes per slot), the products of the last launch (sizeof(T) + 2 bytes per
+ * product slot) and a table of (n_row_blocks + 1) x n_slices u32 (beyond 4 GiB: SMH_ERR_INVALID).  Any out pointer may be NULL. */
 int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_columns_out, uint32_t *rows_per_block_out,
-                         uint32_t *n_row_blocks_out, size_t *copy_entries_out);
+                         uint32_t *n_row_blocks_out, size_t *copy_entries_out, size_t *n_products_out);
+
+/* The arrays of that plan, for inspection (tests restate the build and the passes' summation order from them): `which` =
+ * 0 first chunk of each slice (u32, n_slices + 1) | 1 per chunk {first product slot, entries} (2 x u32) | 2 the copy's 16-bit
+ * codes (bit 15: same row as the entry before; bits 0-13: column within the slice) | 3 the copy's values | 4 per product slot:
+ * its row relative to its row block, or rows_per_block for padding (u16) | 5 first row of each row block (u32, n_row_blocks + 1)
+ * | 6 tile table: (n_row_blocks + 1) x n_slices first product slots (u32) | 7 the products of the last launch.  out == NULL: only
+ * *bytes_out is set. */
+int smh_crs_tiled_array(smh_crs *m, int which, void *out, size_t capacity_bytes, size_t *bytes_out);
 
 /* K2s, the row-length split (built on first use): *split_out == 1 when the handle keeps its rows of >= *min_long_out
  * entries as a compacted sub-matrix (row i of it = row long_rows_out[i], n_long of them; global columns) and all rows

@@ -71,7 +71,8 @@ SIGNATURES = {
     "smh_crs_ring_bands": (_int, [_vp, _u32p, _vp]),
     "smh_crs_ring_plan": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(C.c_double), C.POINTER(_int), _vp, _vp]),
     "smh_crs_set_colblock_shift": (_int, [_vp, C.c_uint32]),
-    "smh_crs_tiled_layout": (_int, [_vp, _u32p, _u32p, _u32p, _u32p, C.POINTER(_sz)]),
+    "smh_crs_tiled_layout": (_int, [_vp, _u32p, _u32p, _u32p, _u32p, C.POINTER(_sz), C.POINTER(_sz)]),
+    "smh_crs_tiled_array": (_int, [_vp, _int, _vp, _sz, C.POINTER(_sz)]),
     "smh_crs_colblock": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(_int), C.POINTER(C.c_double), _vp, _vp, _vp]),
     "smh_crs_colfused": (_int, [_vp, C.POINTER(_int), _u32p, C.POINTER(_sz), _u32p, C.POINTER(_sz), _vp, _vp, _vp, _vp, _vp]),
     "smh_crs_colsplit": (_int, [_vp, C.POINTER(_int), _u32p, C.POINTER(_sz), _vp, C.POINTER(_vp), C.POINTER(_vp)]),

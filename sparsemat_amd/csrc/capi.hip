@@ -416,9 +416,19 @@ static int ensure_stream_windows(smh_crs *m) {
     return SMH_OK;
 }
 
+// The column-blocked / tiled builders size their tables from n_cols and index them with col >> shift (col / slice): a handle
+// created without validation (smh_crs_create_dev's default) may hold columns >= n_cols, which would walk past those tables.
+// Every such build starts here (max_col is a create-time statistic: no per-call cost).
+int columns_within_n_cols(const smh_crs *m, const char *what) {
+    if (m->nnz && (size_t)m->max_col >= m->n_cols)
+        return fail(SMH_ERR_INDEX_RANGE, "%s: column index %u >= n_cols %zu", what, m->max_col, m->n_cols);
+    return SMH_OK;
+}
+
 // K2c: build the column-blocked copy, once per matrix
 static int ensure_colblock(smh_crs *m) {
     if (m->cb_built) return SMH_OK;
+    SMH_TRY(columns_within_n_cols(m, "column-blocked variant"));
     const size_t blocks = cb_blocks_for(m);
     if (blocks == 0 || blocks > 128)
         return fail(SMH_ERR_INVALID, "column-blocked variant: %zu column blocks (supported: 1..128)", blocks);
@@ -458,6 +468,7 @@ static int ensure_colblock(smh_crs *m) {
 // K2f: build the fused column-blocked copy, once per matrix (cf_ok == false afterwards: not describable -> K2c)
 static int ensure_colfused(smh_crs *m) {
     if (m->cf_built) return SMH_OK;
+    SMH_TRY(columns_within_n_cols(m, "fused column-blocked variant"));
     const size_t blocks = cf_blocks_for(m);
     if (blocks > 255) return fail(SMH_ERR_INVALID, "fused column-blocked variant: %zu column blocks (supported: 1..255)", blocks);
     uint32_t rt = 16;
@@ -481,6 +492,7 @@ constexpr uint32_t kSplitMinLong = 64;  // rows of this many entries and more fo
 static int finish_create(smh_crs *m, int validate);
 static int ensure_split(smh_crs *m) {
     if (m->split_built) return SMH_OK;
+    SMH_TRY(columns_within_n_cols(m, "row-length split"));
     m->split_built = true;
     m->split_ok = false;
     if (m->no_split || m->n_rows == 0 || m->nnz == 0) return SMH_OK;
@@ -724,12 +736,27 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
                                                dot_lhs, m->device, s);
             return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt,
                                       c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
-                                      // the staged chunks are 16-byte aligned pieces of x that each hold at least one valid entry: with x itself 16-byte
-                                      // aligned the last one may reach past x_len, but never past the 16-byte block (hence page) the last entry lies in
-                                      ((((x_len + 3) & ~(size_t)3) >= (size_t)m->stream_xs_end) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0);
+                                      // the staged chunks are groups of 4 entries of x fetched with 16-byte loads (f32: one load, f64: two, entries
+                                      // [g, g+2) and [g+2, g+4)); with x itself 16-byte aligned a load that holds at least one valid entry may reach past
+                                      // x_len but never past the 16-byte block (hence page, hence allocation granule) its valid entry lies in.  f32: the last
+                                      // chunk holds a valid entry when x_len rounded up to 4 reaches stream_xs_end; f64: its SECOND load starts at
+                                      // stream_xs_end - 2 and must hold a valid entry too (x_len >= stream_xs_end - 1), else the gathers stay global
+                                      (((m->dtype == SMH_F64 ? x_len + 1 : ((x_len + 3) & ~(size_t)3)) >= (size_t)m->stream_xs_end) &&
+                                       (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0);
         }
         case SMH_SPMV_COLSPLIT: {
-            SMH_TRY(ensure_split(m));
+            {
+                const int rc = ensure_split(m);
+                // AUTO chose this plan and its lazy build failed (scratch out of memory, ...): the plan is marked refused
+                // (split_built && !split_ok) and AUTO resolves again within this call -- K2c / K2f / K1 can still serve the product
+                if (rc != SMH_OK && variant == SMH_SPMV_AUTO && rc != SMH_ERR_INDEX_RANGE) {
+                    m->split_built = true;
+                    m->split_ok = false;
+                    g_err[0] = 0;
+                    return spmv_enqueue(m, x, x_len, y, variant, s, dot_partials, dot_lhs);
+                }
+                SMH_TRY(rc);
+            }
             if (m->split_ok) {
                 // The two parts lean on different resources (LONG: the L2 gather path; SHORT: HBM streams and latency), which
                 // suggests running LONG on a stream of its own beside SHORT (fork and join by events).  Measured on C3, one box:
@@ -767,9 +794,17 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
                                                  m->n_rows, m->nnz, m->cb_rpt, m->cb_single_pass, b > 0, s));
             return SMH_OK;
         }
-        case SMH_SPMV_TILED:
-            SMH_TRY(tiled_build(m));
+        case SMH_SPMV_TILED: {
+            const int rc = tiled_build(m);
+            // as above: a failed lazy build (K2t needs ~5 x 4 B x nnz of scratch, a copy of the entries and a product buffer)
+            // leaves t2_built && !t2_ok, which AUTO's rule reads as "does not fit" -- resolve again within this call
+            if (rc != SMH_OK && variant == SMH_SPMV_AUTO && rc != SMH_ERR_INDEX_RANGE && m->t2_built && !m->t2_ok) {
+                g_err[0] = 0;
+                return spmv_enqueue(m, x, x_len, y, variant, s, dot_partials, dot_lhs);
+            }
+            SMH_TRY(rc);
             return launch_spmv_tiled(m, x, x_len, y, s);
+        }
         case SMH_SPMV_MERGE:
             SMH_TRY(ensure_merge_ws(m));
             return launch_spmv_merge(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->n_tiles,
@@ -1255,7 +1290,7 @@ int smh_crs_scale(smh_crs *m, double a) {
 }
 
 int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_columns_out, uint32_t *rows_per_block_out, uint32_t *n_row_blocks_out,
-                         size_t *copy_entries_out) {
+                         size_t *copy_entries_out, size_t *n_products_out) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(tiled_build(m));
     if (!m->t2_ok) return fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
@@ -1264,7 +1299,15 @@ int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_col
     if (rows_per_block_out) *rows_per_block_out = m->t2_R;
     if (n_row_blocks_out) *n_row_blocks_out = m->t2_n_rb;
     if (copy_entries_out) *copy_entries_out = (size_t)m->t2_tot;
+    if (n_products_out) *n_products_out = (size_t)m->t3_n_prod;
     return SMH_OK;
+}
+
+int smh_crs_tiled_array(smh_crs *m, int which, void *out, size_t capacity_bytes, size_t *bytes_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(tiled_build(m));
+    if (!m->t2_ok) return fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
+    return tiled_array(m, which, out, capacity_bytes, bytes_out);
 }
 
 int smh_crs_set_colblock_shift(smh_crs *m, uint32_t shift) {

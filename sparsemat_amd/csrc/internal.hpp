@@ -160,7 +160,9 @@ int launch_crs_stats(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 // K2t (spmv_tiled.hip)
 void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *rows_per_block, uint32_t *n_rb);
 int tiled_build(::smh_crs *m);   // lazy; sets t2_ok
+int columns_within_n_cols(const ::smh_crs *m, const char *what);  // capi.hip: SMH_ERR_INDEX_RANGE when max_col >= n_cols
 void tiled_free(::smh_crs *m);
+int tiled_array(::smh_crs *m, int which, void *out, size_t capacity_bytes, size_t *bytes_out);
 int launch_spmv_tiled(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s);
 size_t spmv_fused_dot_partials(::smh_crs *m, size_t x_len, int variant, bool any_lhs = false);
 int spmv_enqueue(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, void *dot_partials = nullptr,
@@ -247,6 +249,10 @@ struct smh_crs {
     uint64_t *d_t2_cbptr = nullptr;        // first entry of each slice (n_cb + 1)
     uint32_t *d_t2_tstart = nullptr;       // (n_rb + 1) x n_cb tile starts, relative to the slice
     uint32_t *d_t2_rbstart = nullptr;      // first row of each row block (n_rb + 1); blocks hold equal entry counts
+    uint32_t *d_t3_cptr = nullptr;         // (round 3's form) first chunk of each slice (n_cb + 1)
+    void *d_t3_chunk = nullptr;            // per chunk {where its product sums go, entries}
+    uint32_t t3_n_chunks = 0;
+    uint64_t t3_n_prod = 0;                // product slots (one per (row, slice, chunk), chunk shares padded to 16 bytes)
     // K1r plan (lazy)
     bool ring_planned = false;
     unsigned ring_blocks = 0;

@@ -1,23 +1,36 @@
 // spmv_tiled.hip -- K2t: y = A x in two streaming passes over a 2-D tiled copy of A, for matrices whose columns have no
-// locality (BASELINE C2 "uniform", C3).  Replaces the reference loop sparsematrix.rs:146-158 for those matrices; the
-// sum of a row is taken slice by slice (ascending column slices, storage order within a slice), so the result agrees
-// with the reference within the rounding bound of DESIGN.md section 2, not bit for bit -- like K2c / K2f.
+// locality (BASELINE C2 "uniform", C3).  Replaces the reference loop sparsematrix.rs:146-158 (over sparsemat_crs.rs:102-110)
+// for those matrices.  The sum of a row is formed slice by slice (ascending column slices; inside a slice the order written
+// down under "ORDER" below), so the result agrees with the reference within the rounding bound of DESIGN.md section 2, not
+// bit for bit -- like K1r / K2 / K2c / K2f.  It can return -0.0 where the reference returns +0.0 (a row whose products are all
+// -0.0: the reference starts from +0.0, a run here starts from its first product) -- equal in value, documented in
+// include/sparsemat_hip.h.
 //
-// Why: every other kernel family gathers x[col] through the vector L1, and a gather that misses it costs one cache line
-// and one L2 round trip -- 150-190 G gathers/s however the work is arranged ("gather wall").  Here no
-// gather leaves the CU:
-//   pass 1 "expand":  the entries are stored by column slice (C = 16384 columns); a workgroup stages its slice of x in
-//                     LDS and computes prod[i] = val[i] * x_lds[code[i]] for its part of the slice's entries -- a pure
-//                     streaming map (16-bit column codes; 16-byte loads and stores), the gathers hit LDS.
-//   pass 2 "reduce":  within a slice the entries are ordered by row, so the entries of a block of consecutive rows form
-//                     one contiguous TILE per slice.  The row blocks are cut so that each holds the same number of entries
-//                     (~48 per tile: one entry per lane; skewed matrices get short blocks around their long rows).  One
-//                     wavefront per row block walks its tiles slice by slice, adds runs of equal rows with two
-//                     ballots and one-lane DPP shifts, and accumulates into R wave-private sums in LDS: no atomics,
-//                     no barriers, a fixed order -- bitwise reproducible.  The loads of the next 8 tiles are in flight
-//                     while 8 are folded.
-// Traffic per entry: pass 1 reads sizeof(T)+2 and writes sizeof(T), pass 2 reads sizeof(T)+2 -- 16 B (f32) / 28 B (f64)
-// against CSR's 8 / 12, all of it streaming.  Memory: the copy (sizeof(T)+4 per entry) plus the product buffer.
+// Why two passes: every row-major kernel gathers x[col] through the vector L1, and a gather that misses it costs a cache line
+// and an L2 round trip -- 150-190 G gathers/s however the work is arranged ("gather wall").  Here no gather
+// leaves the CU:
+//   pass 1 "expand":  the entries are stored by column slice (16384 columns), inside a slice by (row, storage order), cut into
+//                     CHUNKS of at most 64 E entries (E = 16 bytes of values: 4 f32 / 2 f64) that one wavefront takes at a time, E
+//                     consecutive entries per lane.  A workgroup stages its slice of x in LDS, multiplies (16-bit column codes),
+//                     and FOLDS the entries of a chunk that belong to one row (adjacent after the sort) with a segmented scan over
+//                     the wavefront; the sums -- one per (row, slice, chunk) -- leave compacted, 16 bytes per lane.  Chunks start
+//                     at row boundaries (the build snaps every chunk start forward to the next one, up to 16 entries), so a
+//                     (row, slice) pair almost always yields ONE product whatever the row's length.
+//   pass 2 "reduce":  inside a slice the products are ordered by row, so those of a block of consecutive rows are one contiguous
+//                     TILE per slice.  The row blocks are cut (host, once) so that each holds the same number of PRODUCTS.  One
+//                     wavefront per row block walks its tiles slice by slice, E products per lane (16-byte loads), and adds them
+//                     into wave-private sums in LDS; the rows of a tile are distinct (checked per tile with one ballot; else a
+//                     segmented scan merges equal neighbours first), so the adds of a tile are independent: no atomics, no
+//                     barriers, a fixed order -- bitwise reproducible.  The loads of the next tiles are in flight meanwhile.
+// Round 2's form (one product per entry, one entry per lane in pass 2: 16 / 28 B per entry, 42 VALU per 48-entry tile) is in
+// the history of this file; what changed and what it bought: DESIGN.md section 4, "K2t".
+//
+// ORDER (what tests/test_tiled_gpu.py restates bit for bit).  prod = round(val * x[col]).  Inside a chunk: lane l holds entries
+// E l .. E l + E - 1; s_0 = p_0, s_k = continues_k ? s_{k-1} + p_k : p_k (left fold inside the lane); the lanes' last running sums
+// are combined by a Kogge-Stone segmented scan in the order row_shr 1, 2, 4, 8, row_bcast 15, row_bcast 31 (v = stop ? v : v + v_in);
+// an entry of a lane's first segment adds the carry of the lanes before it as carry + s_k.  The value at the last entry of a
+// run is its product sum.  Pass 2 adds the product sums of a row to its running sum in slice order (a (row, slice) pair cut by a
+// chunk boundary has its parts merged first by the same scan, inside one round of 64 E products).
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
@@ -27,138 +40,248 @@
 
 namespace smh {
 
-constexpr uint32_t kT2Slice = 16384;   // columns per slice: 64 KiB (f32) / 128 KiB (f64) of x in LDS
-constexpr int kT2ExpandThreads = 1024;
-constexpr int kT2Waves = 4;            // wavefronts (row blocks) per workgroup of the reduce pass
-constexpr int kT2Batch = 8;            // tiles whose loads are in flight together
-constexpr double kT2TileTarget = 48.0; // mean entries per tile (one per lane; a longer tile takes a slow second round)
-// tuning knob SMH_TILED_TILE: another target (16..64)
-static double t2_tile_target() {
-    if (const char *e = getenv("SMH_TILED_TILE")) {
-        const double v = atof(e);
-        if (v >= 16.0 && v <= 64.0) return v;
-    }
-    return kT2TileTarget;
+// round 2's kernels (spmv_tiled_v1.hip), kept beside the new ones while both are measured: SMH_TILED_V1=1 selects them
+void tiled_v1_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *R, uint32_t *n_rb);
+int tiled_v1_build(::smh_crs *m);
+void tiled_v1_free(::smh_crs *m);
+int launch_spmv_tiled_v1(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s);
+static bool tiled_use_v1() {
+    static const bool v1 = getenv("SMH_TILED_V1") && atoi(getenv("SMH_TILED_V1")) == 1;
+    return v1;
 }
 
-typedef float t2_f4 __attribute__((ext_vector_type(4)));
-typedef double t2_d2 __attribute__((ext_vector_type(2)));
-typedef uint32_t t2_u2 __attribute__((ext_vector_type(2)));
-// one lane's 16 bytes of values and the 16-bit codes that go with them
-template <typename T> struct T2Lane;
-template <> struct T2Lane<float> {
-    using V = t2_f4;
-    using C = t2_u2;
-    static constexpr int kEntries = 4, kUnroll = 2;
-    static __device__ __forceinline__ V mul(V v, C c, const float *xs) {
-        V p;
-        p.x = v.x * xs[c.x & 0xFFFF]; p.y = v.y * xs[c.x >> 16];
-        p.z = v.z * xs[c.y & 0xFFFF]; p.w = v.w * xs[c.y >> 16];
-        return p;
-    }
-};
-template <> struct T2Lane<double> {
-    using V = t2_d2;
-    using C = uint32_t;
-    static constexpr int kEntries = 2, kUnroll = 2;
-    static __device__ __forceinline__ V mul(V v, C c, const double *xs) {
-        V p;
-        p.x = v.x * xs[c & 0xFFFF]; p.y = v.y * xs[c >> 16];
-        return p;
-    }
-};
+int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s, uint64_t *total_out);  // spmv_colblock.hip
 
-// ---- pass 1 ---------------------------------------------------------------------------------------------------------
-// grid = slices * parts; cb_ptr[b] = first entry of slice b in the copy (multiples of 8 entries: segments are padded with
-// zero-valued entries of code 0).  Every load and store instruction of a wavefront covers ONE contiguous kilobyte (a lane
-// takes 16 bytes of values -- 4 f32 / 2 f64 entries -- and their codes, the next lane the next 16; two such pieces in flight): with a lane owning 8
-// consecutive entries instead, a 16-byte load used a quarter (f64) or half (f32) of every line it touched and the read
-// side alone ran at 3.6 TB/s on f64 (profiles/r02_t2d_probe.log)
-template <typename T, int U>
-__global__ __launch_bounds__(kT2ExpandThreads) void k_t2_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
-                                                                 const uint16_t *__restrict__ code, const uint64_t *__restrict__ cb_ptr,
-                                                                 T *__restrict__ prod, uint32_t parts) {
-    extern __shared__ __attribute__((aligned(16))) char t2_smem[];
-    T *xs = (T *)t2_smem;
-    const uint32_t cb = blockIdx.x / parts, part = blockIdx.x % parts;
-    const uint64_t c0 = (uint64_t)cb * kT2Slice;
-    for (uint32_t i = threadIdx.x; i < kT2Slice; i += kT2ExpandThreads) xs[i] = c0 + i < x_len ? x[c0 + i] : T(0);
+constexpr uint32_t kT3Slice = 16384;     // columns per slice: 64 KiB (f32) / 128 KiB (f64) of x in LDS
+constexpr int kT3ExpandThreads = 1024;   // 16 wavefronts: one chunk each per step
+constexpr uint32_t kT3Snap = 16;         // a chunk start moves forward by up to this many entries to the next row boundary
+constexpr int kT3Waves = 4;              // wavefronts (row blocks) per workgroup of the reduce pass
+constexpr int kT3Batch = 4;              // tiles whose loads are in flight together, per wavefront
+constexpr uint32_t kT3Cont = 0x8000u;    // code bit 15: same row as the entry before (never set on a chunk's first entry)
+constexpr uint32_t kT3ColMask = 0x3FFFu;
+
+template <typename T> struct T3;
+template <> struct T3<float> {
+    static constexpr int E = 4;
+    typedef float V __attribute__((ext_vector_type(4)));
+    typedef uint32_t C __attribute__((ext_vector_type(2)));  // 4 x u16
+    static constexpr uint32_t kCapRows = 3328;               // rows of a row block: 4 x 3329 sums = 52 KiB -> three workgroups per CU
+};
+template <> struct T3<double> {
+    static constexpr int E = 2;
+    typedef double V __attribute__((ext_vector_type(2)));
+    typedef uint32_t C;                                      // 2 x u16
+    static constexpr uint32_t kCapRows = 1664;               // 4 x 1665 x 8 B = 52 KiB
+};
+template <typename T> constexpr uint32_t t3_chunk() { return 64u * T3<T>::E; }            // slots of a chunk: 256 / 128
+template <typename T> constexpr uint32_t t3_stride() { return t3_chunk<T>() - kT3Snap; }  // nominal entries per chunk: 240 / 112
+
+static double t3_tile_target(int dtype) {
+    // mean products per tile: a round takes 64 E of them (256 / 128); beyond ~0.7 of that too many tiles need a second round
+    double v = dtype == SMH_F64 ? 60.0 : 174.0;
+    if (const char *e = getenv("SMH_TILED_TILE")) {  // tuning knob
+        const double w = atof(e);
+        if (w >= 8.0 && w <= 256.0) v = w;
+    }
+    return v;
+}
+static uint32_t t3_cap_rows(int dtype) {
+    uint32_t cap = dtype == SMH_F64 ? T3<double>::kCapRows : T3<float>::kCapRows;
+    if (const char *e = getenv("SMH_TILED_CAP")) {  // tuning knob: most rows of a row block
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16384) cap = (uint32_t)v;
+    }
+    return cap;
+}
+
+// ---- DPP helpers ------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROWS> __device__ __forceinline__ uint32_t t3_dpp(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, 0xF, false);
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ float t3_dpp(float old, float v) {
+    return __uint_as_float(t3_dpp<CTRL, ROWS>(__float_as_uint(old), __float_as_uint(v)));
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ double t3_dpp(double old, double v) {
+    const uint64_t o = (uint64_t)__double_as_longlong(old), b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = t3_dpp<CTRL, ROWS>((uint32_t)o, (uint32_t)b), hi = t3_dpp<CTRL, ROWS>((uint32_t)(o >> 32), (uint32_t)(b >> 32));
+    return __longlong_as_double((long long)((uint64_t)hi << 32 | lo));
+}
+// one step of the segmented inclusive scan: (v, stop) of this lane takes (v_in, stop_in) of the lane the control names; a lane
+// without a source (row start, rows not in ROWS) keeps its values (v_in = 0 is never added there: stop_in = 1 is not set either,
+// so the add is guarded by `has`)
+template <int CTRL, int ROWS, typename T> __device__ __forceinline__ void t3_scan_step(T &v, uint32_t &stop) {
+    const T v_in = t3_dpp<CTRL, ROWS>(T(0), v);
+    const uint32_t in = t3_dpp<CTRL, ROWS>(2u, stop);  // 2: no source lane
+    if (in != 2u && !stop) v = v + v_in;
+    stop |= (in & 1u);
+}
+// R_l = the running sum at the end of lane l, where lane l passes what comes from the left on only if stop_l == 0
+template <typename T> __device__ __forceinline__ T t3_seg_scan(T v, uint32_t stop) {
+    t3_scan_step<0x111, 0xF>(v, stop);  // row_shr:1
+    t3_scan_step<0x112, 0xF>(v, stop);  // row_shr:2
+    t3_scan_step<0x114, 0xF>(v, stop);  // row_shr:4
+    t3_scan_step<0x118, 0xF>(v, stop);  // row_shr:8
+    t3_scan_step<0x142, 0xA>(v, stop);  // row_bcast:15 into rows 1 and 3
+    t3_scan_step<0x143, 0xC>(v, stop);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// The fold of one chunk / one round held E entries per lane: p[k] products, cont bit k = entry k continues the run of the entry
+// before it (bit 0 of lane 0 must be clear).  On return p[k] is the running sum of its run up to entry k (so the value at a
+// run's LAST entry is the run's sum) and the return value has bit k set where entry k is the last of its run -- as far as `cont`
+// of the following entry tells (the caller masks entries that do not exist).
+template <typename T, int E> __device__ __forceinline__ uint32_t t3_fold_runs(T (&p)[E], uint32_t cont) {
+    uint32_t through = cont & 1u;  // all entries up to k continue: they belong to the run that enters the lane
+    uint32_t first_seg = through;  // bit k: entry k is part of that run
+#pragma unroll
+    for (int k = 1; k < E; ++k) {
+        if (cont >> k & 1u) p[k] = p[k - 1] + p[k];
+        through &= cont >> k;
+        first_seg |= (through & 1u) << k;
+    }
+    // the lanes' last running sums, combined over the wavefront; a lane stops what comes from the left unless all of its entries continue
+    const T run = t3_seg_scan<T>(p[E - 1], (through & 1u) ^ 1u);
+    const T carry = t3_dpp<0x138, 0xF>(T(0), run);  // wave_shr:1 -- the running sum at the end of the lane before
+#pragma unroll
+    for (int k = 0; k < E; ++k)
+        if (first_seg >> k & 1u) p[k] = carry + p[k];
+    const uint32_t next0 = t3_dpp<0x130, 0xF>(0u, cont & 1u);  // wave_shl:1 -- does the next lane's first entry continue?  (lane 63: no)
+    return (~(cont >> 1 | next0 << (E - 1))) & ((1u << E) - 1u);
+}
+
+// ---- pass 1 -----------------------------------------------------------------------------------------------------------
+// chunk c: slots [c * CH, c * CH + len) of val / code hold its entries (the rest of the CH slots is zero), its product sums
+// go to prod[obase ...), 16 bytes per lane (the last piece may be padded: the build gives those slots the dump row).
+struct T3Chunk { uint32_t obase, len; };
+
+template <typename T>
+__global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
+                                                                 const uint16_t *__restrict__ code, const uint32_t *__restrict__ cptr,
+                                                                 const T3Chunk *__restrict__ chunk, T *__restrict__ prod, uint32_t parts,
+                                                                 uint32_t n_items, uint32_t xcd_map) {
+    using V = typename T3<T>::V;
+    using C = typename T3<T>::C;
+    constexpr int E = T3<T>::E;
+    constexpr uint32_t CH = 64u * E;
+    extern __shared__ __attribute__((aligned(16))) char t3_smem[];
+    T *xs = (T *)t3_smem;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    T *stage = xs + kT3Slice + wave * CH;
+    // workgroups b, b + 8, ... share an XCD (round-robin dispatch): an XCD gets a contiguous run of (slice, part) pairs, so the
+    // parts of a slice stage its x from one L2 instead of fetching it into eight (a speed hint only)
+    uint32_t g = blockIdx.x;
+    if (xcd_map) g = (blockIdx.x & 7u) * ((gridDim.x + 7u) / 8u) + (blockIdx.x >> 3);
+    if (g >= n_items) return;  // (the remapped grid is rounded up to a multiple of 8; whole workgroup, before the barrier)
+    const uint32_t cb = g / parts, part = g % parts;
+    const uint64_t col0 = (uint64_t)cb * kT3Slice;
+    for (uint32_t i = threadIdx.x; i < kT3Slice; i += kT3ExpandThreads) xs[i] = col0 + i < x_len ? x[col0 + i] : T(0);
     __syncthreads();
-    using L = T2Lane<T>;
-    using V = typename L::V;
-    using C = typename L::C;
-    constexpr int E = L::kEntries;
-    const uint64_t a0 = cb_ptr[cb], a1 = cb_ptr[cb + 1];
-    const uint64_t chunks = (a1 - a0) / E;  // 16-byte pieces of the slice's values
-    const uint64_t per = (chunks + parts - 1) / parts;
-    const uint64_t k0 = (uint64_t)part * per, k1 = k0 + per < chunks ? k0 + per : chunks;
-    const V *vv = (const V *)(val + a0);
-    const C *cc = (const C *)(code + a0);
-    V *pp = (V *)(prod + a0);
-    for (uint64_t k = k0 + threadIdx.x; k < k1; k += (uint64_t)kT2ExpandThreads * U) {
-        V v[U];
-        C c[U];
+    const uint32_t c_lo = cptr[cb], c_hi = cptr[cb + 1];
+    const uint32_t per = (c_hi - c_lo + parts - 1) / parts;
+    const uint32_t k0 = c_lo + part * per, k1 = k0 + per < c_hi ? k0 + per : c_hi;
+    constexpr uint32_t W = kT3ExpandThreads / 64;
+    const uint32_t pos = E * lane;
+    auto fetch = [&](uint32_t c, V &v, C &cd, T3Chunk &d) {
+        if (c < k1) {
+            d = chunk[__builtin_amdgcn_readfirstlane(c)];
+            if (pos < d.len) {  // (one region for both loads: whole 16-byte pieces, nothing is fetched for the empty part of a chunk)
+                v = __builtin_nontemporal_load((const V *)(val + (uint64_t)c * CH + pos));
+                cd = __builtin_nontemporal_load((const C *)(code + (uint64_t)c * CH + pos));
+            }
+        }
+    };
+    V v_n = V(0);
+    C c_n = C(0);
+    T3Chunk d_n = {0u, 0u};
+    fetch(k0 + wave, v_n, c_n, d_n);
+    for (uint32_t c = k0 + wave; c < k1; c += W) {
+        const V v = v_n;
+        const C cd = c_n;
+        const T3Chunk d = d_n;
+        v_n = V(0);
+        c_n = C(0);
+        fetch(c + W, v_n, c_n, d_n);  // the next chunk's loads are in flight while this one is folded
+        T p[E];
+        uint32_t cont = 0;
+        if constexpr (E == 4) {
+            p[0] = v.x * xs[cd.x & kT3ColMask]; p[1] = v.y * xs[cd.x >> 16 & kT3ColMask];
+            p[2] = v.z * xs[cd.y & kT3ColMask]; p[3] = v.w * xs[cd.y >> 16 & kT3ColMask];
+            cont = (cd.x >> 15 & 1u) | (cd.x >> 31) << 1 | (cd.y >> 15 & 1u) << 2 | (cd.y >> 31) << 3;
+        } else {
+            p[0] = v.x * xs[cd & kT3ColMask]; p[1] = v.y * xs[cd >> 16 & kT3ColMask];
+            cont = (cd >> 15 & 1u) | (cd >> 31) << 1;
+        }
+        uint32_t tail = t3_fold_runs<T, E>(p, cont);
+        // entries that exist: pos + k < len
+        const uint32_t have = pos >= d.len ? 0u : (d.len - pos >= (uint32_t)E ? (1u << E) - 1u : (1u << (d.len - pos)) - 1u);
+        tail &= have;
+        // where each run's sum goes: the number of run ends before it
+        uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {  // unconditional loads from a clamped index; the store decides
-            const uint64_t q = k + (uint64_t)u * kT2ExpandThreads;
-            const uint64_t qe = q < k1 ? q : k1 - 1;
-            v[u] = __builtin_nontemporal_load(vv + qe);
-            c[u] = __builtin_nontemporal_load(cc + qe);
+        for (int k = 0; k < E; ++k) {
+            const uint64_t b = __ballot(tail >> k & 1u);
+            before += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            total += (uint32_t)__popcll(b);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t q = k + (uint64_t)u * kT2ExpandThreads;
-            // plain stores: non-temporal ones cost 30 % here on f64 (profiles/r02_t2d_probe.log)
-            if (q < k1) pp[q] = L::mul(v[u], c[u], xs);
+        for (int k = 0; k < E; ++k) {
+            if (tail >> k & 1u) stage[before] = p[k];
+            before += tail >> k & 1u;
         }
+        // the padding of the last 16-byte piece is zero: where a chunk boundary cuts a (row, slice) pair the build gives these
+        // slots the pair's row, so that pass 2 sees its parts as neighbours and merges them (else they carry the dump row)
+        if (lane < (uint32_t)E && total + lane < ((total + E - 1) & ~(uint32_t)(E - 1))) stage[total + lane] = T(0);
+        __builtin_amdgcn_wave_barrier();
+        if (pos < total) *(V *)(prod + (uint64_t)d.obase + pos) = *(const V *)(stage + pos);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// ---- pass 2 ---------------------------------------------------------------------------------------------------------
-__device__ inline float t2_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false)); }
-__device__ inline double t2_shl1(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xF, 0xF, false);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-}
-
+// ---- pass 2 -----------------------------------------------------------------------------------------------------------
 template <typename T>
-struct T2Batch {
-    T pv[kT2Batch];
-    uint32_t rv[kT2Batch], ln[kT2Batch];
-    uint64_t bs[kT2Batch];
+struct T3Tiles {
+    typename T3<T>::V pv[kT3Batch];
+    typename T3<T>::C rv[kT3Batch];
+    uint32_t bs[kT3Batch], ln[kT3Batch];
 };
 
-// tstart[rb * n_cb + cb] = first entry of tile (cb, rb) relative to cb_ptr[cb]; row n_rb of the table holds the ends of the
-// last row block's tiles.  Row block rb = rows [rb_start[rb], rb_start[rb+1]); rowc: the entry's row relative to its block.
-// LDS: kT2Waves * R sums.
+// tstart[rb * n_cb + cb] = index (into prod / rowc) of the first product of tile (cb, rb); row n_rb of the table holds the ends of
+// the last row block's tiles.  rowc: the product's row relative to its block, or `R` (the dump slot) for padding.
+// LDS: kT3Waves * (R + 1) sums.
 template <typename T>
-__global__ __launch_bounds__(kT2Waves * 64) void k_t2_reduce(const T *__restrict__ prod, const uint16_t *__restrict__ rowc,
-                                                              const uint64_t *__restrict__ cb_ptr, const uint32_t *__restrict__ tstart, uint32_t n_cb,
-                                                              uint32_t n_rb, const uint32_t *__restrict__ rb_start, uint32_t R, T *__restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) char t2_smem[];
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t rb = blockIdx.x * kT2Waves + w;
+__global__ __launch_bounds__(kT3Waves * 64) void k_t3_reduce(const T *__restrict__ prod, const uint16_t *__restrict__ rowc,
+                                                              const uint32_t *__restrict__ tstart, uint32_t n_cb, uint32_t n_rb,
+                                                              const uint32_t *__restrict__ rb_start, uint32_t R, T *__restrict__ y,
+                                                              uint32_t xcd_map) {
+    using V = typename T3<T>::V;
+    using C = typename T3<T>::C;
+    constexpr int E = T3<T>::E;
+    constexpr uint32_t RND = 64u * E;
+    extern __shared__ __attribute__((aligned(16))) char t3_smem[];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t g = blockIdx.x;  // neighbouring row blocks' tiles share cache lines: neighbours on one XCD (one L2)
+    if (xcd_map) g = (blockIdx.x & 7u) * ((gridDim.x + 7u) / 8u) + (blockIdx.x >> 3);
+    const uint32_t rb = g * kT3Waves + w;
     if (rb >= n_rb) return;  // whole wavefronts; no barrier below
-    T *acc = (T *)t2_smem + (size_t)w * R;  // R = the largest row block
+    T *acc = (T *)t3_smem + (size_t)w * (R + 1);
     const uint32_t r0 = rb_start[rb], rows = rb_start[rb + 1] - r0;
     for (uint32_t i = lane; i < rows; i += 64) acc[i] = T(0);
+    if (lane == 0) acc[R] = T(0);
     const uint32_t *ts0 = tstart + (size_t)rb * n_cb, *ts1 = ts0 + n_cb;
-    auto table = [&](uint32_t g, uint64_t &base, uint32_t &len) {  // lane l: tile g + l
-        const uint32_t cbl = g + lane;
+    auto table = [&](uint32_t t, uint32_t &base, uint32_t &len) {  // lane l: tile t + l
+        const uint32_t cbl = t + lane;
         base = 0;
         len = 0;
         if (cbl < n_cb) {
-            const uint32_t s = ts0[cbl], e = ts1[cbl];
-            base = cb_ptr[cbl] + s;
-            len = e - s;
+            base = ts0[cbl];
+            len = ts1[cbl] - base;
         }
     };
-    uint64_t cur_base, nxt_base;
-    uint32_t cur_len, nxt_len, win = 0;  // cur_*: tiles [win, win + 64), nxt_*: the 64 after them
+    uint32_t cur_base, nxt_base, cur_len, nxt_len, win = 0;  // cur_*: tiles [win, win + 64), nxt_*: the 64 after them
     table(0, cur_base, cur_len);
     table(64, nxt_base, nxt_len);
-    auto issue = [&](T2Batch<T> &B, uint32_t j0) {
+    const uint32_t pos = E * lane;
+    auto issue = [&](T3Tiles<T> &B, uint32_t j0) {
         if (j0 >= win + 64) {
             cur_base = nxt_base;
             cur_len = nxt_len;
@@ -166,83 +289,87 @@ __global__ __launch_bounds__(kT2Waves * 64) void k_t2_reduce(const T *__restrict
             table(win + 64, nxt_base, nxt_len);
         }
 #pragma unroll
-        for (int d = 0; d < kT2Batch; ++d) {
+        for (int d = 0; d < kT3Batch; ++d) {
             const int j = (int)((j0 + d) & 63);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur_base, j);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur_base >> 32), j);
-            B.bs[d] = (uint64_t)hi << 32 | lo;
+            B.bs[d] = (uint32_t)__builtin_amdgcn_readlane((int)cur_base, j);
             B.ln[d] = (uint32_t)__builtin_amdgcn_readlane((int)cur_len, j);  // 0 past the last slice
         }
 #pragma unroll
-        for (int d = 0; d < kT2Batch; ++d) {  // unconditional loads (a tile's first entry is always a valid address), masked when folded
-            const uint32_t idx = lane < B.ln[d] ? lane : 0;
-            B.pv[d] = prod[B.bs[d] + idx];
-            B.rv[d] = rowc[B.bs[d] + idx];
+        for (int d = 0; d < kT3Batch; ++d) {  // unconditional, aligned 16-byte loads (the buffers end in a round of slack); masked when folded
+            const uint64_t a = (uint64_t)(B.bs[d] & ~(uint32_t)(E - 1)) + pos;
+            B.pv[d] = *(const V *)(prod + a);
+            B.rv[d] = *(const C *)(rowc + a);
         }
     };
-    // one round = up to 64 consecutive entries of a tile, one per lane (p, r: this lane's product and row; r = ~0 past the end)
-    auto round = [&](uint64_t bs, uint32_t len, uint32_t t0, T p, uint32_t r, uint32_t prev0) {
-        const uint32_t t = t0 + lane;
-        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)r, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        if (lane == 0) prev = prev0;
-        const bool valid = t < len;
-        const bool head = valid && prev != r;
-        // run lengths from two ballots: m = heads whose run is longer than k; the k-th neighbour's product arrives by k one-lane shifts
-        const uint64_t nh = __ballot(valid && !head);
-        uint64_t m = __ballot(head);
-        T s = p, q = p;
-        for (uint32_t k = 1;; ++k) {
-            m &= nh >> k;
-            if (!m) break;
-            q = t2_shl1(q);
-            if ((m >> lane) & 1) s += q;
+    // one round: up to 64 E consecutive products, E per lane: p[k] at index a + k of prod, valid for lo <= a + k < hi
+    auto round = [&](const V &pv, const C &rv, uint32_t a, uint32_t lo, uint32_t hi) {
+        T p[E];
+        uint32_t r[E];
+        if constexpr (E == 4) {
+            p[0] = pv.x; p[1] = pv.y; p[2] = pv.z; p[3] = pv.w;
+            r[0] = rv.x & 0xFFFFu; r[1] = rv.x >> 16; r[2] = rv.y & 0xFFFFu; r[3] = rv.y >> 16;
+        } else {
+            p[0] = pv.x; p[1] = pv.y;
+            r[0] = rv & 0xFFFFu; r[1] = rv >> 16;
         }
-        const uint32_t r63 = (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
-        if (head) {
-            const uint32_t nx = t0 + 64;  // the run may go on past this round (tiles of more than 64 entries only)
-            if (r63 == r && nx < len)
-                for (uint32_t k = nx; k < len && rowc[bs + k] == r; ++k) s += prod[bs + k];
-            acc[r] += s;
-        }
-    };
-    // the first round of every tile works on the prefetched registers and issues no load, so the wait in front of it can leave
-    // the next batch's loads in flight (a load inside the common path would force vmcnt(0): they return in order)
-    auto fold = [&](T2Batch<T> &B) {
 #pragma unroll
-        for (int d = 0; d < kT2Batch; ++d) {
-            const uint32_t len = B.ln[d];
-            const uint64_t bs = B.bs[d];
-            round(bs, len, 0, lane < len ? B.pv[d] : T(0), lane < len ? B.rv[d] : 0xFFFFFFFFu, 0xFFFFFFFFu);
-            for (uint32_t t0 = 64; t0 < len; t0 += 64) {  // rare: a tile of more than 64 entries
-                const uint32_t t = t0 + lane;
-                T p = T(0);
-                uint32_t r = 0xFFFFFFFFu;
-                if (t < len) { p = prod[bs + t]; r = rowc[bs + t]; }
-                round(bs, len, t0, p, r, (uint32_t)rowc[bs + t0 - 1]);
+        for (int k = 0; k < E; ++k) {
+            const bool ok = a + k >= lo && a + k < hi;
+            if (!ok) { r[k] = R; p[k] = T(0); }  // (the dump slot; its value is never read)
+        }
+        // equal neighbours (a (row, slice) pair cut by a chunk boundary; the dump row never counts)
+        const uint32_t prev_r = t3_dpp<0x138, 0xF>(0xFFFFFFFFu, r[E - 1]);  // wave_shr:1
+        uint32_t cont = (uint32_t)(r[0] == prev_r && r[0] != R);
+#pragma unroll
+        for (int k = 1; k < E; ++k) cont |= (uint32_t)(r[k] == r[k - 1] && r[k] != R) << k;
+        if (__ballot(cont != 0)) {
+            // rare: merge them first (same fold as pass 1), then only the last entry of each run adds
+            const uint32_t tail = t3_fold_runs<T, E>(p, cont);
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+                if (!(tail >> k & 1u)) r[k] = R;
+        }
+        // the rows of the round are distinct now (sorted, no equal neighbours), the dump slot aside: independent adds
+        T s[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) s[k] = acc[r[k]];
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[r[k]] = s[k] + p[k];
+    };
+    auto fold = [&](T3Tiles<T> &B) {
+#pragma unroll
+        for (int d = 0; d < kT3Batch; ++d) {
+            const uint32_t bs = B.bs[d], end = bs + B.ln[d];
+            const uint32_t a0 = bs & ~(uint32_t)(E - 1);
+            round(B.pv[d], B.rv[d], a0 + pos, bs, end);
+            for (uint32_t a = a0 + RND; a < end; a += RND) {  // rare: a tile of more than one round
+                const V pv = *(const V *)(prod + (uint64_t)a + pos);
+                const C rv = *(const C *)(rowc + (uint64_t)a + pos);
+                round(pv, rv, a + pos, bs, end);
             }
         }
     };
-    T2Batch<T> A, B;
+    T3Tiles<T> A, B;
     issue(A, 0);
-    for (uint32_t j0 = 0; j0 < n_cb; j0 += 2 * kT2Batch) {
-        issue(B, j0 + kT2Batch);
+    for (uint32_t j0 = 0; j0 < n_cb; j0 += 2 * kT3Batch) {
+        issue(B, j0 + kT3Batch);
         fold(A);
-        issue(A, j0 + 2 * kT2Batch);
+        issue(A, j0 + 2 * kT3Batch);
         fold(B);
     }
     for (uint32_t i = lane; i < rows; i += 64) y[(uint64_t)r0 + i] = acc[i];
 }
 
-// ---- plan -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_t2_keys(const uint32_t *__restrict__ col, uint64_t nnz, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
+// ---- plan -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_t3_keys(const uint32_t *__restrict__ col, uint64_t nnz, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kBlock) {
-        key[i] = col[i] / kT2Slice;
+        key[i] = col[i] / kT3Slice;
         idx[i] = (uint32_t)i;
     }
 }
 
 // start[b] = first position of the sorted keys holding a value >= b (b = 0 .. n_cb)
-__global__ __launch_bounds__(kBlock) void k_t2_bounds(const uint32_t *__restrict__ key_s, uint64_t nnz, uint32_t n_cb, uint64_t *__restrict__ start) {
+__global__ __launch_bounds__(kBlock) void k_t3_bounds(const uint32_t *__restrict__ key_s, uint64_t nnz, uint32_t n_cb, uint64_t *__restrict__ start) {
     const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
     if (b > n_cb) return;
     uint64_t lo = 0, hi = nnz;
@@ -253,79 +380,190 @@ __global__ __launch_bounds__(kBlock) void k_t2_bounds(const uint32_t *__restrict
     start[b] = lo;
 }
 
-// the copy in slice-major order: position of sorted rank q = cb_ptr[slice] + (q - start[slice])
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_t2_fill(const uint32_t *__restrict__ off, uint64_t n_rows, const uint32_t *__restrict__ col,
-                                                     const T *__restrict__ val, const uint32_t *__restrict__ key_s, const uint32_t *__restrict__ perm,
-                                                     uint64_t nnz, const uint64_t *__restrict__ start, const uint64_t *__restrict__ cb_ptr,
-                                                     const uint32_t *__restrict__ rb_start, uint32_t n_rb,
-                                                     T *__restrict__ val_a, uint16_t *__restrict__ code_a, uint16_t *__restrict__ row_a,
-                                                     uint32_t *__restrict__ row_full) {
+// rowq[q] = the row of the entry of sorted rank q: the last one with off[row] <= perm[q]
+__global__ __launch_bounds__(kBlock) void k_t3_rows(const uint32_t *__restrict__ off, uint64_t n_rows, const uint32_t *__restrict__ perm, uint64_t nnz,
+                                                     uint32_t *__restrict__ rowq) {
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nnz; q += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t cb = key_s[q], i = perm[q];
-        const uint64_t p = cb_ptr[cb] + (q - start[cb]);
-        uint64_t lo = 0, hi = n_rows;  // the row of entry i: the last one with off[row] <= i
+        const uint32_t i = perm[q];
+        uint64_t lo = 0, hi = n_rows;
         while (lo < hi) {
             const uint64_t mid = (lo + hi) / 2;
             if (off[mid + 1] <= i) lo = mid + 1; else hi = mid;
         }
-        const uint32_t row = (uint32_t)lo;
-        val_a[p] = val[i];
-        code_a[p] = (uint16_t)(col[i] - cb * kT2Slice);
-        uint32_t bl = 0, bh = n_rb;  // the row block: the last one with rb_start[b] <= row
-        while (bl + 1 < bh) {
-            const uint32_t mid = (bl + bh) / 2;
-            if (rb_start[mid] <= row) bl = mid; else bh = mid;
-        }
-        row_a[p] = (uint16_t)(row - rb_start[bl]);
-        row_full[p] = row;
+        rowq[q] = (uint32_t)lo;
     }
 }
 
-// tstart[rb * n_cb + cb], rb = 0 .. n_rb: first entry of slice cb (relative) whose row is >= rb_start[rb] (= n_rows for rb = n_rb)
-__global__ __launch_bounds__(kBlock) void k_t2_table(const uint32_t *__restrict__ row_full, const uint64_t *__restrict__ start,
-                                                      const uint64_t *__restrict__ cb_ptr, uint32_t n_cb, uint32_t n_rb,
-                                                      const uint32_t *__restrict__ rb_start, uint32_t *__restrict__ tstart) {
+// the slice of chunk c: the last s with cptr[s] <= c
+__device__ __forceinline__ uint32_t t3_slice_of(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t c) {
+    uint32_t lo = 0, hi = n_cb;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (cptr[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// cstart[c] = where chunk c begins among its slice's sorted entries: nominally at (c - cptr[s]) * stride, moved forward to the
+// next row boundary when there is one within kT3Snap entries (so that a (row, slice) pair is not cut); never past the slice's end
+__global__ __launch_bounds__(kBlock) void k_t3_chunk_starts(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t n_chunks,
+                                                             const uint64_t *__restrict__ start, const uint32_t *__restrict__ rowq,
+                                                             uint32_t stride, uint32_t *__restrict__ cstart) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t s = t3_slice_of(cptr, n_cb, c);
+    const uint64_t q0 = start[s], cnt = start[s + 1] - q0;
+    const uint64_t nominal = (uint64_t)(c - cptr[s]) * stride;
+    uint64_t at = nominal < cnt ? nominal : cnt;
+    for (uint32_t j = 0; j < kT3Snap; ++j) {
+        const uint64_t q = nominal + j;
+        if (q >= cnt) { at = cnt; break; }
+        if (q == 0 || rowq[q0 + q] != rowq[q0 + q - 1]) { at = q; break; }
+    }
+    cstart[c] = (uint32_t)at;
+}
+
+// one wavefront per chunk: the chunk's slots of val / code (continuation bits included) and the number of its runs
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_t3_fill(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t n_chunks, const uint64_t *__restrict__ start,
+                                                     const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ rowq,
+                                                     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ col, const T *__restrict__ val,
+                                                     T *__restrict__ val_a, uint16_t *__restrict__ code_a, uint32_t *__restrict__ clen,
+                                                     uint32_t *__restrict__ ntails) {
+    constexpr uint32_t CH = t3_chunk<T>();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const uint32_t s = t3_slice_of(cptr, n_cb, c);
+    const uint64_t q0 = start[s], cnt = start[s + 1] - q0;
+    const uint32_t a = cstart[c], b = c + 1 < cptr[s + 1] ? cstart[c + 1] : (uint32_t)cnt;
+    const uint32_t len = b - a;  // <= CH - 1
+    uint32_t runs = 0;
+    for (uint32_t j = lane; j < CH; j += 64) {
+        T v = T(0);
+        uint32_t cd = 0;
+        if (j < len) {
+            const uint64_t q = q0 + a + j;
+            const uint32_t i = perm[q];
+            v = val[i];
+            cd = col[i] - s * kT3Slice;
+            if (j > 0 && rowq[q] == rowq[q - 1]) cd |= kT3Cont;
+            else ++runs;
+        }
+        val_a[(uint64_t)c * CH + j] = v;
+        code_a[(uint64_t)c * CH + j] = (uint16_t)cd;
+    }
+    for (int o = 32; o; o >>= 1) runs += (uint32_t)__shfl_down((int)runs, o, 64);
+    if (lane == 0) {
+        clen[c] = len;
+        ntails[c] = (runs + (uint32_t)T3<T>::E - 1u) & ~((uint32_t)T3<T>::E - 1u);  // the chunk's share of prod: whole 16-byte pieces
+    }
+}
+
+// one wavefront per chunk: prow[obase + j] = row of the chunk's j-th run (the padding of the last piece repeats the last row, so
+// that the array stays sorted inside a slice); rcount[row] += 1 per run; desc[c] = {obase, len}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t n_chunks, const uint64_t *__restrict__ start,
+                                                     const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ clen,
+                                                     const uint32_t *__restrict__ obase, const uint32_t *__restrict__ rowq,
+                                                     const uint16_t *__restrict__ code_a, uint32_t *__restrict__ prow, uint32_t *__restrict__ preal,
+                                                     uint32_t *__restrict__ rcount, T3Chunk *__restrict__ desc) {
+    constexpr uint32_t CH = t3_chunk<T>();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const uint32_t s = t3_slice_of(cptr, n_cb, c);
+    const uint64_t q0 = start[s] + cstart[c];
+    const uint32_t len = clen[c], ob = obase[c], slots = obase[c + 1] - ob;
+    if (lane == 0) desc[c] = T3Chunk{ob, len};
+    uint32_t done = 0, last_row = 0;
+    for (uint32_t j0 = 0; j0 < CH; j0 += 64) {  // run starts in order: the k-th one names product slot k
+        const uint32_t j = j0 + lane;
+        const bool head = j < len && !(code_a[(uint64_t)c * CH + j] & kT3Cont);
+        const uint64_t m = __ballot(head);
+        const uint32_t rank = done + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (head) {
+            const uint32_t row = rowq[q0 + j];
+            prow[ob + rank] = row;
+            atomicAdd(rcount + row, 1u);
+        }
+        done += (uint32_t)__popcll(m);
+    }
+    if (len) last_row = rowq[q0 + len - 1];
+    for (uint32_t k = done + lane; k < slots; k += 64) prow[ob + k] = last_row;
+    // does the chunk's last run go on in the next chunk (a (row, slice) pair longer than the snap distance, cut here)?
+    bool cut = false;
+    if (len && c + 1 < cptr[s + 1] && clen[c + 1]) cut = rowq[start[s] + cstart[c + 1]] == last_row;
+    if (lane == 0) preal[c] = done | (cut ? 0x80000000u : 0u);
+}
+
+// rowc[i]: the row of product slot i relative to its row block; the padding slots of a chunk's last piece: `dump`, or the row of
+// the chunk's last run when that run goes on in the next chunk
+__global__ __launch_bounds__(kBlock) void k_t3_rowcode(uint32_t n_chunks, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ preal,
+                                                        const uint32_t *__restrict__ prow, const uint32_t *__restrict__ rb_start, uint32_t n_rb,
+                                                        uint32_t dump, uint16_t *__restrict__ rowc) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const uint32_t ob = obase[c], slots = obase[c + 1] - ob, real = preal[c] & 0x7FFFFFFFu;
+    const bool cut = preal[c] >> 31;  // the padding then belongs to the cut pair's row (its value is zero): see k_t3_expand
+    for (uint32_t k = lane; k < slots; k += 64) {
+        uint32_t code = dump;
+        if (k < real || cut) {
+            const uint32_t row = prow[ob + k];
+            uint32_t bl = 0, bh = n_rb;  // the row block: the last one with rb_start[b] <= row
+            while (bl + 1 < bh) {
+                const uint32_t mid = (bl + bh) / 2;
+                if (rb_start[mid] <= row) bl = mid; else bh = mid;
+            }
+            code = row - rb_start[bl];
+        }
+        rowc[ob + k] = (uint16_t)code;
+    }
+}
+
+// tstart[rb * n_cb + cb], rb = 0 .. n_rb: the first product slot of slice cb whose row is >= rb_start[rb] (= n_rows for rb = n_rb)
+__global__ __launch_bounds__(kBlock) void k_t3_table(const uint32_t *__restrict__ prow, const uint32_t *__restrict__ cptr, const uint32_t *__restrict__ obase,
+                                                      uint32_t n_cb, uint32_t n_rb, const uint32_t *__restrict__ rb_start, uint32_t *__restrict__ tstart) {
     const uint64_t total = (uint64_t)(n_rb + 1) * n_cb;
     for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kBlock) {
         const uint32_t rb = (uint32_t)(t / n_cb), cb = (uint32_t)(t % n_cb);
-        const uint64_t cnt = start[cb + 1] - start[cb], first_row = rb_start[rb];
-        const uint32_t *seg = row_full + cb_ptr[cb];
-        uint64_t lo = 0, hi = cnt;
+        const uint32_t first_row = rb_start[rb];
+        uint32_t lo = obase[cptr[cb]], hi = obase[cptr[cb + 1]];
         while (lo < hi) {
-            const uint64_t mid = (lo + hi) / 2;
-            if (seg[mid] < first_row) lo = mid + 1; else hi = mid;
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (prow[mid] < first_row) lo = mid + 1; else hi = mid;
         }
-        tstart[t] = (uint32_t)lo;
+        tstart[t] = lo;
     }
 }
 
-static unsigned t2_bits_for(uint64_t v) {
+static unsigned t3_bits_for(uint64_t v) {
     unsigned b = 1;
     while (b < 64 && (v >> b)) ++b;
     return b;
 }
 
-struct T2Scratch {
-    void *p[8] = {};
+struct T3Scratch {
+    void *p[16] = {};
     int n = 0;
     template <typename U> int alloc(U **out, size_t count) {
         SMH_HIP(hipMalloc((void **)out, (count ? count : 1) * sizeof(U)));
         p[n++] = *out;
         return SMH_OK;
     }
-    ~T2Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
+    ~T3Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
 };
 
-// the geometry for rows of equal length (AUTO's estimate; the build cuts the row blocks by entries, see row_blocks())
+// the geometry for rows of equal length and no two entries of a row in one slice (AUTO's estimate; the build cuts the row blocks
+// by the products the rows really have)
 void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *R, uint32_t *n_rb) {
-    const uint64_t cb = ((uint64_t)n_cols + kT2Slice - 1) / kT2Slice;
+    if (tiled_use_v1()) return tiled_v1_geometry(n_rows, n_cols, nnz, dtype, n_cb, R, n_rb);
+    const uint64_t cb = ((uint64_t)n_cols + kT3Slice - 1) / kT3Slice;
     *n_cb = (uint32_t)(cb ? cb : 1);
-    // rows per block: a tile (one slice x one row block) should hold ~kT2TileTarget entries; the sums of kT2Waves blocks
-    // share 48 KiB of LDS
     const double per_row_and_slice = n_rows ? (double)nnz / (double)n_rows / (double)*n_cb : 0.0;
-    const uint32_t cap = dtype == SMH_F64 ? 1280u : 3072u;  // rows whose sums one wavefront keeps in LDS (see build_t)
-    double r = per_row_and_slice > 0.0 ? t2_tile_target() / per_row_and_slice : (double)cap;
+    const uint32_t cap = t3_cap_rows(dtype);
+    double r = per_row_and_slice > 0.0 ? t3_tile_target(dtype) / per_row_and_slice : (double)cap;
     if (r > (double)cap) r = (double)cap;
     if (r < 1.0) r = 1.0;
     *R = (uint32_t)r;
@@ -337,126 +575,153 @@ template <typename T>
 static int build_t(::smh_crs *m) {
     hipStream_t s = m->stream;
     const uint64_t nnz = m->nnz;
-    uint32_t n_cb, R, n_rb;
-    tiled_geometry(m->n_rows, m->n_cols, m->nnz, m->dtype, &n_cb, &R, &n_rb);
-    // row blocks of equal ENTRY counts (a tile = one slice of a block: ~kT2TileTarget entries whatever the row lengths), at most
-    // `cap` rows each (their sums share the LDS); greedy over the row offsets, on the host
-    std::vector<uint32_t> rb_start;
-    {
-        // f32: 3072 rows (12 KiB of sums per wavefront); f64: 1280 (10 KiB: 16 wavefronts per CU) -- C3 2.31 / 2.15 / 2.19 / 2.18 ms
-        // with 1536 / 1280 / 1024 / 768, 10 M x 16 uniform 1.11 / 1.02 / 1.13 / 1.21 (profiles/r02_tiled_cap.log)
-        uint32_t cap = sizeof(T) == 8 ? 1280u : 3072u;
-        if (const char *e = getenv("SMH_TILED_CAP")) {  // tuning knob: most rows of a row block
-            const int v = atoi(e);
-            if (v >= 1 && v <= 8192) cap = (uint32_t)v;
-        }
-        const uint64_t per_block = (uint64_t)(t2_tile_target() * (double)n_cb);
-        std::vector<uint32_t> h_off(m->n_rows + 1);
-        SMH_HIP(hipMemcpyAsync(h_off.data(), m->d_off, h_off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        SMH_HIP(hipStreamSynchronize(s));
-        rb_start.reserve((size_t)n_rb + 16);
-        size_t r = 0;
-        while (r < m->n_rows) {
-            rb_start.push_back((uint32_t)r);
-            const size_t hi = r + cap < m->n_rows ? r + cap : m->n_rows;
-            // the first row boundary in (r, hi] at which the block holds per_block entries or more
-            const uint64_t want = (uint64_t)h_off[r] + per_block;
-            size_t e = (size_t)(std::lower_bound(h_off.begin() + r + 1, h_off.begin() + hi + 1, want,
-                                                 [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - h_off.begin());
-            if (e > hi) e = hi;
-            r = e;
-        }
-        if (rb_start.empty()) rb_start.push_back(0);
-        rb_start.push_back((uint32_t)m->n_rows);
-        n_rb = (uint32_t)(rb_start.size() - 1);
-        R = 1;
-        for (uint32_t b = 0; b < n_rb; ++b) R = std::max(R, rb_start[b + 1] - rb_start[b]);
-    }
-    const uint64_t table_entries = (uint64_t)(n_rb + 1) * n_cb;
-    if (table_entries * 4 > (4ull << 30))
-        return fail(SMH_ERR_INVALID, "tiled variant: %u column slices x %u row blocks need a tile table beyond 4 GiB", n_cb, n_rb);
-    T2Scratch tmp;
-    uint32_t *key = nullptr, *key_s = nullptr, *idx = nullptr, *perm = nullptr, *row_full = nullptr;
+    constexpr uint32_t CH = t3_chunk<T>(), STRIDE = t3_stride<T>(), E = (uint32_t)T3<T>::E;
+    const uint64_t n_cb64 = ((uint64_t)m->n_cols + kT3Slice - 1) / kT3Slice;
+    const uint32_t n_cb = (uint32_t)(n_cb64 ? n_cb64 : 1);
+    if (nnz + nnz / 64 + 1024 >= (1ull << 32)) return fail(SMH_ERR_INVALID, "tiled variant: %llu entries are too many for its 32-bit product index", (unsigned long long)nnz);
+    T3Scratch tmp;
+    uint32_t *key = nullptr, *key_s = nullptr, *idx = nullptr, *perm = nullptr, *rowq = nullptr;
     uint64_t *d_start = nullptr;
     SMH_TRY(tmp.alloc(&key, nnz));
     SMH_TRY(tmp.alloc(&key_s, nnz));
     SMH_TRY(tmp.alloc(&idx, nnz));
     SMH_TRY(tmp.alloc(&perm, nnz));
+    SMH_TRY(tmp.alloc(&rowq, nnz));
     SMH_TRY(tmp.alloc(&d_start, (size_t)n_cb + 1));
     const unsigned grid = 2048;
     if (nnz) {
-        hipLaunchKernelGGL(k_t2_keys, dim3(grid), dim3(kBlock), 0, s, m->d_col, nnz, key, idx);
+        hipLaunchKernelGGL(k_t3_keys, dim3(grid), dim3(kBlock), 0, s, m->d_col, nnz, key, idx);
         SMH_HIP(hipGetLastError());
-        {
-            size_t bytes = 0;
-            void *ws = nullptr;
-            SMH_HIP(rocprim::radix_sort_pairs(ws, bytes, key, key_s, idx, perm, (size_t)nnz, 0u, t2_bits_for(n_cb - 1), s));
-            SMH_HIP(hipMalloc(&ws, bytes ? bytes : 16));
-            const hipError_t e1 = rocprim::radix_sort_pairs(ws, bytes, key, key_s, idx, perm, (size_t)nnz, 0u, t2_bits_for(n_cb - 1), s);
-            const hipError_t e2 = hipStreamSynchronize(s);
-            (void)hipFree(ws);
-            SMH_HIP(e1);
-            SMH_HIP(e2);
-        }
+        size_t bytes = 0;
+        void *ws = nullptr;
+        SMH_HIP(rocprim::radix_sort_pairs(ws, bytes, key, key_s, idx, perm, (size_t)nnz, 0u, t3_bits_for(n_cb - 1), s));
+        SMH_HIP(hipMalloc(&ws, bytes ? bytes : 16));
+        const hipError_t e1 = rocprim::radix_sort_pairs(ws, bytes, key, key_s, idx, perm, (size_t)nnz, 0u, t3_bits_for(n_cb - 1), s);
+        const hipError_t e2 = hipStreamSynchronize(s);
+        (void)hipFree(ws);
+        SMH_HIP(e1);
+        SMH_HIP(e2);
+        hipLaunchKernelGGL(k_t3_rows, dim3(grid), dim3(kBlock), 0, s, m->d_off, (uint64_t)m->n_rows, perm, nnz, rowq);
+        SMH_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_t2_bounds, dim3((n_cb + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, key_s, nnz, n_cb, d_start);
+    hipLaunchKernelGGL(k_t3_bounds, dim3((n_cb + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, key_s, nnz, n_cb, d_start);
     SMH_HIP(hipGetLastError());
-    std::vector<uint64_t> start((size_t)n_cb + 1), cb_ptr((size_t)n_cb + 1);
+    std::vector<uint64_t> start((size_t)n_cb + 1);
     SMH_HIP(hipMemcpyAsync(start.data(), d_start, start.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     SMH_HIP(hipStreamSynchronize(s));
-    cb_ptr[0] = 0;
+    // chunks: ceil(entries of the slice / stride) each (a chunk whose start was moved past the slice's end stays empty)
+    std::vector<uint32_t> cptr((size_t)n_cb + 1);
+    cptr[0] = 0;
     for (uint32_t b = 0; b < n_cb; ++b) {
         const uint64_t cnt = start[b + 1] - start[b];
         if (cnt >= (1ull << 32)) return fail(SMH_ERR_INVALID, "tiled variant: a column slice holds %llu entries", (unsigned long long)cnt);
-        cb_ptr[b + 1] = cb_ptr[b] + ((cnt + 7) & ~7ull);
+        cptr[b + 1] = cptr[b] + (uint32_t)((cnt + STRIDE - 1) / STRIDE);
     }
-    const uint64_t tot = cb_ptr[n_cb];
-    SMH_TRY(tmp.alloc(&row_full, tot));
-    // the plan's own buffers (+8 entries of slack: a tile past the last entry still has a valid first address)
-    SMH_HIP(hipMalloc(&m->d_t2_val, (tot + 8) * sizeof(T)));
-    SMH_HIP(hipMalloc(&m->d_t2_prod, (tot + 8) * sizeof(T)));
-    SMH_HIP(hipMalloc((void **)&m->d_t2_code, (tot + 8) * sizeof(uint16_t)));
-    SMH_HIP(hipMalloc((void **)&m->d_t2_row, (tot + 8) * sizeof(uint16_t)));
-    SMH_HIP(hipMalloc((void **)&m->d_t2_cbptr, ((size_t)n_cb + 1) * sizeof(uint64_t)));
+    const uint32_t n_chunks = cptr[n_cb];
+    const uint64_t slots = (uint64_t)n_chunks * CH;
+    uint32_t *cstart = nullptr, *clen = nullptr, *obase = nullptr, *preal = nullptr, *rcount = nullptr, *prow = nullptr;
+    SMH_TRY(tmp.alloc(&cstart, (size_t)n_chunks));
+    SMH_TRY(tmp.alloc(&clen, (size_t)n_chunks));
+    SMH_TRY(tmp.alloc(&obase, (size_t)n_chunks + 1));
+    SMH_TRY(tmp.alloc(&preal, (size_t)n_chunks));
+    SMH_TRY(tmp.alloc(&rcount, m->n_rows));
+    SMH_HIP(hipMalloc(&m->d_t2_val, (slots + CH) * sizeof(T)));
+    SMH_HIP(hipMalloc((void **)&m->d_t2_code, (slots + CH) * sizeof(uint16_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_t3_cptr, ((size_t)n_cb + 1) * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_t3_chunk, ((size_t)n_chunks + 1) * sizeof(T3Chunk)));
+    SMH_HIP(hipMemcpyAsync(m->d_t3_cptr, cptr.data(), cptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    SMH_HIP(hipMemsetAsync(rcount, 0, (m->n_rows ? m->n_rows : 1) * sizeof(uint32_t), s));
+    SMH_HIP(hipMemsetAsync(obase, 0, ((size_t)n_chunks + 1) * sizeof(uint32_t), s));
+    const unsigned wgrid = (n_chunks + kBlock / 64 - 1) / (kBlock / 64);
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_t3_chunk_starts, dim3((n_chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, rowq, STRIDE, cstart);
+        SMH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_t3_fill<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, rowq, perm, m->d_col, (const T *)m->d_val,
+                           (T *)m->d_t2_val, m->d_t2_code, clen, obase);
+        SMH_HIP(hipGetLastError());
+    }
+    uint64_t n_prod = 0;
+    SMH_TRY(device_exclusive_scan_u32(obase, (uint64_t)n_chunks + 1, s, &n_prod));  // obase[c] = products before chunk c; obase[n_chunks] = all
+    if (n_prod >= (1ull << 32) - 4 * CH) return fail(SMH_ERR_INVALID, "tiled variant: %llu products are too many for its 32-bit index", (unsigned long long)n_prod);
+    SMH_TRY(tmp.alloc(&prow, (size_t)n_prod));
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_t3_prow<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, clen, obase, rowq, m->d_t2_code, prow, preal,
+                           rcount, (T3Chunk *)m->d_t3_chunk);
+        SMH_HIP(hipGetLastError());
+    }
+    // row blocks of equal PRODUCT counts (a tile = one slice of a block: ~target products whatever the row lengths), at most `cap`
+    // rows each (their sums share the LDS); greedy over the rows' product counts, on the host
+    std::vector<uint32_t> rb_start;
+    uint32_t n_rb = 0, R = 1;
+    {
+        const uint32_t cap = t3_cap_rows(m->dtype);
+        const uint64_t per_block = (uint64_t)(t3_tile_target(m->dtype) * (double)n_cb);
+        std::vector<uint32_t> h_cnt(m->n_rows);
+        if (m->n_rows) SMH_HIP(hipMemcpyAsync(h_cnt.data(), rcount, h_cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        SMH_HIP(hipStreamSynchronize(s));
+        size_t r = 0;
+        while (r < m->n_rows) {
+            rb_start.push_back((uint32_t)r);
+            uint64_t have = 0;
+            size_t e = r;
+            while (e < m->n_rows && e - r < cap && (e == r || have + h_cnt[e] <= per_block)) have += h_cnt[e++];
+            r = e;
+        }
+        if (rb_start.empty()) rb_start.push_back(0);
+        rb_start.push_back((uint32_t)m->n_rows);
+        n_rb = (uint32_t)(rb_start.size() - 1);
+        for (uint32_t b = 0; b < n_rb; ++b) R = std::max(R, rb_start[b + 1] - rb_start[b]);
+    }
+    const uint64_t table_entries = (uint64_t)(n_rb + 1) * n_cb;
+    if (table_entries * 4 > (4ull << 30))
+        return fail(SMH_ERR_INVALID, "tiled variant: %u column slices x %u row blocks need a tile table beyond 4 GiB", n_cb, n_rb);
+    // (+ a round of slack: a tile's loads cover whole rounds whatever its length)
+    SMH_HIP(hipMalloc(&m->d_t2_prod, (n_prod + 2 * CH) * sizeof(T)));
+    SMH_HIP(hipMalloc((void **)&m->d_t2_row, (n_prod + 2 * CH) * sizeof(uint16_t)));
     SMH_HIP(hipMalloc((void **)&m->d_t2_tstart, table_entries * sizeof(uint32_t)));
     SMH_HIP(hipMalloc((void **)&m->d_t2_rbstart, rb_start.size() * sizeof(uint32_t)));
     SMH_HIP(hipMemcpyAsync(m->d_t2_rbstart, rb_start.data(), rb_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    SMH_HIP(hipMemsetAsync(m->d_t2_val, 0, (tot + 8) * sizeof(T), s));
-    SMH_HIP(hipMemsetAsync(m->d_t2_prod, 0, (tot + 8) * sizeof(T), s));
-    SMH_HIP(hipMemsetAsync(m->d_t2_code, 0, (tot + 8) * sizeof(uint16_t), s));
-    SMH_HIP(hipMemsetAsync(m->d_t2_row, 0, (tot + 8) * sizeof(uint16_t), s));
-    SMH_HIP(hipMemcpyAsync(m->d_t2_cbptr, cb_ptr.data(), cb_ptr.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    if (nnz) {
-        hipLaunchKernelGGL(k_t2_fill<T>, dim3(grid), dim3(kBlock), 0, s, m->d_off, (uint64_t)m->n_rows, m->d_col, (const T *)m->d_val, key_s, perm, nnz,
-                           d_start, m->d_t2_cbptr, m->d_t2_rbstart, n_rb, (T *)m->d_t2_val, m->d_t2_code, m->d_t2_row, row_full);
+    SMH_HIP(hipMemsetAsync(m->d_t2_prod, 0, (n_prod + 2 * CH) * sizeof(T), s));
+    SMH_HIP(hipMemsetAsync(m->d_t2_row, 0xFF, (n_prod + 2 * CH) * sizeof(uint16_t), s));  // (slack: rows no block has -- masked anyway)
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_t3_rowcode, dim3(wgrid), dim3(kBlock), 0, s, n_chunks, obase, preal, prow, m->d_t2_rbstart, n_rb, R, m->d_t2_row);
         SMH_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_t2_table, dim3(grid), dim3(kBlock), 0, s, row_full, d_start, m->d_t2_cbptr, n_cb, n_rb, m->d_t2_rbstart, m->d_t2_tstart);
+    // (obase of a slice's first chunk = where its products begin; empty slices have none)
+    hipLaunchKernelGGL(k_t3_table, dim3(grid), dim3(kBlock), 0, s, prow, m->d_t3_cptr, obase, n_cb, n_rb, m->d_t2_rbstart, m->d_t2_tstart);
     SMH_HIP(hipGetLastError());
     SMH_HIP(hipStreamSynchronize(s));
-    // 128 KiB of dynamic LDS (f64) need the attribute on every device the kernel runs on: set with each build, on the matrix's device
-    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
-    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
-    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t2_expand<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kT2Slice * sizeof(T))));
+    // 128 KiB and more of dynamic LDS need the attribute on every device the kernel runs on: set with each build, on the matrix's device
+    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t3_expand<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T))));
+    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t3_reduce<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(kT3Waves * ((size_t)R + 1) * sizeof(T))));
     m->t2_n_cb = n_cb;
     m->t2_n_rb = n_rb;
     m->t2_R = R;
-    m->t2_tot = tot;
+    m->t2_tot = slots;
+    m->t3_n_chunks = n_chunks;
+    m->t3_n_prod = n_prod;
+    (void)E;
     return SMH_OK;
 }
 
 void tiled_free(::smh_crs *m) {
+    if (tiled_use_v1()) return tiled_v1_free(m);
     (void)hipFree(m->d_t2_val); (void)hipFree(m->d_t2_prod); (void)hipFree(m->d_t2_code); (void)hipFree(m->d_t2_row);
-    (void)hipFree(m->d_t2_cbptr); (void)hipFree(m->d_t2_tstart); (void)hipFree(m->d_t2_rbstart);
+    (void)hipFree(m->d_t3_cptr); (void)hipFree(m->d_t3_chunk); (void)hipFree(m->d_t2_tstart); (void)hipFree(m->d_t2_rbstart);
     m->d_t2_val = m->d_t2_prod = nullptr;
     m->d_t2_code = m->d_t2_row = nullptr;
-    m->d_t2_cbptr = nullptr;
+    m->d_t3_cptr = nullptr;
+    m->d_t3_chunk = nullptr;
     m->d_t2_tstart = m->d_t2_rbstart = nullptr;
     m->t2_built = m->t2_ok = false;
 }
 
 int tiled_build(::smh_crs *m) {
-    if (m->t2_built) return SMH_OK;
+    if (tiled_use_v1()) return tiled_v1_build(m);
+    if (m->t2_built) return m->t2_ok ? SMH_OK : fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
+    SMH_TRY(columns_within_n_cols(m, "tiled variant"));  // (the slice tables are sized from n_cols)
     m->t2_built = true;
     const int rc = m->dtype == SMH_F64 ? build_t<double>(m) : build_t<float>(m);
     if (rc != SMH_OK) {
@@ -469,29 +734,60 @@ int tiled_build(::smh_crs *m) {
     return SMH_OK;
 }
 
+// the plan's integer structure (and the copy) for inspection: `which` as in include/sparsemat_hip.h (smh_crs_tiled_array)
+int tiled_array(::smh_crs *m, int which, void *out, size_t capacity_bytes, size_t *bytes_out) {
+    if (tiled_use_v1()) return fail(SMH_ERR_INVALID, "smh_crs_tiled_array: not available with SMH_TILED_V1=1");
+    const size_t vs = dtype_size(m->dtype), chunk_slots = m->dtype == SMH_F64 ? t3_chunk<double>() : t3_chunk<float>();
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = m->d_t3_cptr; bytes = ((size_t)m->t2_n_cb + 1) * 4; break;
+        case 1: src = m->d_t3_chunk; bytes = (size_t)m->t3_n_chunks * sizeof(T3Chunk); break;
+        case 2: src = m->d_t2_code; bytes = (size_t)m->t3_n_chunks * chunk_slots * 2; break;
+        case 3: src = m->d_t2_val; bytes = (size_t)m->t3_n_chunks * chunk_slots * vs; break;
+        case 4: src = m->d_t2_row; bytes = (size_t)m->t3_n_prod * 2; break;
+        case 5: src = m->d_t2_rbstart; bytes = ((size_t)m->t2_n_rb + 1) * 4; break;
+        case 6: src = m->d_t2_tstart; bytes = ((size_t)m->t2_n_rb + 1) * m->t2_n_cb * 4; break;
+        case 7: src = m->d_t2_prod; bytes = (size_t)m->t3_n_prod * vs; break;
+        default: return fail(SMH_ERR_INVALID, "smh_crs_tiled_array: unknown array %d", which);
+    }
+    if (bytes_out) *bytes_out = bytes;
+    if (!out) return SMH_OK;
+    if (capacity_bytes < bytes) return fail(SMH_ERR_INVALID, "smh_crs_tiled_array: %zu bytes needed, %zu given", bytes, capacity_bytes);
+    if (bytes) {
+        SMH_HIP(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, m->stream));
+        SMH_HIP(hipStreamSynchronize(m->stream));
+    }
+    return SMH_OK;
+}
+
 template <typename T>
 static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
-    const size_t lds1 = (size_t)kT2Slice * sizeof(T), lds2 = (size_t)kT2Waves * m->t2_R * sizeof(T);
-    // a workgroup pays for staging its slice of x (16384 entries), so it should multiply several times as many entries: ~65 000 per
-    // workgroup, two 16-byte pieces per thread in flight (profiles/r02_tiled_pass1.log: C2-uniform / C3 with 8 parts per slice 1.14 /
-    // 2.17 ms against 1.22 / 2.32 with 5 parts and 8 pieces; 2 M rows x 16 f64 with 2 / 4 / 8 / 32 parts 0.208 / 0.216 / 0.227 / 0.319)
-    const uint64_t per_slice = m->t2_tot / (m->t2_n_cb ? m->t2_n_cb : 1);
-    uint32_t parts = (uint32_t)((per_slice + 32768) / 65536);
-    int unroll = T2Lane<T>::kUnroll;
-    if (const char *e = getenv("SMH_TILED_PARTS")) { const int v = atoi(e); if (v >= 1) parts = (uint32_t)v; }      // tuning knobs
-    if (const char *e = getenv("SMH_TILED_UNROLL")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) unroll = v; }
-    parts = parts < 1 ? 1 : (parts > 32 ? 32 : parts);
-    auto *kern = unroll == 4 ? k_t2_expand<T, 4> : unroll == 8 ? k_t2_expand<T, 8> : k_t2_expand<T, 2>;
-    hipLaunchKernelGGL(kern, dim3(m->t2_n_cb * parts), dim3(kT2ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val,
-                       m->d_t2_code, m->d_t2_cbptr, (T *)m->d_t2_prod, parts);
-    SMH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_t2_reduce<T>, dim3((m->t2_n_rb + kT2Waves - 1) / kT2Waves), dim3(kT2Waves * 64), lds2, s, (const T *)m->d_t2_prod, m->d_t2_row,
-                       m->d_t2_cbptr, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb, m->d_t2_rbstart, m->t2_R, (T *)y);
+    constexpr uint32_t CH = t3_chunk<T>();
+    const size_t lds1 = ((size_t)kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T), lds2 = (size_t)kT3Waves * ((size_t)m->t2_R + 1) * sizeof(T);
+    static const uint32_t xcd_map = getenv("SMH_TILED_XCD") ? (uint32_t)atoi(getenv("SMH_TILED_XCD")) : 3u;  // tuning knob: bit 0 pass 1, bit 1 pass 2
+    if (m->t3_n_chunks) {
+        // a workgroup pays for staging its slice of x (16384 entries), so it should fold several times as many entries: ~65 000
+        // (round 2's measurement, profiles/r02_tiled_pass1.log) = 16 chunks per wavefront
+        const uint64_t per_slice = (uint64_t)m->t3_n_chunks * CH / (m->t2_n_cb ? m->t2_n_cb : 1);
+        uint32_t parts = (uint32_t)((per_slice + 32768) / 65536);
+        if (const char *e = getenv("SMH_TILED_PARTS")) { const int v = atoi(e); if (v >= 1) parts = (uint32_t)v; }  // tuning knob
+        parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
+        // (the remapped grid is rounded up to a multiple of 8 so that every XCD's run has the same length)
+        const uint32_t g1 = m->t2_n_cb * parts, g1r = (xcd_map & 1u) ? (g1 + 7u) & ~7u : g1;
+        hipLaunchKernelGGL(k_t3_expand<T>, dim3(g1r), dim3(kT3ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val, m->d_t2_code,
+                           m->d_t3_cptr, (const T3Chunk *)m->d_t3_chunk, (T *)m->d_t2_prod, parts, g1, xcd_map & 1u);
+        SMH_HIP(hipGetLastError());
+    }
+    const uint32_t g2 = (m->t2_n_rb + kT3Waves - 1) / kT3Waves, g2r = (xcd_map & 2u) ? (g2 + 7u) & ~7u : g2;
+    hipLaunchKernelGGL(k_t3_reduce<T>, dim3(g2r), dim3(kT3Waves * 64), lds2, s, (const T *)m->d_t2_prod, m->d_t2_row, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb,
+                       m->d_t2_rbstart, m->t2_R, (T *)y, xcd_map >> 1 & 1u);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
 
 int launch_spmv_tiled(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
+    if (tiled_use_v1()) return launch_spmv_tiled_v1(m, x, x_len, y, s);
     if (m->n_rows == 0) return SMH_OK;
     return m->dtype == SMH_F64 ? launch_t<double>(m, x, x_len, y, s) : launch_t<float>(m, x, x_len, y, s);
 }

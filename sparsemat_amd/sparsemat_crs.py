@@ -207,12 +207,27 @@ class SparseMatCRS:
         """K2c: column blocks of 2**shift columns (0: automatic, 2 MiB of x)."""
         check(lib().smh_crs_set_colblock_shift(self._h, shift))
 
-    def tiled_layout(self):
+    def tiled_layout(self, arrays=False):
         """K2t (``smh_crs_tiled_layout``; builds the 2-D tiled copy on first use): dict with n_slices, slice_columns,
-        rows_per_block, n_row_blocks, copy_entries."""
-        a, b, c, d, e = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_size_t()
-        check(lib().smh_crs_tiled_layout(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
-        return {"n_slices": a.value, "slice_columns": b.value, "rows_per_block": c.value, "n_row_blocks": d.value, "copy_entries": e.value}
+        rows_per_block, n_row_blocks, copy_entries, n_products; with ``arrays`` also the plan's arrays
+        (``smh_crs_tiled_array``): slice_chunks, chunks (n x 2: first product slot, entries), codes, values, product_rows,
+        row_block_start, tile_start ((n_row_blocks + 1) x n_slices), products (of the last launch)."""
+        a, b, c, d, e, f = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_size_t(), C.c_size_t()
+        check(lib().smh_crs_tiled_layout(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f)))
+        out = {"n_slices": a.value, "slice_columns": b.value, "rows_per_block": c.value, "n_row_blocks": d.value, "copy_entries": e.value,
+               "n_products": f.value}
+        if arrays:
+            kinds = (("slice_chunks", np.uint32), ("chunks", np.uint32), ("codes", np.uint16), ("values", self.dtype), ("product_rows", np.uint16),
+                     ("row_block_start", np.uint32), ("tile_start", np.uint32), ("products", self.dtype))
+            for which, (name, dt) in enumerate(kinds):
+                n = C.c_size_t()
+                check(lib().smh_crs_tiled_array(self._h, which, None, 0, C.byref(n)))
+                buf = np.empty(n.value // np.dtype(dt).itemsize, dtype=dt)
+                check(lib().smh_crs_tiled_array(self._h, which, buf.ctypes.data, buf.nbytes, None))
+                out[name] = buf
+            out["chunks"] = out["chunks"].reshape(-1, 2)
+            out["tile_start"] = out["tile_start"].reshape(d.value + 1, a.value)
+        return out
 
     def colsplit_flag(self):
         """True when the handle keeps a row-length split (builds it on first use)."""

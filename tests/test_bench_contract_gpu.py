@@ -13,10 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
 
 
-def run_bench(args, env=None, launcher=None):
+def run_bench(args, env=None, launcher=None, expect_rc=0):
     cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == expect_rc, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]  # exactly one line on stdout
     return json.loads(lines[0])
@@ -29,6 +29,9 @@ def test_single_gpu_line(gpu):
     assert (d["n_gpus"], d["steps"], d["warmup"], d["dtype"], d["scaling"], d["vs_baseline"]) == (1, 7, 2, "f32", "weak", None)
     assert d["metric"] == "csr_spmv_effective_hbm_GBps" and d["unit"] == "GB/s" and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the headline sits on SURVEY 8d's literal pattern; the stratified subset rides along
+    assert d["config"]["pattern"] == "window" and "without replacement from [i-4096, i+4096]" in d["config"]["workload"]
+    assert d["other_pattern"]["pattern"] == "stratified" and d["other_pattern"]["launches"] == 20 and d["other_pattern"]["kernel_ms"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches"] == 7 and r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"] and r["traffic"] is None
@@ -70,8 +73,9 @@ def test_one_rank_under_the_launcher(gpu):
 
 def test_a_hanging_optional_leg_does_not_cost_the_headline(gpu):
     """The extras of an N > 1 line (exchange self-check, all-gather leg) run after the headline under a watchdog: with a leg that
-    never returns, the line still comes out, marked, and the process exits with status 0."""
+    never returns, the line still comes out, marked with the leg that hung -- and the process exits with status 3, not 0: a hung
+    collective on a process that owns the GPU must not look like a successful run."""
     env = {"SMH_BENCH_SHARE_DEVICES": "1", "SMH_BENCH_HANG_IN_LEGS": "1", "SMH_BENCH_WATCHDOG_S": "3"}
-    d = run_bench(["--gpus", "2", "--rows", "300000", "--steps", "3", "--warmup", "1"], env)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and "gave up after 3 s" in d["optional_legs"]
+    d = run_bench(["--gpus", "2", "--rows", "300000", "--steps", "3", "--warmup", "1"], env, expect_rc=3)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "gave up after 3 s" in d["optional_legs"] and d["hung_leg"] == "exchange_check"
     assert "exchange_check" not in d and "allgather_leg" not in d

@@ -1,95 +1,72 @@
-"""K2t (spmv_tiled.hip): y = A x in two streaming passes over a 2-D tiled copy -- products against slices of x held in
-LDS, then one wavefront per block of rows folding its tiles slice by slice.  Checked three ways: within the parity bound
-of the storage-order oracle (the reference's loop, sparsematrix.rs:146-158); BIT-EXACT against a numpy restatement of the
-kernel's own summation order (per row: slices ascending, storage order inside a slice, each slice's sum added to the row's
-running sum); bitwise reproducible from launch to launch."""
+"""K2t (spmv_tiled.hip): y = A x in two streaming passes over a 2-D tiled copy -- products against slices of x held in LDS,
+folded per (row, slice) inside pass 1, then one wavefront per block of rows adding its tiles slice by slice.  Checked four ways:
+the plan's INTEGER STRUCTURE (chunks, continuation bits, product slots, row blocks, row codes, tile table) array by array
+against a numpy restatement of the build (tests/tiled_model.py); the result within the parity bound of the storage-order
+oracle (the reference's loop, sparsematrix.rs:146-158); pass 1's products and y BIT-EXACT against the numpy restatement of
+the kernels' own summation order; bitwise reproducible from launch to launch."""
 import numpy as np
 import pytest
 
 import oracle
 import sparsemat_amd as sm
+from tiled_model import SLICE, TiledModel
 from util import assert_spmv_close, random_crs
 
 pytestmark = pytest.mark.gpu
-
-SLICE = 16384
 
 
 def bits(a):
     return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
 
 
-def tiled_reference(off, col, val, x, n_rows):
-    """The kernel's order in the value type: prod = round(val * x[col]); per (row, slice) a left fold from the first product;
-    y = ((0 + S_slice_a) + S_slice_b) + ... over the slices the row touches, ascending."""
-    dt = val.dtype.type
-    y = np.zeros(n_rows, dtype=val.dtype)
-    prod = (val * x[col]).astype(val.dtype)
-    sl = (col // SLICE).astype(np.int64)
-    for i in range(n_rows):
-        a, e = int(off[i]), int(off[i + 1])
-        if a == e:
-            continue
-        s_i, p_i = sl[a:e], prod[a:e]
-        acc = dt(0)
-        for b in np.unique(s_i):
-            part = p_i[s_i == b]
-            s = part[0]
-            for v in part[1:]:
-                s = dt(s + v)
-            acc = dt(acc + s)
-        y[i] = acc
-    return y
+def check_against_model(m, off, col, val, x, n_rows, n_cols, what, structure=True):
+    lay = m.tiled_layout(arrays=True)
+    mod = TiledModel(off, col, val, n_rows, n_cols)
+    if structure:
+        assert (lay["n_slices"], lay["slice_columns"], lay["n_row_blocks"], lay["rows_per_block"]) == (mod.n_cb, SLICE, mod.n_rb, mod.R), what
+        assert lay["copy_entries"] == mod.n_chunks * mod.CH and lay["n_products"] == mod.n_prod
+        assert np.array_equal(lay["slice_chunks"], mod.slice_chunks) and np.array_equal(lay["chunks"], mod.chunks)
+        assert np.array_equal(lay["codes"], mod.codes) and np.array_equal(bits(lay["values"]), bits(mod.values))
+        assert np.array_equal(lay["row_block_start"], mod.rb_start) and np.array_equal(lay["product_rows"], mod.product_rows)
+        assert np.array_equal(lay["tile_start"], mod.tile_start)
+    y = m.mvp(x, variant="tiled")
+    prod = mod.products(val, x)
+    got = m.tiled_layout(arrays=True)["products"]
+    assert np.array_equal(bits(got[mod.real]), bits(prod[mod.real])), what + ": pass 1's product sums"
+    assert np.array_equal(bits(y), bits(mod.reduce(prod))), what + ": y in the kernels' own order"
+    assert np.array_equal(bits(y), bits(m.mvp(x, variant="tiled"))), what + ": run-to-run"
+    return y, lay
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("kind", ["short", "uniform32", "ragged", "skewed", "empty_heavy"])
-def test_tiled_product_in_its_own_order_and_within_the_bound(gpu, dtype, kind):
-    rng = np.random.default_rng({"short": 30, "uniform32": 31, "ragged": 32, "skewed": 33, "empty_heavy": 34}[kind])
+@pytest.mark.parametrize("kind", ["short", "uniform32", "ragged", "skewed", "empty_heavy", "dense_rows"])
+def test_tiled_structure_products_and_result(gpu, dtype, kind):
+    rng = np.random.default_rng({"short": 30, "uniform32": 31, "ragged": 32, "skewed": 33, "empty_heavy": 34, "dense_rows": 38}[kind])
     n_rows, n_cols = 6007, 5 * SLICE - 331  # 5 column slices, the last one short
     if kind == "short":
-        lens = rng.integers(0, 5, n_rows)          # tiles of ~50 entries: one round per tile
+        lens = rng.integers(0, 5, n_rows)
     elif kind == "uniform32":
-        lens = np.full(n_rows, 32)                 # 64-row blocks hold ~400 entries per tile: several rounds, runs across them
+        lens = np.full(n_rows, 32)                 # ~6 entries per (row, slice): every row is folded inside pass 1
     elif kind == "ragged":
         lens = rng.integers(0, 70, n_rows)
     elif kind == "skewed":
         lens = rng.integers(0, 6, n_rows)
-        lens[17] = 9000                            # ~1800 entries of ONE row in every tile it touches
-        lens[4000:4100] = 300
+        lens[17] = 9000                            # ~1800 entries of ONE row per slice: cut by 7 chunk boundaries, merged again in pass 2
+        lens[4000:4100] = 300                      # ~60 per slice: runs longer than the snap distance
+    elif kind == "dense_rows":
+        lens = np.zeros(n_rows, dtype=np.int64)    # every tile is a handful of long runs (equal neighbours in every round of pass 2)
+        lens[::97] = 2500
     else:
         lens = rng.integers(0, 5, n_rows)
         lens[rng.random(n_rows) < 0.8] = 0
     off, col, val = random_crs(rng, n_rows, n_cols, lens, dtype, dup=True)
     x = rng.uniform(-1, 1, n_cols).astype(dtype)
     m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
-    lay = m.tiled_layout()
-    assert lay["n_slices"] == 5 and lay["slice_columns"] == SLICE
-    # row blocks of equal entry counts (~48 per tile): never fewer blocks than the largest one would give
-    assert lay["n_row_blocks"] >= -(-n_rows // lay["rows_per_block"]) and lay["rows_per_block"] <= 3072
-    if len(col):
-        assert 0.5 < len(col) / (lay["n_row_blocks"] * 5 * 48.0) < 1.5 or kind in ("skewed", "empty_heavy")
-    cnt = np.bincount((col // SLICE).astype(np.int64), minlength=5)
-    assert lay["copy_entries"] == int(((cnt + 7) // 8 * 8).sum())
-    y = m.mvp(x, variant="tiled")
+    y, lay = check_against_model(m, off, col, val, x, n_rows, n_cols, "tiled " + kind)
     assert_spmv_close(y, off, col, val, x, "tiled " + kind)
-    assert np.array_equal(bits(y), bits(tiled_reference(off, col, val, x, n_rows)))
-    assert np.array_equal(bits(y), bits(m.mvp(x, variant="tiled")))  # run-to-run reproducible
+    assert lay["n_slices"] == 5 and lay["rows_per_block"] <= (3328 if dtype == np.float32 else 1664)
+    assert lay["n_products"] <= len(col) + 4 * len(lay["chunks"])  # never more product slots than entries (+ the 16-byte padding)
     assert m.resolved_variant()[0] != "tiled"  # x is tiny: AUTO never picks it here
-
-
-def test_tiled_single_slice_equals_the_reference_order(gpu):
-    """One column slice: the kernel's order IS the reference's (storage order from the first entry) -> the oracle's bits."""
-    rng = np.random.default_rng(35)
-    n_rows, n_cols = 3001, 9000
-    off, col, val = random_crs(rng, n_rows, n_cols, rng.integers(0, 40, n_rows), np.float32, dup=True)
-    x = rng.uniform(-1, 1, n_cols).astype(np.float32)
-    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
-    assert m.tiled_layout()["n_slices"] == 1
-    y = m.mvp(x, variant="tiled")
-    # the oracle starts from +0 and adds the first product (0 + p = p exactly, except that -0 becomes +0)
-    ref = oracle.spmv(off, col, val, x)
-    assert np.array_equal(bits(y + np.float32(0)), bits(ref + np.float32(0)))
 
 
 def test_tiled_follows_value_updates_and_edge_shapes(gpu):
@@ -100,15 +77,16 @@ def test_tiled_follows_value_updates_and_edge_shapes(gpu):
     x = rng.uniform(-1, 1, n_cols).astype(f)
     m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
     assert_spmv_close(m.mvp(x, variant="tiled"), off, col, val, x, "before")
+    mod = TiledModel(off, col, val, n_rows, n_cols)
     m.scale(-0.5)
-    y = m.mvp(x, variant="tiled")
-    assert np.array_equal(bits(y), bits(tiled_reference(off, col, (val * -0.5), x, n_rows)))
+    assert np.array_equal(bits(m.mvp(x, variant="tiled")), bits(mod.reduce(mod.products(val * -0.5, x))))
     val2 = rng.uniform(-1, 1, len(val)).astype(f)
     m.update_values(val2)
-    assert np.array_equal(bits(m.mvp(x, variant="tiled")), bits(tiled_reference(off, col, val2, x, n_rows)))
+    want = mod.reduce(mod.products(val2, x))
+    assert np.array_equal(bits(m.mvp(x, variant="tiled")), bits(want))
     # an x longer than n_cols is fine, a shorter one only if it covers the largest column (densevec.rs:40-42: the gather panics)
     xl = np.concatenate([x, np.ones(7, f)])
-    assert np.array_equal(bits(m.mvp(xl, variant="tiled")), bits(tiled_reference(off, col, val2, x, n_rows)))
+    assert np.array_equal(bits(m.mvp(xl, variant="tiled")), bits(want))
     with pytest.raises(sm.SparseMatPanic) as e:
         m.mvp(x[:int(col.max())], variant="tiled")
     assert "index out of bounds" in str(e.value)
@@ -121,20 +99,51 @@ def test_tiled_follows_value_updates_and_edge_shapes(gpu):
     cols = np.arange(0, 4 * SLICE, 97, dtype=np.uint32)
     m = sm.SparseMatCRS.from_raw_parts(1, 4 * SLICE, [0, len(cols)], cols, np.ones(len(cols), f))
     xx = rng.uniform(-1, 1, 4 * SLICE).astype(f)
-    assert np.array_equal(bits(m.mvp(xx, variant="tiled")), bits(tiled_reference(np.array([0, len(cols)]), cols, np.ones(len(cols), f), xx, 1)))
+    one = TiledModel(np.array([0, len(cols)]), cols, np.ones(len(cols), f), 1, 4 * SLICE)
+    assert np.array_equal(bits(m.mvp(xx, variant="tiled")), bits(one.reduce(one.products(np.ones(len(cols), f), xx))))
 
 
-def test_tiled_rows_whose_block_is_not_a_power_of_two_and_many_slices(gpu):
-    """Rows per block follow the density (here ~48 entries per tile -> a few hundred rows, not a power of two); 40 slices
-    walk the reduce pass's 64-tile table window and its 8-tile batches through their edges (40 = 5 batches)."""
+def test_tiled_many_slices_and_row_blocks(gpu):
+    """40 / 67 / 129 slices walk the reduce pass's 64-tile table window and its 4-tile batches through their edges; short rows
+    make row blocks of thousands of rows (the cap) whose tiles hold a few dozen products."""
     rng = np.random.default_rng(37)
     for n_slices, dtype in ((40, np.float32), (67, np.float64), (129, np.float32)):
         n_rows, n_cols = 20011, n_slices * SLICE - 3
         off, col, val = random_crs(rng, n_rows, n_cols, rng.integers(0, 9, n_rows), dtype)
         x = rng.uniform(-1, 1, n_cols).astype(dtype)
         m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
-        lay = m.tiled_layout()
+        y, lay = check_against_model(m, off, col, val, x, n_rows, n_cols, "tiled %d slices" % n_slices)
         assert lay["n_slices"] == n_slices and lay["rows_per_block"] > 64
-        y = m.mvp(x, variant="tiled")
         assert_spmv_close(y, off, col, val, x, "tiled %d slices" % n_slices)
-        assert np.array_equal(bits(y), bits(tiled_reference(off, col, val, x, n_rows)))
+
+
+def test_tiled_tiles_of_several_rounds(gpu):
+    """Row blocks hold target x n_slices products; with every column inside the FIRST of four slices all of them land in one tile:
+    ~700 (f32) / ~240 (f64) products = 3 / 2 rounds of 64 E -- the reduce pass's later rounds (direct loads, masks at both ends)."""
+    rng = np.random.default_rng(39)
+    n_rows, n_cols = 9000, 4 * SLICE
+    lens = rng.integers(1, 4, n_rows)
+    for dtype in (np.float32, np.float64):
+        off, col, val = random_crs(rng, n_rows, SLICE - 7, lens, dtype)
+        x = rng.uniform(-1, 1, n_cols).astype(dtype)
+        m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+        y, lay = check_against_model(m, off, col, val, x, n_rows, n_cols, "long tiles")
+        tiles = np.diff(lay["tile_start"].astype(np.int64), axis=0)
+        assert tiles[:, 0].max() > (256 if dtype == np.float32 else 128) and not tiles[:, 1:].any()
+        assert_spmv_close(y, off, col, val, x, "long tiles")
+
+
+def test_tiled_refuses_columns_beyond_n_cols(gpu):
+    """A handle made without validation may hold a column >= n_cols (smh_crs_create_dev's default); the tiled / column-blocked
+    builders size their tables from n_cols and must refuse it instead of walking past them."""
+    f = np.float32
+    off = np.array([0, 2, 3], dtype=np.uint32)
+    col = np.array([1, 70000, 5], dtype=np.uint32)  # n_cols says 100
+    val = np.ones(3, f)
+    m = sm.SparseMatCRS.from_raw_parts(2, 100, off, col, val, validate=False)
+    x = np.ones(70001, f)
+    for variant in ("tiled", "colblock", "colfused", "colsplit"):
+        with pytest.raises(sm.SparseMatPanic) as e:
+            m.mvp(x, variant=variant)
+        assert ">= n_cols" in str(e.value), variant
+    assert np.array_equal(m.mvp(x, variant="seq"), np.array([2.0, 1.0], f))  # the row-major kernels only need x to reach

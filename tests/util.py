@@ -65,11 +65,17 @@ def _log_buckets(what, dt, lens, excess):
             pass
 
 
+# what the suite reports at its end (tests/conftest.py): rows compared, rows that needed the looser form, worst literal ratio
+PARITY_STATS = {"comparisons": 0, "rows": 0, "fallback_rows": 0, "worst_literal": {}}
+
+
 def assert_spmv_close(y, off, col, val, x, what=""):
-    """north_star's bound without a row-length allowance: against an (effectively) exact row sum, the device result may be
-    no further off than the reference's own storage-order sequential sum (the oracle) plus 1e-5 * sum_j |a_ij x_j|
-    (1e-12 for f64).  So a kernel is never blamed for the reference's rounding of a 2048-entry row, and never gets
-    credit for it either: |y_gpu - exact| <= |y_oracle - exact| + tol * sum|a x| per row, and the same normwise."""
+    """SURVEY 8(d)'s componentwise gate, literally: |y_gpu - y_oracle| <= tol * sum_j |a_ij x_j| per row (tol 1e-5 for f32,
+    1e-12 for f64), the oracle being the reference's storage-order sequential sum.  Only a row in which THE ORACLE ITSELF is
+    further than tol * sum|a x| from the (effectively) exact row sum -- the reference's own rounding of a very long row --
+    may instead satisfy |y_gpu - exact| <= |y_oracle - exact| + tol * sum|a x|: there the device is held to being no worse
+    than the reference, not to reproducing its error.  Such rows are counted (PARITY_STATS; the suite prints the total) --
+    none is expected at these tolerances.  The same normwise."""
     dt = np.dtype(val.dtype)
     y_ref = oracle.spmv(off, col, val, x)
     assert y.shape == y_ref.shape, what
@@ -77,14 +83,31 @@ def assert_spmv_close(y, off, col, val, x, what=""):
     lens = np.diff(off.astype(np.int64))
     exact = exact_row_sums(off, col, val, x)
     wide = exact.dtype
+    tol = REL_TOL[dt]
+    tiny = np.finfo(dt).tiny
+    literal = np.abs(y.astype(wide) - y_ref.astype(wide)).astype(np.float64)
     err_gpu = np.abs(y.astype(wide) - exact).astype(np.float64)
     err_ref = np.abs(y_ref.astype(wide) - exact).astype(np.float64)
     excess = (err_gpu - err_ref) / np.maximum(scale, 1e-300)
     _log_buckets(what, dt, lens, excess)
-    bad = err_gpu > err_ref + REL_TOL[dt] * scale + np.finfo(dt).tiny
-    assert not bad.any(), "%s: %d rows out of bound, worst excess %g * sum|a x| (row %d, len %d)" % (
+    fails_literal = literal > tol * scale + tiny
+    oracle_is_far = err_ref > tol * scale + tiny          # the only rows the looser form is for
+    fallback = fails_literal & oracle_is_far
+    PARITY_STATS["comparisons"] += 1
+    PARITY_STATS["rows"] += int(len(lens))
+    PARITY_STATS["fallback_rows"] += int(fallback.sum())
+    if len(lens):
+        w = float((literal / np.maximum(scale, 1e-300)).max())
+        PARITY_STATS["worst_literal"][dt.name] = max(PARITY_STATS["worst_literal"].get(dt.name, 0.0), w)
+    bad = fails_literal & ~oracle_is_far
+    assert not bad.any(), "%s: %d rows beyond |y_gpu - y_oracle| <= %g * sum|a x|, worst %g (row %d, len %d)" % (
+        what, bad.sum(), tol, float((literal / np.maximum(scale, 1e-300))[bad].max()), int(np.argmax(bad)), int(lens[np.argmax(bad)]))
+    bad = fallback & (err_gpu > err_ref + tol * scale + tiny)
+    assert not bad.any(), "%s: %d rows out of the excess bound, worst excess %g * sum|a x| (row %d, len %d)" % (
         what, bad.sum(), excess.max(), int(np.argmax(excess)), int(lens[np.argmax(excess)]))
-    denom = float(np.abs(exact).max()) if len(exact) else 0.0
-    if denom > 0:
-        assert err_gpu.max() / denom <= err_ref.max() / denom + REL_TOL[dt], what
+    denom = float(np.abs(y_ref.astype(np.float64)).max()) if len(y_ref) else 0.0
+    if denom > 0:  # normwise, literal: max |y_gpu - y_oracle| <= tol * max |y_oracle| (else: no worse than the oracle against exact)
+        if literal.max() / denom > tol:
+            denom = float(np.abs(exact).max())
+            assert err_gpu.max() / denom <= err_ref.max() / denom + tol, what
     return y_ref
