@@ -221,9 +221,10 @@ static int resolve_variant(const smh_crs *m, int variant) {
             if (pays) return SMH_SPMV_TILED;
             return SMH_SPMV_COLFUSED;
         }
-        // skewed rows: K2t cuts its row blocks by entries, so long rows cost it nothing special -- on f64 with many column blocks
-        // (C3: 2.57 ms against K2s's 2.76 and K2c's 3.25) it is ahead; a 3M-row f32 power law (12 blocks) ties with K2c (0.61 both)
-        if (m->dtype == SMH_F64 && cf_blocks_for(m) >= 24 && !m->no_split && tiled_fits(m)) return SMH_SPMV_TILED;  // (the parts of a K2s split stay as measured)
+        // skewed rows: K2t folds the entries a long row has in one slice inside its first pass and cuts its row blocks by product
+        // counts, so long rows cost it nothing special.  Round 3's form is ahead on both value types: C3 (f64) 1.6 ms against K2s's 2.76
+        // and K2c's 3.25; a 3M-row f32 power law (184 slices) 0.23 ms against K2c's 0.62 (tests/test_auto_choice_gpu.py)
+        if (!m->no_split && tiled_fits(m, m->dtype == SMH_F64 && cf_blocks_for(m) >= 24 ? 12.0 : 32.0)) return SMH_SPMV_TILED;  // (the parts of a K2s split stay as measured)
         // ... and a matrix with a minority of long rows is taken apart by row length (K2s)
         static const bool split_off = getenv("SMH_COLBLOCK_SPLIT") && atoi(getenv("SMH_COLBLOCK_SPLIT")) == 0;  // tuning knob
         // ... when K2c's sweeps (per column block and row: one offset, y read and written) weigh as much as the entries

@@ -251,7 +251,8 @@ struct smh_crs {
     uint32_t *d_t2_rbstart = nullptr;      // first row of each row block (n_rb + 1); blocks hold equal entry counts
     uint32_t *d_t3_cptr = nullptr;         // (round 3's form) first chunk of each slice (n_cb + 1)
     void *d_t3_chunk = nullptr;            // per chunk {where its product sums go, entries}
-    uint32_t t3_n_chunks = 0;
+    uint32_t t3_n_chunks = 0, t3_max_slice_chunks = 0;
+    bool t3_dups = false;                  // a chunk boundary cuts a (row, slice) pair somewhere: pass 2 checks for equal neighbours
     uint64_t t3_n_prod = 0;                // product slots (one per (row, slice, chunk), chunk shares padded to 16 bytes)
     // K1r plan (lazy)
     bool ring_planned = false;

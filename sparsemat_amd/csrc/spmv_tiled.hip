@@ -55,29 +55,35 @@ int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s, uint64_
 constexpr uint32_t kT3Slice = 16384;     // columns per slice: 64 KiB (f32) / 128 KiB (f64) of x in LDS
 constexpr int kT3ExpandThreads = 1024;   // 16 wavefronts: one chunk each per step
 constexpr uint32_t kT3Snap = 16;         // a chunk start moves forward by up to this many entries to the next row boundary
-constexpr int kT3Waves = 4;              // wavefronts (row blocks) per workgroup of the reduce pass
 constexpr int kT3Batch = 4;              // tiles whose loads are in flight together, per wavefront
+constexpr int kT3Ahead = 3;              // pass 1: chunks whose loads are in flight per wavefront
 constexpr uint32_t kT3Cont = 0x8000u;    // code bit 15: same row as the entry before (never set on a chunk's first entry)
 constexpr uint32_t kT3ColMask = 0x3FFFu;
 
 template <typename T> struct T3;
 template <> struct T3<float> {
-    static constexpr int E = 4;
-    typedef float V __attribute__((ext_vector_type(4)));
-    typedef uint32_t C __attribute__((ext_vector_type(2)));  // 4 x u16
+    static constexpr int E1 = 4, E2 = 4;                     // entries per lane: pass 1 (a chunk = 64 E1), pass 2 (a round = 64 E2)
+    typedef float V1 __attribute__((ext_vector_type(4)));
+    typedef float V2 __attribute__((ext_vector_type(4)));
+    typedef uint32_t C2 __attribute__((ext_vector_type(2))); // 4 x u16
     static constexpr uint32_t kCapRows = 3328;               // rows of a row block: 4 x 3329 sums = 52 KiB -> three workgroups per CU
 };
 template <> struct T3<double> {
-    static constexpr int E = 2;
-    typedef double V __attribute__((ext_vector_type(2)));
-    typedef uint32_t C;                                      // 2 x u16
+    static constexpr int E1 = 4, E2 = 2;                     // (pass 1: two 16-byte loads of values per lane; pass 2: one)
+    typedef double V1 __attribute__((ext_vector_type(4)));
+    typedef double V2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t C2;                                     // 2 x u16
     static constexpr uint32_t kCapRows = 1664;               // 4 x 1665 x 8 B = 52 KiB
 };
-template <typename T> constexpr uint32_t t3_chunk() { return 64u * T3<T>::E; }            // slots of a chunk: 256 / 128
-template <typename T> constexpr uint32_t t3_stride() { return t3_chunk<T>() - kT3Snap; }  // nominal entries per chunk: 240 / 112
+typedef uint32_t T3C1 __attribute__((ext_vector_type(2)));   // pass 1: the 4 codes of a lane
+typedef uint32_t t3_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t t3_u8 __attribute__((ext_vector_type(8)));
+constexpr int kT3Rsrc = 0x00020000;                          // dword 3 of a raw buffer descriptor on gfx9 (32-bit data format)
+template <typename T> constexpr uint32_t t3_chunk() { return 64u * T3<T>::E1; }           // slots of a chunk: 256
+template <typename T> constexpr uint32_t t3_stride() { return t3_chunk<T>() - kT3Snap; }  // nominal entries per chunk: 240
 
 static double t3_tile_target(int dtype) {
-    // mean products per tile: a round takes 64 E of them (256 / 128); beyond ~0.7 of that too many tiles need a second round
+    // mean products per tile: a round takes 64 E2 of them (256 / 128); beyond ~0.7 of that too many tiles need a second round
     double v = dtype == SMH_F64 ? 60.0 : 174.0;
     if (const char *e = getenv("SMH_TILED_TILE")) {  // tuning knob
         const double w = atof(e);
@@ -139,8 +145,11 @@ template <typename T, int E> __device__ __forceinline__ uint32_t t3_fold_runs(T 
         through &= cont >> k;
         first_seg |= (through & 1u) << k;
     }
-    // the lanes' last running sums, combined over the wavefront; a lane stops what comes from the left unless all of its entries continue
-    const T run = t3_seg_scan<T>(p[E - 1], (through & 1u) ^ 1u);
+    // the lanes' last running sums, combined over the wavefront; a lane stops what comes from the left unless all of its entries
+    // continue -- and when no lane does (the usual case: a run rarely spans a whole lane) the scan has nothing to combine: the
+    // running sum at the end of a lane is its own last sum (the scan below returns exactly that for all-stop flags)
+    T run = p[E - 1];
+    if (__ballot(through & 1u)) run = t3_seg_scan<T>(run, (through & 1u) ^ 1u);
     const T carry = t3_dpp<0x138, 0xF>(T(0), run);  // wave_shr:1 -- the running sum at the end of the lane before
 #pragma unroll
     for (int k = 0; k < E; ++k)
@@ -155,13 +164,20 @@ template <typename T, int E> __device__ __forceinline__ uint32_t t3_fold_runs(T 
 struct T3Chunk { uint32_t obase, len; };
 
 template <typename T>
+struct T3Slot {
+    typename T3<T>::V1 v;
+    T3C1 cd;
+    uint32_t ob, ln;
+};
+
+template <typename T, int AHEAD>
 __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
                                                                  const uint16_t *__restrict__ code, const uint32_t *__restrict__ cptr,
                                                                  const T3Chunk *__restrict__ chunk, T *__restrict__ prod, uint32_t parts,
                                                                  uint32_t n_items, uint32_t xcd_map) {
-    using V = typename T3<T>::V;
-    using C = typename T3<T>::C;
-    constexpr int E = T3<T>::E;
+    using V = typename T3<T>::V1;
+    using V2 = typename T3<T>::V2;
+    constexpr int E = T3<T>::E1, E2 = T3<T>::E2;
     constexpr uint32_t CH = 64u * E;
     extern __shared__ __attribute__((aligned(16))) char t3_smem[];
     T *xs = (T *)t3_smem;
@@ -179,41 +195,50 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
     const uint32_t c_lo = cptr[cb], c_hi = cptr[cb + 1];
     const uint32_t per = (c_hi - c_lo + parts - 1) / parts;
     const uint32_t k0 = c_lo + part * per, k1 = k0 + per < c_hi ? k0 + per : c_hi;
+    // every wavefront takes a contiguous run of the part's chunks (their descriptors are then one coalesced load per 64 chunks,
+    // handed out with v_readlane), AHEAD chunks' loads in flight while one is folded
     constexpr uint32_t W = kT3ExpandThreads / 64;
+    const uint32_t n_w = (k1 > k0 ? k1 - k0 + W - 1 : 0u) / W;
+    // (wave-uniform by construction; said to the compiler so that the buffer descriptors below live in scalar registers)
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k0 + wave * n_w < k1 ? k0 + wave * n_w : k1));
+    const uint32_t w1 = w0 + n_w < k1 ? w0 + n_w : k1;
     const uint32_t pos = E * lane;
-    auto fetch = [&](uint32_t c, V &v, C &cd, T3Chunk &d) {
-        if (c < k1) {
-            d = chunk[__builtin_amdgcn_readfirstlane(c)];
-            if (pos < d.len) {  // (one region for both loads: whole 16-byte pieces, nothing is fetched for the empty part of a chunk)
-                v = __builtin_nontemporal_load((const V *)(val + (uint64_t)c * CH + pos));
-                cd = __builtin_nontemporal_load((const C *)(code + (uint64_t)c * CH + pos));
-            }
-        }
-    };
-    V v_n = V(0);
-    C c_n = C(0);
-    T3Chunk d_n = {0u, 0u};
-    fetch(k0 + wave, v_n, c_n, d_n);
-    for (uint32_t c = k0 + wave; c < k1; c += W) {
-        const V v = v_n;
-        const C cd = c_n;
-        const T3Chunk d = d_n;
-        v_n = V(0);
-        c_n = C(0);
-        fetch(c + W, v_n, c_n, d_n);  // the next chunk's loads are in flight while this one is folded
-        T p[E];
-        uint32_t cont = 0;
-        if constexpr (E == 4) {
-            p[0] = v.x * xs[cd.x & kT3ColMask]; p[1] = v.y * xs[cd.x >> 16 & kT3ColMask];
-            p[2] = v.z * xs[cd.y & kT3ColMask]; p[3] = v.w * xs[cd.y >> 16 & kT3ColMask];
-            cont = (cd.x >> 15 & 1u) | (cd.x >> 31) << 1 | (cd.y >> 15 & 1u) << 2 | (cd.y >> 31) << 3;
+    // lane l: the descriptor of the wavefront's l-th chunk (the launch sizes the parts so that a wavefront never has more than 64)
+    uint32_t my_ob = 0, my_ln = 0;
+    if (w0 + lane < w1) {
+        const T3Chunk d = chunk[w0 + lane];
+        my_ob = d.obase;
+        my_ln = d.len;
+    }
+    // Loads and stores go through BUFFER instructions whose descriptor covers exactly the chunk's pieces: a lane past them reads
+    // zeros / stores nothing, without a branch -- a branch around a load or store makes the compiler drain every load in flight
+    // before the next use (it cannot count them any more), which is what kept the first form of this loop at one chunk in flight.
+    auto issue = [&](T3Slot<T> &S, uint32_t i) {  // the i-th chunk of this wavefront (beyond its run: an empty one)
+        S.ob = (uint32_t)__builtin_amdgcn_readlane((int)my_ob, (int)(i & 63u));
+        S.ln = (uint32_t)__builtin_amdgcn_readlane((int)my_ln, (int)(i & 63u));
+        const uint64_t at = (uint64_t)(w0 + i) * CH;
+        const uint32_t pieces = (S.ln + E - 1) & ~(uint32_t)(E - 1);  // whole pieces (the rest of the chunk's slots is zero)
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(val + at), 0, (int)(pieces * sizeof(T)), kT3Rsrc);
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(code + at), 0, (int)(pieces * 2u), kT3Rsrc);
+        if constexpr (sizeof(T) == 4) {
+            S.v = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(pos * 4u), 0, 2 /* nt */));
         } else {
-            p[0] = v.x * xs[cd & kT3ColMask]; p[1] = v.y * xs[cd >> 16 & kT3ColMask];
-            cont = (cd >> 15 & 1u) | (cd >> 31) << 1;
+            const t3_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(pos * 8u), 0, 2);
+            const t3_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(pos * 8u + 16u), 0, 2);
+            const t3_u8 ab = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            S.v = __builtin_bit_cast(V, ab);
         }
+        S.cd = __builtin_bit_cast(T3C1, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(pos * 2u), 0, 2));
+    };
+    auto process = [&](const T3Slot<T> &S) {
+        T p[E];
+        p[0] = S.v.x * xs[S.cd.x & kT3ColMask]; p[1] = S.v.y * xs[S.cd.x >> 16 & kT3ColMask];
+        p[2] = S.v.z * xs[S.cd.y & kT3ColMask]; p[3] = S.v.w * xs[S.cd.y >> 16 & kT3ColMask];
+        const uint32_t cont = (S.cd.x >> 15 & 1u) | (S.cd.x >> 31) << 1 | (S.cd.y >> 15 & 1u) << 2 | (S.cd.y >> 31) << 3;
         uint32_t tail = t3_fold_runs<T, E>(p, cont);
-        // entries that exist: pos + k < len
-        const uint32_t have = pos >= d.len ? 0u : (d.len - pos >= (uint32_t)E ? (1u << E) - 1u : (1u << (d.len - pos)) - 1u);
+        // entries that exist: pos + k < len (the slots after them hold zeros without continuation bits: they reach no run's sum,
+        // and no run end is taken from them)
+        const uint32_t have = pos >= S.ln ? 0u : (S.ln - pos >= (uint32_t)E ? (1u << E) - 1u : (1u << (S.ln - pos)) - 1u);
         tail &= have;
         // where each run's sum goes: the number of run ends before it
         uint32_t before = 0, total = 0;
@@ -230,43 +255,61 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
         }
         // the padding of the last 16-byte piece is zero: where a chunk boundary cuts a (row, slice) pair the build gives these
         // slots the pair's row, so that pass 2 sees its parts as neighbours and merges them (else they carry the dump row)
-        if (lane < (uint32_t)E && total + lane < ((total + E - 1) & ~(uint32_t)(E - 1))) stage[total + lane] = T(0);
+        const uint32_t total_r = (total + E2 - 1) & ~(uint32_t)(E2 - 1);
+        if (lane < (uint32_t)E2 && total + lane < total_r) stage[total + lane] = T(0);
         __builtin_amdgcn_wave_barrier();
-        if (pos < total) *(V *)(prod + (uint64_t)d.obase + pos) = *(const V *)(stage + pos);
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(prod + S.ob), 0, (int)(total_r * sizeof(T)), kT3Rsrc);
+#pragma unroll
+        for (int h = 0; h < E / E2; ++h)  // 16 bytes per store; a lane past the chunk's products stores nothing
+            __builtin_amdgcn_raw_buffer_store_b128(*(const t3_u4 *)(stage + pos + h * E2), rp, (int)((pos + h * E2) * sizeof(T)), 0, 0);
         __builtin_amdgcn_wave_barrier();
+    };
+    T3Slot<T> S[AHEAD];
+    // (in THIS order: left alone the scheduler issued the prologue's loads last chunk first, and the loop -- which has to be right
+    // for its first trip too -- then waited for every load in flight before each chunk)
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) {
+        issue(S[u], (uint32_t)u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (uint32_t i = 0; w0 + i < w1; i += AHEAD) {
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            process(S[u]);
+            issue(S[u], i + u + AHEAD);
+        }
     }
 }
 
 // ---- pass 2 -----------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NB>
 struct T3Tiles {
-    typename T3<T>::V pv[kT3Batch];
-    typename T3<T>::C rv[kT3Batch];
-    uint32_t bs[kT3Batch], ln[kT3Batch];
+    typename T3<T>::V2 pv[NB];
+    typename T3<T>::C2 rv[NB];
+    uint32_t bs[NB], ln[NB];
 };
 
 // tstart[rb * n_cb + cb] = index (into prod / rowc) of the first product of tile (cb, rb); row n_rb of the table holds the ends of
-// the last row block's tiles.  rowc: the product's row relative to its block, or `R` (the dump slot) for padding.
-// LDS: kT3Waves * (R + 1) sums.
-template <typename T>
-__global__ __launch_bounds__(kT3Waves * 64) void k_t3_reduce(const T *__restrict__ prod, const uint16_t *__restrict__ rowc,
-                                                              const uint32_t *__restrict__ tstart, uint32_t n_cb, uint32_t n_rb,
-                                                              const uint32_t *__restrict__ rb_start, uint32_t R, T *__restrict__ y,
-                                                              uint32_t xcd_map) {
-    using V = typename T3<T>::V;
-    using C = typename T3<T>::C;
-    constexpr int E = T3<T>::E;
+// the last row block's tiles.  rowc: (the product's row relative to its block + 1) * sizeof(T) -- the byte offset of the row's sum
+// in the wavefront's LDS -- or 0, the dump slot, for padding (so a lane past the tile, which reads zeros, lands there too).
+// One wavefront per workgroup: LDS = (R + 1) sums.  DUPS: the copy has (row, slice) pairs cut by a chunk boundary, i.e. a tile
+// may hold equal neighbours (checked per round; merged first); without them the rows of a round are distinct by construction.
+template <typename T, bool DUPS, int NB>
+__global__ __launch_bounds__(64) void k_t3_reduce(const T *__restrict__ prod, const uint16_t *__restrict__ rowc,
+                                                   const uint32_t *__restrict__ tstart, uint32_t n_cb, uint32_t n_rb,
+                                                   const uint32_t *__restrict__ rb_start, T *__restrict__ y, uint32_t xcd_map) {
+    using V = typename T3<T>::V2;
+    using C = typename T3<T>::C2;
+    constexpr int E = T3<T>::E2;
     constexpr uint32_t RND = 64u * E;
     extern __shared__ __attribute__((aligned(16))) char t3_smem[];
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    uint32_t g = blockIdx.x;  // neighbouring row blocks' tiles share cache lines: neighbours on one XCD (one L2)
-    if (xcd_map) g = (blockIdx.x & 7u) * ((gridDim.x + 7u) / 8u) + (blockIdx.x >> 3);
-    const uint32_t rb = g * kT3Waves + w;
-    if (rb >= n_rb) return;  // whole wavefronts; no barrier below
-    T *acc = (T *)t3_smem + (size_t)w * (R + 1);
+    const uint32_t lane = threadIdx.x;
+    uint32_t rb = blockIdx.x;  // neighbouring row blocks' tiles share cache lines: neighbours on one XCD (one L2)
+    if (xcd_map) rb = (blockIdx.x & 7u) * ((gridDim.x + 7u) / 8u) + (blockIdx.x >> 3);
+    if (rb >= n_rb) return;
+    T *acc = (T *)t3_smem;  // [0]: dump; [1 + i]: row r0 + i
     const uint32_t r0 = rb_start[rb], rows = rb_start[rb + 1] - r0;
-    for (uint32_t i = lane; i < rows; i += 64) acc[i] = T(0);
-    if (lane == 0) acc[R] = T(0);
+    for (uint32_t i = lane; i <= rows; i += 64) acc[i] = T(0);
     const uint32_t *ts0 = tstart + (size_t)rb * n_cb, *ts1 = ts0 + n_cb;
     auto table = [&](uint32_t t, uint32_t &base, uint32_t &len) {  // lane l: tile t + l
         const uint32_t cbl = t + lane;
@@ -281,7 +324,7 @@ __global__ __launch_bounds__(kT3Waves * 64) void k_t3_reduce(const T *__restrict
     table(0, cur_base, cur_len);
     table(64, nxt_base, nxt_len);
     const uint32_t pos = E * lane;
-    auto issue = [&](T3Tiles<T> &B, uint32_t j0) {
+    auto issue = [&](T3Tiles<T, NB> &B, uint32_t j0) {
         if (j0 >= win + 64) {
             cur_base = nxt_base;
             cur_len = nxt_len;
@@ -289,20 +332,28 @@ __global__ __launch_bounds__(kT3Waves * 64) void k_t3_reduce(const T *__restrict
             table(win + 64, nxt_base, nxt_len);
         }
 #pragma unroll
-        for (int d = 0; d < kT3Batch; ++d) {
+        for (int d = 0; d < NB; ++d) {
             const int j = (int)((j0 + d) & 63);
             B.bs[d] = (uint32_t)__builtin_amdgcn_readlane((int)cur_base, j);
             B.ln[d] = (uint32_t)__builtin_amdgcn_readlane((int)cur_len, j);  // 0 past the last slice
         }
 #pragma unroll
-        for (int d = 0; d < kT3Batch; ++d) {  // unconditional, aligned 16-byte loads (the buffers end in a round of slack); masked when folded
-            const uint64_t a = (uint64_t)(B.bs[d] & ~(uint32_t)(E - 1)) + pos;
-            B.pv[d] = *(const V *)(prod + a);
-            B.rv[d] = *(const C *)(rowc + a);
+        for (int d = 0; d < NB; ++d) {
+            // aligned 16-byte BUFFER loads whose descriptor ends with the tile: the lanes past it fetch nothing and read zeros -- the
+            // dump row -- (a tile of 174 products fills 44 lanes; plain loads had the other 20 fetch the neighbours' products), and no
+            // branch surrounds the loads
+            const uint32_t a0 = B.bs[d] & ~(uint32_t)(E - 1);
+            const uint32_t n = (B.bs[d] + B.ln[d] - a0 + E - 1) & ~(uint32_t)(E - 1);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(prod + a0), 0, (int)(n * sizeof(T)), kT3Rsrc);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(rowc + a0), 0, (int)(n * 2u), kT3Rsrc);
+            B.pv[d] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)(pos * sizeof(T)), 0, 0));
+            if constexpr (E == 4) B.rv[d] = __builtin_bit_cast(C, __builtin_amdgcn_raw_buffer_load_b64(rr, (int)(pos * 2u), 0, 0));
+            else B.rv[d] = __builtin_amdgcn_raw_buffer_load_b32(rr, (int)(pos * 2u), 0, 0);
         }
     };
-    // one round: up to 64 E consecutive products, E per lane: p[k] at index a + k of prod, valid for lo <= a + k < hi
-    auto round = [&](const V &pv, const C &rv, uint32_t a, uint32_t lo, uint32_t hi) {
+    // one round: up to 64 E consecutive products, E per lane, the first `skip` of the round (lane 0's) and those from `stop` on (the
+    // last piece's, when the tile ends inside it and its neighbour's products follow) belonging to other tiles
+    auto round = [&](const V &pv, const C &rv, uint32_t skip, uint32_t stop) {
         T p[E];
         uint32_t r[E];
         if constexpr (E == 4) {
@@ -313,51 +364,59 @@ __global__ __launch_bounds__(kT3Waves * 64) void k_t3_reduce(const T *__restrict
             r[0] = rv & 0xFFFFu; r[1] = rv >> 16;
         }
 #pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const bool ok = a + k >= lo && a + k < hi;
-            if (!ok) { r[k] = R; p[k] = T(0); }  // (the dump slot; its value is never read)
-        }
-        // equal neighbours (a (row, slice) pair cut by a chunk boundary; the dump row never counts)
-        const uint32_t prev_r = t3_dpp<0x138, 0xF>(0xFFFFFFFFu, r[E - 1]);  // wave_shr:1
-        uint32_t cont = (uint32_t)(r[0] == prev_r && r[0] != R);
+        for (int k = 0; k < E; ++k)
+            if (pos + k < skip || pos + k >= stop) r[k] = 0;  // (the dump slot: what is added there is never read)
+        if constexpr (DUPS) {
+            // equal neighbours (a (row, slice) pair cut by a chunk boundary; the dump row never counts)
+            const uint32_t prev_r = t3_dpp<0x138, 0xF>(0u, r[E - 1]);  // wave_shr:1
+            uint32_t cont = (uint32_t)(r[0] == prev_r && r[0] != 0u);
 #pragma unroll
-        for (int k = 1; k < E; ++k) cont |= (uint32_t)(r[k] == r[k - 1] && r[k] != R) << k;
-        if (__ballot(cont != 0)) {
-            // rare: merge them first (same fold as pass 1), then only the last entry of each run adds
-            const uint32_t tail = t3_fold_runs<T, E>(p, cont);
+            for (int k = 1; k < E; ++k) cont |= (uint32_t)(r[k] == r[k - 1] && r[k] != 0u) << k;
+            if (__ballot(cont != 0)) {
+                // merge them first (same fold as pass 1), then only the last entry of each run adds
+                const uint32_t tail = t3_fold_runs<T, E>(p, cont);
 #pragma unroll
-            for (int k = 0; k < E; ++k)
-                if (!(tail >> k & 1u)) r[k] = R;
+                for (int k = 0; k < E; ++k)
+                    if (!(tail >> k & 1u)) r[k] = 0;
+            }
         }
-        // the rows of the round are distinct now (sorted, no equal neighbours), the dump slot aside: independent adds
+        // the rows of the round are distinct (sorted, no equal neighbours): independent read-add-write sequences, all reads first.
+        // Code 0 (padding, other tiles' products, lanes past the tile) is the dump slot, whose value is never read.  (LDS float atomics
+        // -- one ds_add_f32 instead of read, add, write -- measured 4x SLOWER here: 1.77 ms against 0.42 for C2-uniform's pass 2,
+        // ~150 cycles per wavefront instruction; ds_add_f64 no faster than the three instructions it replaces.)
         T s[E];
 #pragma unroll
-        for (int k = 0; k < E; ++k) s[k] = acc[r[k]];
+        for (int k = 0; k < E; ++k) s[k] = *(const T *)(t3_smem + r[k]);
 #pragma unroll
-        for (int k = 0; k < E; ++k) acc[r[k]] = s[k] + p[k];
+        for (int k = 0; k < E; ++k) *(T *)(t3_smem + r[k]) = s[k] + p[k];  // (unconditional: a branch per write cost 20 %)
     };
-    auto fold = [&](T3Tiles<T> &B) {
+    auto fold = [&](T3Tiles<T, NB> &B) {
 #pragma unroll
-        for (int d = 0; d < kT3Batch; ++d) {
+        for (int d = 0; d < NB; ++d) {
             const uint32_t bs = B.bs[d], end = bs + B.ln[d];
             const uint32_t a0 = bs & ~(uint32_t)(E - 1);
-            round(B.pv[d], B.rv[d], a0 + pos, bs, end);
+            round(B.pv[d], B.rv[d], bs - a0, end - a0);
             for (uint32_t a = a0 + RND; a < end; a += RND) {  // rare: a tile of more than one round
-                const V pv = *(const V *)(prod + (uint64_t)a + pos);
-                const C rv = *(const C *)(rowc + (uint64_t)a + pos);
-                round(pv, rv, a + pos, bs, end);
+                V pv = V(0);
+                C rv = C(0);
+                if (a + pos < end) {
+                    pv = *(const V *)(prod + (uint64_t)a + pos);
+                    rv = *(const C *)(rowc + (uint64_t)a + pos);
+                }
+                round(pv, rv, 0u, end - a);
             }
         }
     };
-    T3Tiles<T> A, B;
+    T3Tiles<T, NB> A, B;
     issue(A, 0);
-    for (uint32_t j0 = 0; j0 < n_cb; j0 += 2 * kT3Batch) {
-        issue(B, j0 + kT3Batch);
+    __builtin_amdgcn_sched_barrier(0);
+    for (uint32_t j0 = 0; j0 < n_cb; j0 += 2 * NB) {
+        issue(B, j0 + NB);
         fold(A);
-        issue(A, j0 + 2 * kT3Batch);
+        issue(A, j0 + 2 * NB);
         fold(B);
     }
-    for (uint32_t i = lane; i < rows; i += 64) y[(uint64_t)r0 + i] = acc[i];
+    for (uint32_t i = lane; i < rows; i += 64) y[(uint64_t)r0 + i] = acc[i + 1];
 }
 
 // ---- plan -------------------------------------------------------------------------------------------------------------
@@ -456,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_fill(const uint32_t *__restrict__
     for (int o = 32; o; o >>= 1) runs += (uint32_t)__shfl_down((int)runs, o, 64);
     if (lane == 0) {
         clen[c] = len;
-        ntails[c] = (runs + (uint32_t)T3<T>::E - 1u) & ~((uint32_t)T3<T>::E - 1u);  // the chunk's share of prod: whole 16-byte pieces
+        ntails[c] = (runs + (uint32_t)T3<T>::E2 - 1u) & ~((uint32_t)T3<T>::E2 - 1u);  // the chunk's share of prod: whole 16-byte pieces
     }
 }
 
@@ -467,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__
                                                      const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ clen,
                                                      const uint32_t *__restrict__ obase, const uint32_t *__restrict__ rowq,
                                                      const uint16_t *__restrict__ code_a, uint32_t *__restrict__ prow, uint32_t *__restrict__ preal,
-                                                     uint32_t *__restrict__ rcount, T3Chunk *__restrict__ desc) {
+                                                     uint32_t *__restrict__ rcount, T3Chunk *__restrict__ desc, uint32_t *__restrict__ any_cut) {
     constexpr uint32_t CH = t3_chunk<T>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -494,21 +553,25 @@ __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__
     // does the chunk's last run go on in the next chunk (a (row, slice) pair longer than the snap distance, cut here)?
     bool cut = false;
     if (len && c + 1 < cptr[s + 1] && clen[c + 1]) cut = rowq[start[s] + cstart[c + 1]] == last_row;
-    if (lane == 0) preal[c] = done | (cut ? 0x80000000u : 0u);
+    if (lane == 0) {
+        preal[c] = done | (cut ? 0x80000000u : 0u);
+        if (cut) atomicOr(any_cut, 1u);
+    }
 }
 
-// rowc[i]: the row of product slot i relative to its row block; the padding slots of a chunk's last piece: `dump`, or the row of
-// the chunk's last run when that run goes on in the next chunk
+// rowc[i] = (the row of product slot i relative to its row block + 1) * value_bytes: where the row's sum lives in pass 2's LDS;
+// the padding slots of a chunk's last piece: 0 (the dump slot), or the row of the chunk's last run when that run goes on in the
+// next chunk
 __global__ __launch_bounds__(kBlock) void k_t3_rowcode(uint32_t n_chunks, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ preal,
                                                         const uint32_t *__restrict__ prow, const uint32_t *__restrict__ rb_start, uint32_t n_rb,
-                                                        uint32_t dump, uint16_t *__restrict__ rowc) {
+                                                        uint32_t value_bytes, uint16_t *__restrict__ rowc) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const uint32_t ob = obase[c], slots = obase[c + 1] - ob, real = preal[c] & 0x7FFFFFFFu;
     const bool cut = preal[c] >> 31;  // the padding then belongs to the cut pair's row (its value is zero): see k_t3_expand
     for (uint32_t k = lane; k < slots; k += 64) {
-        uint32_t code = dump;
+        uint32_t code = 0;
         if (k < real || cut) {
             const uint32_t row = prow[ob + k];
             uint32_t bl = 0, bh = n_rb;  // the row block: the last one with rb_start[b] <= row
@@ -516,7 +579,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_rowcode(uint32_t n_chunks, const 
                 const uint32_t mid = (bl + bh) / 2;
                 if (rb_start[mid] <= row) bl = mid; else bh = mid;
             }
-            code = row - rb_start[bl];
+            code = (row - rb_start[bl] + 1u) * value_bytes;
         }
         rowc[ob + k] = (uint16_t)code;
     }
@@ -575,7 +638,7 @@ template <typename T>
 static int build_t(::smh_crs *m) {
     hipStream_t s = m->stream;
     const uint64_t nnz = m->nnz;
-    constexpr uint32_t CH = t3_chunk<T>(), STRIDE = t3_stride<T>(), E = (uint32_t)T3<T>::E;
+    constexpr uint32_t CH = t3_chunk<T>(), STRIDE = t3_stride<T>();
     const uint64_t n_cb64 = ((uint64_t)m->n_cols + kT3Slice - 1) / kT3Slice;
     const uint32_t n_cb = (uint32_t)(n_cb64 ? n_cb64 : 1);
     if (nnz + nnz / 64 + 1024 >= (1ull << 32)) return fail(SMH_ERR_INVALID, "tiled variant: %llu entries are too many for its 32-bit product index", (unsigned long long)nnz);
@@ -618,6 +681,8 @@ static int build_t(::smh_crs *m) {
         cptr[b + 1] = cptr[b] + (uint32_t)((cnt + STRIDE - 1) / STRIDE);
     }
     const uint32_t n_chunks = cptr[n_cb];
+    uint32_t max_slice_chunks = 0;
+    for (uint32_t b = 0; b < n_cb; ++b) max_slice_chunks = std::max(max_slice_chunks, cptr[b + 1] - cptr[b]);
     const uint64_t slots = (uint64_t)n_chunks * CH;
     uint32_t *cstart = nullptr, *clen = nullptr, *obase = nullptr, *preal = nullptr, *rcount = nullptr, *prow = nullptr;
     SMH_TRY(tmp.alloc(&cstart, (size_t)n_chunks));
@@ -625,6 +690,9 @@ static int build_t(::smh_crs *m) {
     SMH_TRY(tmp.alloc(&obase, (size_t)n_chunks + 1));
     SMH_TRY(tmp.alloc(&preal, (size_t)n_chunks));
     SMH_TRY(tmp.alloc(&rcount, m->n_rows));
+    uint32_t *any_cut = nullptr;  // does any chunk boundary cut a (row, slice) pair?
+    SMH_TRY(tmp.alloc(&any_cut, 1));
+    SMH_HIP(hipMemsetAsync(any_cut, 0, sizeof(uint32_t), s));
     SMH_HIP(hipMalloc(&m->d_t2_val, (slots + CH) * sizeof(T)));
     SMH_HIP(hipMalloc((void **)&m->d_t2_code, (slots + CH) * sizeof(uint16_t)));
     SMH_HIP(hipMalloc((void **)&m->d_t3_cptr, ((size_t)n_cb + 1) * sizeof(uint32_t)));
@@ -646,9 +714,11 @@ static int build_t(::smh_crs *m) {
     SMH_TRY(tmp.alloc(&prow, (size_t)n_prod));
     if (n_chunks) {
         hipLaunchKernelGGL(k_t3_prow<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, clen, obase, rowq, m->d_t2_code, prow, preal,
-                           rcount, (T3Chunk *)m->d_t3_chunk);
+                           rcount, (T3Chunk *)m->d_t3_chunk, any_cut);
         SMH_HIP(hipGetLastError());
     }
+    uint32_t h_cut = 0;
+    SMH_HIP(hipMemcpyAsync(&h_cut, any_cut, sizeof h_cut, hipMemcpyDeviceToHost, s));  // (synchronised with the row counts below)
     // row blocks of equal PRODUCT counts (a tile = one slice of a block: ~target products whatever the row lengths), at most `cap`
     // rows each (their sums share the LDS); greedy over the rows' product counts, on the host
     std::vector<uint32_t> rb_start;
@@ -682,9 +752,9 @@ static int build_t(::smh_crs *m) {
     SMH_HIP(hipMalloc((void **)&m->d_t2_rbstart, rb_start.size() * sizeof(uint32_t)));
     SMH_HIP(hipMemcpyAsync(m->d_t2_rbstart, rb_start.data(), rb_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     SMH_HIP(hipMemsetAsync(m->d_t2_prod, 0, (n_prod + 2 * CH) * sizeof(T), s));
-    SMH_HIP(hipMemsetAsync(m->d_t2_row, 0xFF, (n_prod + 2 * CH) * sizeof(uint16_t), s));  // (slack: rows no block has -- masked anyway)
+    SMH_HIP(hipMemsetAsync(m->d_t2_row, 0, (n_prod + 2 * CH) * sizeof(uint16_t), s));  // (slack: the dump slot)
     if (n_chunks) {
-        hipLaunchKernelGGL(k_t3_rowcode, dim3(wgrid), dim3(kBlock), 0, s, n_chunks, obase, preal, prow, m->d_t2_rbstart, n_rb, R, m->d_t2_row);
+        hipLaunchKernelGGL(k_t3_rowcode, dim3(wgrid), dim3(kBlock), 0, s, n_chunks, obase, preal, prow, m->d_t2_rbstart, n_rb, (uint32_t)sizeof(T), m->d_t2_row);
         SMH_HIP(hipGetLastError());
     }
     // (obase of a slice's first chunk = where its products begin; empty slices have none)
@@ -692,17 +762,18 @@ static int build_t(::smh_crs *m) {
     SMH_HIP(hipGetLastError());
     SMH_HIP(hipStreamSynchronize(s));
     // 128 KiB and more of dynamic LDS need the attribute on every device the kernel runs on: set with each build, on the matrix's device
-    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t3_expand<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T))));
-    SMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_t3_reduce<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(kT3Waves * ((size_t)R + 1) * sizeof(T))));
+    for (const void *f : {reinterpret_cast<const void *>(k_t3_expand<T, 2>), reinterpret_cast<const void *>(k_t3_expand<T, 3>), reinterpret_cast<const void *>(k_t3_expand<T, 4>)})
+        SMH_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T))));
+    // (the row codes are byte offsets into a wavefront's sums and must fit 16 bits)
+    if (((uint64_t)R + 1) * sizeof(T) > 0xFFFFu) return fail(SMH_ERR_INVALID, "tiled variant: row blocks of %u rows do not fit the 16-bit row codes", R);
     m->t2_n_cb = n_cb;
     m->t2_n_rb = n_rb;
     m->t2_R = R;
     m->t2_tot = slots;
     m->t3_n_chunks = n_chunks;
+    m->t3_max_slice_chunks = max_slice_chunks;
     m->t3_n_prod = n_prod;
-    (void)E;
+    m->t3_dups = h_cut != 0;
     return SMH_OK;
 }
 
@@ -764,7 +835,7 @@ int tiled_array(::smh_crs *m, int which, void *out, size_t capacity_bytes, size_
 template <typename T>
 static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
     constexpr uint32_t CH = t3_chunk<T>();
-    const size_t lds1 = ((size_t)kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T), lds2 = (size_t)kT3Waves * ((size_t)m->t2_R + 1) * sizeof(T);
+    const size_t lds1 = ((size_t)kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T), lds2 = ((size_t)m->t2_R + 1) * sizeof(T);
     static const uint32_t xcd_map = getenv("SMH_TILED_XCD") ? (uint32_t)atoi(getenv("SMH_TILED_XCD")) : 3u;  // tuning knob: bit 0 pass 1, bit 1 pass 2
     if (m->t3_n_chunks) {
         // a workgroup pays for staging its slice of x (16384 entries), so it should fold several times as many entries: ~65 000
@@ -773,15 +844,25 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
         uint32_t parts = (uint32_t)((per_slice + 32768) / 65536);
         if (const char *e = getenv("SMH_TILED_PARTS")) { const int v = atoi(e); if (v >= 1) parts = (uint32_t)v; }  // tuning knob
         parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
+        // (a wavefront keeps the descriptors of its chunks in one register: at most 64 chunks each, 1024 per workgroup)
+        const uint32_t need = (m->t3_max_slice_chunks + 1023u) / 1024u;
+        if (parts < need) parts = need;
         // (the remapped grid is rounded up to a multiple of 8 so that every XCD's run has the same length)
         const uint32_t g1 = m->t2_n_cb * parts, g1r = (xcd_map & 1u) ? (g1 + 7u) & ~7u : g1;
-        hipLaunchKernelGGL(k_t3_expand<T>, dim3(g1r), dim3(kT3ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val, m->d_t2_code,
+        static const int ahead = getenv("SMH_TILED_AHEAD") ? atoi(getenv("SMH_TILED_AHEAD")) : kT3Ahead;  // tuning knob: chunks in flight per wavefront
+        auto *exp = ahead == 2 ? k_t3_expand<T, 2> : ahead == 4 ? k_t3_expand<T, 4> : k_t3_expand<T, 3>;
+        hipLaunchKernelGGL(exp, dim3(g1r), dim3(kT3ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val, m->d_t2_code,
                            m->d_t3_cptr, (const T3Chunk *)m->d_t3_chunk, (T *)m->d_t2_prod, parts, g1, xcd_map & 1u);
         SMH_HIP(hipGetLastError());
     }
-    const uint32_t g2 = (m->t2_n_rb + kT3Waves - 1) / kT3Waves, g2r = (xcd_map & 2u) ? (g2 + 7u) & ~7u : g2;
-    hipLaunchKernelGGL(k_t3_reduce<T>, dim3(g2r), dim3(kT3Waves * 64), lds2, s, (const T *)m->d_t2_prod, m->d_t2_row, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb,
-                       m->d_t2_rbstart, m->t2_R, (T *)y, xcd_map >> 1 & 1u);
+    // pass 2: one wavefront = one workgroup per row block
+    const uint32_t g2 = m->t2_n_rb, g2r = (xcd_map & 2u) ? (g2 + 7u) & ~7u : g2;
+    static const int batch = getenv("SMH_TILED_BATCH") ? atoi(getenv("SMH_TILED_BATCH")) : kT3Batch;  // tuning knob: 2, 4 or 8 tiles per batch
+    auto *red = batch == 8 ? (m->t3_dups ? k_t3_reduce<T, true, 8> : k_t3_reduce<T, false, 8>)
+                : batch == 2 ? (m->t3_dups ? k_t3_reduce<T, true, 2> : k_t3_reduce<T, false, 2>)
+                             : (m->t3_dups ? k_t3_reduce<T, true, 4> : k_t3_reduce<T, false, 4>);
+    hipLaunchKernelGGL(red, dim3(g2r), dim3(64), lds2, s, (const T *)m->d_t2_prod, m->d_t2_row, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb, m->d_t2_rbstart,
+                       (T *)y, xcd_map >> 1 & 1u);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }

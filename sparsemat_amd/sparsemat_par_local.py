@@ -5,8 +5,8 @@ window send-receive, or direct peer reads) and the device-resident CG all live i
 * one process, all blocks: ``with_sub_matrices`` (split host arrays) or ``adopt`` (blocks already on their devices);
 * one process per GPU: ``Comm`` (``ncclCommInitRank``) + ``for_rank`` around the rank's own block.
 
-The older one-process-per-GPU form over ``torch.distributed`` is ``sparsemat_par.SparseMatPar`` (kept for its gloo tests
-of the plan arithmetic on CPU).
+(Round 1's form over ``torch.distributed`` is test infrastructure now: ``tests/par_reference.py``, the restatement the plan
+arithmetic of ``smh_par_plan`` is checked against in the CPU / gloo tests.)
 """
 import ctypes as C
 

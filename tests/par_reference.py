@@ -1,4 +1,9 @@
-"""SparseMatPar: row-block partitioned SpMV across the GPUs of one node.
+"""TEST INFRASTRUCTURE (moved out of the product package in round 3): a Python / torch.distributed form of the row-block
+partition, kept for the CPU (gloo, world size 2-3) tests of the plan arithmetic and of the exchange layout, and as the
+independent restatement `smh_par_plan` (csrc/par.hip) is compared with.  The PRODUCT's partition is csrc/par.hip behind
+`smh_par_*` (sparsemat_amd.SparseMatParLocal); nothing under sparsemat_amd/ imports this file.
+
+SparseMatPar: row-block partitioned SpMV across the GPUs of one node.
 
 Mirrors the reference's ``SparseMatPar<M>`` (sparsemat_par.rs:12-35, 71-140): ``n_blocks``
 sub-matrices of ``R = max_n_rows / n_blocks`` local rows each (:21), LOCAL row ids and GLOBAL
@@ -246,3 +251,99 @@ class SparseMatPar:
             out = torch.zeros(self._n_rows, dtype=x.dtype, device=x.device)
         self.local.mvp_into(x, out[self.begin:self.end])
         return self.exchange_window(out)
+
+
+# ---- the row-partitioned CG recurrence on torch tensors (round 1's solver; the product's is smh_par_cg_solve) ----------------
+import ctypes as C  # noqa: E402
+
+from sparsemat_amd import _lib  # noqa: E402
+from sparsemat_amd._lib import check, lib  # noqa: E402
+
+
+class HipVectorOps:
+    """DenseVec kernels of the library on torch CUDA tensors, scalars read from device memory."""
+
+    def __init__(self, like):
+        import torch
+        self._torch = torch
+        self.dtype_code = _lib.SMH_F64 if like.dtype == torch.float64 else _lib.SMH_F32
+        self.scratch = torch.empty(lib().smh_blas_dot_scratch_bytes(), dtype=torch.uint8, device=like.device)
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream().cuda_stream)
+
+    def dot(self, x, y, out):
+        check(lib().smh_blas_dot_dev(self.dtype_code, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), x.numel(),
+                                     C.c_void_p(out.data_ptr()), C.c_void_p(self.scratch.data_ptr()), self._stream()))
+
+    def axpy(self, y, a, x):  # y += round(a*x)
+        check(lib().smh_blas_axpy_dev(self.dtype_code, C.c_void_p(y.data_ptr()), C.c_void_p(a.data_ptr()),
+                                      C.c_void_p(x.data_ptr()), y.numel(), self._stream()))
+
+    def xpby(self, p, b, r):  # p = round(b*p) + r
+        check(lib().smh_blas_xpby_dev(self.dtype_code, C.c_void_p(p.data_ptr()), C.c_void_p(b.data_ptr()),
+                                      C.c_void_p(r.data_ptr()), p.numel(), self._stream()))
+
+
+class ParConjugateGradient:
+    """ConjugateGradient::solve (linearsolver.rs:27-61) over a SparseMatPar: rank b holds rows
+    [b*R, (b+1)*R) of A and the matching slices of b and x.  Same update order and roundings as the
+    reference; the two reductions are local deterministic trees + an all-reduce (sum) over the ranks."""
+
+    def __init__(self, tol=1e-12, iter_max=10_000, ops=None):
+        self.tol, self.iter_max, self.ops = float(tol), int(iter_max), ops
+        self.iterations = None
+        self.r_norm_squared = None
+
+    def solve(self, par, b_local, x_local):
+        import torch
+        import torch.distributed as dist
+        if par.n_rows() != par.n_cols():
+            raise _lib.SparseMatPanic(_lib.SMH_ERR_NOT_SQUARE, "Matrix is not symmetric")            # :30-32
+        rows = par.end - par.begin
+        if b_local.numel() != rows or x_local.numel() != rows:
+            raise _lib.SparseMatPanic(_lib.SMH_ERR_DIM_MISMATCH, "Matrix and vector size mismatch")  # :33-36
+        ops = self.ops or HipVectorOps(x_local)
+        multi = par.n_blocks > 1
+        if par._plan is None:
+            par.setup_window_exchange(x_local)
+
+        def allreduce(t):
+            if multi:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=par.group)
+
+        n = par.n_rows()
+        dev, dt = x_local.device, x_local.dtype
+        full = torch.zeros(n, dtype=dt, device=dev)        # holds x, then p: own slice + exchanged window
+        mine = full[par.begin:par.end]
+        ap = torch.empty(rows, dtype=dt, device=dev)
+        rr, rr_prev, pap, alpha, neg_alpha, beta = (torch.zeros(1, dtype=dt, device=dev) for _ in range(6))
+        # r = b - A x (:38); p = r (:39); rr = r.r (:40)
+        mine.copy_(x_local)
+        par.exchange_window(full)
+        par.mvp_local(full, ap)
+        r = b_local - ap
+        mine.copy_(r)                                      # p lives in `full`
+        ops.dot(r, r, rr)
+        allreduce(rr)
+        iters = 0
+        for _k in range(self.iter_max):
+            iters += 1
+            par.exchange_window(full)                      # the entries of p this block references
+            par.mvp_local(full, ap)                        # :43
+            ops.dot(mine, ap, pap)
+            allreduce(pap)
+            torch.div(rr, pap, out=alpha)                  # :45
+            ops.axpy(x_local, alpha, mine)                 # *x += p * alpha          :47
+            torch.neg(alpha, out=neg_alpha)
+            ops.axpy(r, neg_alpha, ap)                     # r -= mat_p * alpha       :49  (r + round(-alpha*Ap))
+            rr_prev.copy_(rr)
+            ops.dot(r, r, rr)                              # :51
+            allreduce(rr)
+            if float(rr.item()) ** 0.5 < self.tol:         # :52-54, before the beta update
+                break
+            torch.div(rr, rr_prev, out=beta)               # :56
+            ops.xpby(mine, beta, r)                        # p = beta*p + r           :58-59
+        self.iterations = iters
+        self.r_norm_squared = float(rr.item())
+        return x_local

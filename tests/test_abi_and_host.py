@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 import sparsemat_amd as sm
-from sparsemat_amd import _lib, sparsemat_par
+from sparsemat_amd import _lib
+import par_reference as sparsemat_par
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "sparsemat_hip.h")
@@ -83,6 +84,17 @@ def test_product_never_uses_the_oracle():
                     assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", text), fn
 
 
+def test_product_package_has_one_partition_and_no_torch():
+    """a8 / a9 exist once in the product: csrc/par.hip behind smh_par_* (sparsemat_amd.SparseMatPar = SparseMatParLocal).  Round 1's
+    torch.distributed form lives under tests/ (par_reference.py: plan restatement + gloo harness); the package imports no torch."""
+    assert sm.SparseMatPar is sm.SparseMatParLocal and not hasattr(sm, "sparsemat_par")
+    for fn in os.listdir(os.path.join(ROOT, "sparsemat_amd")):
+        if fn.endswith(".py"):
+            text = open(os.path.join(ROOT, "sparsemat_amd", fn)).read()
+            assert not re.search(r"^(import|from)\s+torch\b", text, flags=re.M), fn  # (DenseVec.from_torch borrows a tensor's memory, lazily)
+    assert not os.path.exists(os.path.join(ROOT, "sparsemat_amd", "sparsemat_par.py"))
+
+
 def test_laplace3d_closed_form_offsets_match_the_oracle():
     """Host part of the device generator (size query needs no GPU): prefix counts are bit-exact."""
     import oracle
@@ -145,10 +157,11 @@ def test_split_crs_rebases_offsets_and_keeps_global_columns():
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + '/tests')
 import numpy as np, torch, torch.distributed as dist
 import oracle
-from sparsemat_amd import sparsemat_par
-from sparsemat_amd.sparsemat_par import SparseMatPar
+import par_reference as sparsemat_par
+from par_reference import SparseMatPar
 
 class CheckerBlock:  # test-only local product (the CPU oracle); the product's block is HipBlock
     def __init__(self, off, col, val):
@@ -270,11 +283,11 @@ def test_exchange_plan_arithmetic():
 WORKER_CG = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + '/tests')
 import numpy as np, torch, torch.distributed as dist
 import oracle
-from sparsemat_amd import sparsemat_par
-from sparsemat_amd.sparsemat_par import SparseMatPar
-from sparsemat_amd.linearsolver import ParConjugateGradient
+import par_reference as sparsemat_par
+from par_reference import SparseMatPar, ParConjugateGradient
 
 class CheckerBlock:
     def __init__(self, off, col, val):

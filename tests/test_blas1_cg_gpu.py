@@ -177,8 +177,7 @@ def test_par_cg_single_rank_matches_oracle(gpu, dtype, tol):
     """ParConjugateGradient (the row-partitioned recurrence, device scalars, smh_blas_*_dev kernels) with one
     block: same iterates as the oracle up to the reduction order."""
     import torch
-    from sparsemat_amd.linearsolver import ParConjugateGradient
-    from sparsemat_amd.sparsemat_par import HipBlock, SparseMatPar
+    from par_reference import HipBlock, ParConjugateGradient, SparseMatPar
     nx = ny = nz = 12
     n = nx * ny * nz
     off, col, val = oracle.laplace3d(nx, ny, nz, dtype)

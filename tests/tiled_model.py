@@ -16,7 +16,11 @@ TARGET = {np.dtype(np.float32): 174.0, np.dtype(np.float64): 60.0}
 CAP = {np.dtype(np.float32): 3328, np.dtype(np.float64): 1664}
 
 
+E1 = 4  # entries per lane in pass 1 (a chunk = 64 E1 slots)
+
+
 def lanes_per(dtype):
+    """Products per lane in pass 2 (16 bytes): a round = 64 of these; a chunk's share of the product stream is padded to it."""
     return 4 if np.dtype(dtype) == np.dtype(np.float32) else 2
 
 
@@ -70,7 +74,7 @@ class TiledModel:
         dt = np.dtype(val.dtype)
         self.dt, self.E = dt, lanes_per(dt)
         E = self.E
-        self.CH, self.STRIDE = 64 * E, 64 * E - SNAP
+        self.CH, self.STRIDE = 64 * E1, 64 * E1 - SNAP
         CH, STRIDE = self.CH, self.STRIDE
         off = np.asarray(off, dtype=np.int64)
         col = np.asarray(col, dtype=np.int64)
@@ -172,7 +176,8 @@ class TiledModel:
         self.R = int(max(1, np.diff(self.rb_start.astype(np.int64)).max()))
         blk = np.searchsorted(self.rb_start[1:].astype(np.int64), prow, side="right")
         blk = np.minimum(blk, self.n_rb - 1)
-        self.product_rows = np.where(counts, prow - self.rb_start[blk].astype(np.int64), self.R).astype(np.uint16)
+        # (the byte offset of the row's sum in pass 2's LDS: slot 0 is the dump slot)
+        self.product_rows = np.where(counts, (prow - self.rb_start[blk].astype(np.int64) + 1) * dt.itemsize, 0).astype(np.uint16)
         # tile table
         pb = obase[self.slice_chunks.astype(np.int64)]
         ts = np.zeros((self.n_rb + 1, self.n_cb), dtype=np.uint32)
@@ -194,7 +199,7 @@ class TiledModel:
         xi = np.minimum(base + colv, len(x) - 1)
         p = (v * np.asarray(x, dtype=dt)[xi]).astype(dt)
         p = np.where(self.have, p, 0).astype(dt)  # (what the empty slots multiply is never part of a run's sum)
-        ps, tail = fold_runs(p.reshape(nC, 64, E), self.cont.reshape(nC, 64, E))
+        ps, tail = fold_runs(p.reshape(nC, 64, E1), self.cont.reshape(nC, 64, E1))
         tail = tail.reshape(nC, CH) & self.have
         ps = ps.reshape(nC, CH)
         for c in range(nC):
@@ -208,27 +213,27 @@ class TiledModel:
         RND = 64 * E
         y = np.zeros(self.n_rows, dtype=dt)
         pad = np.concatenate([prod, np.zeros(2 * RND, dtype=dt)])
-        rc = np.concatenate([self.product_rows, np.full(2 * RND, 0xFFFF, dtype=np.uint16)]).astype(np.int64)
+        rc = np.concatenate([self.product_rows, np.zeros(2 * RND, dtype=np.uint16)]).astype(np.int64) // dt.itemsize
         for rb in range(self.n_rb):
             r0 = int(self.rb_start[rb])
-            acc = np.zeros(R + 1, dtype=dt)
+            acc = np.zeros(R + 1, dtype=dt)  # [0]: the dump slot
             for s in range(self.n_cb):
                 lo, hi = int(self.tile_start[rb, s]), int(self.tile_start[rb + 1, s])
                 a = lo & ~(E - 1)
                 while a < hi:  # (an empty tile's single round adds nothing)
                     idx = np.arange(a, a + RND)
                     ok = (idx >= lo) & (idx < hi)
-                    r = np.where(ok, rc[idx], R)
+                    r = np.where(ok, rc[idx], 0)
                     p = np.where(ok, pad[idx], 0).astype(dt)
-                    prev = np.concatenate([[-1], r[:-1]])
-                    cont = (r == prev) & (r != R)
+                    prev = np.concatenate([[0], r[:-1]])
+                    cont = (r == prev) & (r != 0)
                     if cont.any():
                         ps, tail = fold_runs(p.reshape(1, 64, E), cont.reshape(1, 64, E))
                         p = ps.reshape(-1)
-                        r = np.where(tail.reshape(-1), r, R)
-                    sel = r != R
+                        r = np.where(tail.reshape(-1), r, 0)
+                    sel = r != 0
                     acc[r[sel]] = acc[r[sel]] + p[sel]
                     a += RND
             n = int(self.rb_start[rb + 1]) - r0
-            y[r0:r0 + n] = acc[:n]
+            y[r0:r0 + n] = acc[1:n + 1]
         return y
