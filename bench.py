@@ -11,8 +11,10 @@ A "step" is one pass of the hot path over the resident matrix: y = A.x with A, x
          lanes 8).  `other_pattern` carries the kernel time of the stratified subset (one column per 256-wide
          stratum: what rounds 1-2 put the headline on) measured in the same process.
   N > 1  weak scaling, BASELINE configs[4] shape: block b owns rows [b*10M, (b+1)*10M) of an (N*10M)-row
-         matrix with global columns (SparseMatPar), step = local SpMV into the block's slice of y + ONE
-         exchange INSIDE libsparsemat_hip.so (csrc/par.hip) that makes y usable as the next x on every GPU:
+         matrix with global columns (SparseMatPar), step = ONE library call (smh_par_spmv_dev): the local SpMV into the block's
+         slice of y + the exchange INSIDE libsparsemat_hip.so (csrc/par.hip) that makes y usable as the next x on every GPU -- a
+         window exchange runs on a second stream beside the product of the block's interior rows (`exchange_hidden_ms` = the
+         same K steps with that switched off minus the headline's; results are bit-identical):
          --exchange allgather: in-place ncclAllGather of the y slices; window: grouped ncclSend/ncclRecv of
          exactly the entries each block's columns reference (this banded matrix: 4096 entries from each
          neighbour); auto (default): the window when no block receives half of the vector or more.
@@ -411,6 +413,11 @@ def main():
             if not skip_exchange:
                 par.exchange(y, exchange_req)
 
+        def step():
+            # ONE call: the local products and the exchange inside the library -- a window exchange runs on a second stream per
+            # block beside the product of the block's interior rows (csrc/par.hip; bit-identical to product-then-exchange)
+            par.mvp_dev(x, y, args.variant, "none" if skip_exchange else exchange_req)
+
         def sync():
             par.synchronize()
 
@@ -424,22 +431,35 @@ def main():
         if comm is not None:
             comm.barrier()  # device drained, then all ranks meet (an RCCL all-reduce on the communicator)
 
+    if par is None:
+        def step():
+            spmv()
+
     for _ in range(args.warmup):  # exactly the body of a timed step, so lazily created state exists before the clock starts
-        spmv()
-        exchange()
+        step()
     barrier()
     ev = Events(lib, check, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev.start(i, stream)  # HIP events around the SpMV kernel, on the stream it is launched on (block 0 of this process)
-        spmv()
+        ev.start(i, stream)  # HIP events on the launch stream (block 0 of this process): N = 1: around the SpMV kernel
+        step()               # N > 1: y becomes usable as the next x on every GPU inside this call
         ev.stop(i, stream)
-        exchange()           # y becomes usable as the next x on every GPU
     barrier()
     elapsed = time.perf_counter() - t0
     if comm is not None:
         elapsed = comm.max(elapsed)
     kernel = stats(ev.times_ms())
+    step_events = None
+    if par is not None:
+        # N > 1: the events above bracket block 0's whole step; the SpMV kernel alone (the roofline's launch) is timed here
+        step_events = kernel
+        kev = Events(lib, check, args.steps)
+        for i in range(args.steps):
+            kev.start(i, stream)
+            spmv()
+            kev.stop(i, stream)
+        barrier()
+        kernel = stats(kev.times_ms())
 
     if args.child:
         # the calibration kernel of the PMC pass: x += y on CALIB_N f32 (known traffic, 16 B per lane)
@@ -545,6 +565,8 @@ def main():
     }
     if other is not None:
         result["other_pattern"] = other
+    if step_events is not None:
+        result["step_ms_block0_events"] = step_events["mean"]
     # The optional legs of an N > 1 run come AFTER the headline is complete, under a watchdog: should one of them hang (it is
     # the first time this code meets a real multi-GPU node), every rank gives up after 180 s (SMH_BENCH_WATCHDOG_S), rank 0 prints the
     # line without them (naming the leg that hung) and every rank exits with status 3: the measured headline is never lost to an
@@ -575,6 +597,25 @@ def main():
         if os.environ.get("SMH_BENCH_HANG_IN_LEGS") == "1":  # test knob: what the watchdog is for
             time.sleep(10 ** 6)
         xcheck = exchange_check(lib, check, synth, np, par, x, y, n, comm, pattern)  # (collective: every rank calls it)
+        # what running the exchange beside the interior rows' product hides: the same K steps once more with the overlap off
+        # (product, THEN exchange on the same stream) -- bit-identical results, only the schedule differs
+        if exchange_mode == "window" and not skip_exchange:
+            leg["name"] = "no_overlap_leg"
+            par.set_overlap(False)
+            for _ in range(min(args.warmup, 2) + 1):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            el = time.perf_counter() - t0
+            if comm is not None:
+                el = comm.max(el)
+            par.set_overlap(True)
+            result["ms_per_step_no_overlap"] = el / args.steps * 1e3
+            result["exchange_hidden_ms"] = el / args.steps * 1e3 - ms_per_step
+            result["interior_rows_block0"] = list(par.interior(0, args.variant))
         # BASELINE configs[4] names the all-gather of the dense vector: when AUTO chose the cheaper window exchange, the same
         # K steps are timed once more with the in-place all-gather and reported beside the headline (never instead of it)
         if exchange_mode != "allgather" and os.environ.get("SMH_BENCH_NO_ALLGATHER_LEG") != "1":

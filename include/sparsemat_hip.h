@@ -450,6 +450,17 @@ int smh_par_scale(smh_par *p, double a);          /* :135-139 */
  * device is SMH_ERR_INVALID; a per-rank handle is always RCCL. */
 int smh_par_set_backend(smh_par *p, int backend);
 int smh_par_backend(const smh_par *p);
+/* The exchange beside the product (on by default; SMH_PAR_OVERLAP=0 in the environment switches it off).  The blocks of the
+ * reference's design are independent (sparsemat_par.rs:54-64: every block multiplies on its own, results at b R), so the order
+ * in which a block's rows are multiplied is free of semantics.  When the exchange of a call is a WINDOW and the block's kernel
+ * can be launched by runs of rows (K1s: 256-row tiles, K1r: the plan's row ranges -- same kernels, same arithmetic per row, so
+ * results are bit-identical either way), smh_par_spmv_dev multiplies the rows other blocks reference first, starts the exchange
+ * on a second stream per block and multiplies the block's INTERIOR rows meanwhile; smh_par_cg_solve_vec starts the exchange of p,
+ * multiplies the interior rows (which reference no other block's entries) meanwhile and the rest after it.  smh_par_interior:
+ * the rows [*row_begin, *row_end) (local) of local block i that its kernel for `variant` treats as interior (equal: none -- the
+ * call is then not split for that block). */
+int smh_par_set_overlap(smh_par *p, int on);
+int smh_par_interior(const smh_par *p, size_t local_block, int variant, size_t *row_begin, size_t *row_end);
 /* what SMH_EXCHANGE_AUTO resolves to for this matrix (WINDOW when the matrix is square and no block
  * receives half of the vector or more, else ALLGATHER; NONE for one block) and the largest number of
  * entries any block receives in a window exchange */

@@ -126,6 +126,8 @@ SIGNATURES = {
     "smh_par_n_local_blocks": (_sz, [_vp]),
     "smh_par_set_backend": (_int, [_vp, _int]),
     "smh_par_backend": (_int, [_vp]),
+    "smh_par_set_overlap": (_int, [_vp, _int]),
+    "smh_par_interior": (_int, [_vp, _sz, _int, C.POINTER(_sz), C.POINTER(_sz)]),
     "smh_par_exchange_mode": (_int, [_vp, _int, C.POINTER(_int), C.POINTER(_sz)]),
     "smh_par_plan": (_int, [_sz, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_int), C.POINTER(_sz)]),
     "smh_par_vec_create": (_int, [_vp, _sz, C.POINTER(_vp)]),

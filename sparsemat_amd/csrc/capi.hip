@@ -815,6 +815,57 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
     }
 }
 
+// ---- products of a run of rows (par.hip: a block's boundary rows before / after its interior ones) --------------------------
+// The kernels whose launches decompose by rows WITHOUT changing any row's arithmetic: K1s (256-row tiles; bit-exact anyway) and
+// K1r (the plan's row ranges; a row's lanes, chunks and order do not depend on which workgroup takes it).  *gran_out = the row
+// granularity a run must respect (0: this handle's kernel for `variant` cannot be launched by parts).
+int spmv_rows_granularity(smh_crs *m, int variant, size_t *gran_out) {
+    *gran_out = 0;
+    if (m->n_rows == 0) return SMH_OK;
+    const int v = resolve_variant(m, variant);
+    if (v == SMH_SPMV_STREAM) {
+        StreamCfg c;
+        SMH_TRY(stream_cfg(m, &c));
+        if (!c.pipe) *gran_out = (size_t)kStreamRows * (size_t)(c.win ? 1 : c.rpt);
+    } else if (v == SMH_SPMV_VECTOR) {
+        bool ring = false;
+        SMH_TRY(vector_uses_ring(m, &ring));
+        if (ring && m->ring_blocks) {
+            const size_t n_tiles = (m->n_rows + 63) / 64;
+            *gran_out = ((n_tiles + m->ring_blocks - 1) / m->ring_blocks) * 64;  // build_ring_plan: tiles per row range
+        }
+    }
+    return SMH_OK;
+}
+
+// y[row0, row1) = (A x)[row0, row1): row0 a multiple of the granularity, row1 too or == n_rows.  Same kernels, same arithmetic as
+// the whole product.  dot_partials: as spmv_enqueue (K1s only; the tiles of the run write their partials, the others are left alone)
+int spmv_enqueue_rows(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, size_t row0, size_t row1,
+                      void *dot_partials, const void *dot_lhs) {
+    if (m->nnz > 0 && (size_t)m->max_col >= x_len)
+        return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, m->max_col);
+    if (row1 > m->n_rows) row1 = m->n_rows;
+    if (row0 >= row1) return SMH_OK;
+    size_t gran = 0;
+    SMH_TRY(spmv_rows_granularity(m, variant, &gran));
+    if (gran == 0 || row0 % gran || (row1 % gran && row1 != m->n_rows))
+        return fail(SMH_ERR_INVALID, "rows [%zu, %zu) cannot be launched on their own (granularity %zu)", row0, row1, gran);
+    const int v = resolve_variant(m, variant);
+    if (v == SMH_SPMV_STREAM) {
+        StreamCfg c;
+        SMH_TRY(stream_cfg(m, &c));
+        return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt, c.single_pass,
+                                  dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
+                                  (((m->dtype == SMH_F64 ? x_len + 1 : ((x_len + 3) & ~(size_t)3)) >= (size_t)m->stream_xs_end) &&
+                                   (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0,
+                                  row0 / gran, (row1 + gran - 1) / gran);
+    }
+    if (dot_partials) return fail(SMH_ERR_INVALID, "a product by parts with the dot epilogue needs the CSR-stream kernel");
+    return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_col16, m->d_val, x, y, m->n_rows, m->nnz,
+                             m->owns || m->nnz % 4 == 0, m->ring_blocks, m->d_phase_ptr, m->d_phases, m->ring_entries, m->ring_bands, s, nullptr,
+                             (unsigned)(row0 / gran), (unsigned)((row1 + gran - 1) / gran));
+}
+
 static int finish_create(smh_crs *m, int validate) {
     SMH_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     if (m->n_rows > 0) {

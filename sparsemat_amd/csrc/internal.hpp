@@ -67,7 +67,8 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
                        const uint8_t *len8, const uint32_t *tbase /* optional (with codes): byte row lengths + tile starts */,
                        const void *dot_lhs /* with dot_partials: the vector dotted with y (NULL: x); y may then be NULL */,
                        hipStream_t s, bool small_tiles = false /* no tile holds more than kStreamCapSmall entries */,
-                       int xs = 0 /* ... and the tiles' column intervals fit an LDS stage of x of xs * 1024 entries (2 or 4; stream_xs_* checked by the caller) */);
+                       int xs = 0 /* ... and the tiles' column intervals fit an LDS stage of x of xs * 1024 entries (2 or 4; stream_xs_* checked by the caller) */,
+                       uint64_t tile_begin = 0, uint64_t tile_end = ~uint64_t(0) /* the matrix's tiles [begin, end) only (default: all) */);
 int launch_stream_xs_stats(const uint32_t *win, size_t n_tiles, uint32_t *d_out2, hipStream_t s);
 int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
 // K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip)
@@ -139,7 +140,8 @@ int launch_tile_span(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
                       const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, unsigned bands,
-                      hipStream_t s, void *dot_partials = nullptr /* DOT form: y = lhs (read only), n_blocks + 1 partials of lhs . (A x) */);
+                      hipStream_t s, void *dot_partials = nullptr /* DOT form: y = lhs (read only), n_blocks + 1 partials of lhs . (A x) */,
+                      unsigned block_begin = 0, unsigned block_end = ~0u /* the plan's row ranges [begin, end) only (default: all; not with the DOT form) */);
 // banded ring (4 bands): per-tile column intervals (the K1s inspector over 64-row tiles) and the 16-bit ring slots
 int launch_tile_intervals(const uint32_t *off, const uint32_t *col, size_t n_rows, size_t tile_rows, size_t max_width,
                           uint32_t *win, uint32_t *d_count, hipStream_t s);
@@ -167,6 +169,10 @@ int launch_spmv_tiled(::smh_crs *m, const void *x, size_t x_len, void *y, hipStr
 size_t spmv_fused_dot_partials(::smh_crs *m, size_t x_len, int variant, bool any_lhs = false);
 int spmv_enqueue(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, void *dot_partials = nullptr,
                  const void *dot_lhs = nullptr);
+// products of a run of rows (capi.hip; used by par.hip to multiply a block's boundary rows before / after its interior ones)
+int spmv_rows_granularity(::smh_crs *m, int variant, size_t *gran_out);
+int spmv_enqueue_rows(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, size_t row0, size_t row1,
+                      void *dot_partials = nullptr, const void *dot_lhs = nullptr);
 // BLAS-1 (a_dev: scalar read from device memory when non-null, else `a`)
 enum class Ew { Add, Sub, Scale, Axpy, Xpby, RSubInto };
 int launch_ew(int dtype, Ew op, void *x, const void *y, size_t n, double a, const void *a_dev, hipStream_t s);

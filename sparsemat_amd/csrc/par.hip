@@ -72,6 +72,11 @@ struct ParBlock {
     bool owns_m = true;
     size_t r0 = 0, r1 = 0;        // global rows [r0, r1)
     hipStream_t s = nullptr;
+    hipStream_t sx = nullptr;       // the exchange's stream when it runs beside the interior rows' product
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // s -> sx (what the exchange needs is written), sx -> s (the exchange is done)
+    // INTERIOR rows [in0, in1) (local): no other block references them and they reference no other block's columns, so their
+    // product needs nothing from the exchange and gives nothing to it (in1 <= in0: none)
+    size_t in0 = 0, in1 = 0;
     hipEvent_t ev_slice = nullptr;  // own slice of the vector being exchanged is written
     hipEvent_t ev_done = nullptr;   // this block's pulls from its peers are complete
     hipEvent_t ev_red[2] = {nullptr, nullptr};  // its value of fold slot 0 / 1 is written
@@ -119,6 +124,20 @@ __global__ void __launch_bounds__(kBlock) k_peer_pull(uint32_t *__restrict__ dst
     }
 }
 
+// flag[t] = 1 when a row of the 256-row tile t references a column outside [c0, c1) (the block's own slice of the vector)
+__global__ void __launch_bounds__(kBlock) k_par_remote_tiles(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, uint64_t n_rows,
+                                                             uint32_t c0, uint32_t c1, uint8_t *__restrict__ flag) {
+    const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool remote = false;
+    if (r < n_rows)
+        for (uint64_t k = off[r], e = off[r + 1]; k < e; ++k) {
+            const uint32_t c = col[k];
+            remote |= c < c0 || c >= c1;
+        }
+    const bool any = __syncthreads_or(remote);
+    if (threadIdx.x == 0) flag[blockIdx.x] = any;
+}
+
 }  // namespace
 
 struct smh_par {
@@ -128,6 +147,7 @@ struct smh_par {
     smh_comm *rank_comm = nullptr;  // one process per GPU (borrowed)
     int backend = SMH_PAR_BACKEND_PEER;  // resolved
     bool comms_ready = false;
+    bool overlap = true;            // window exchanges run beside the interior rows' product (smh_par_set_overlap; SMH_PAR_OVERLAP=0)
     // column intervals of ALL blocks: block q references [lo[q], hi[q]] when needs[q]
     std::vector<uint32_t> lo, hi;
     std::vector<uint8_t> needs;
@@ -161,6 +181,7 @@ int sync_all(smh_par *p) {
     for (ParBlock &blk : p->b) {
         SMH_TRY(use(blk));
         SMH_HIP(hipStreamSynchronize(blk.s));
+        if (blk.sx) SMH_HIP(hipStreamSynchronize(blk.sx));
     }
     return SMH_OK;
 }
@@ -245,7 +266,10 @@ int ensure_comms(smh_par *p) {
 }
 
 // ---- the exchange -------------------------------------------------------------------------------------------------
-int exchange_rccl(smh_par *p, smh_par_vec *v, int mode) {
+// side: on the blocks' exchange streams (sx) instead of their main ones -- the caller forks and joins them
+hipStream_t xs(const ParBlock &blk, bool side) { return side ? blk.sx : blk.s; }
+
+int exchange_rccl(smh_par *p, smh_par_vec *v, int mode, bool side) {
     SMH_TRY(ensure_comms(p));
     const size_t vs = dtype_size(p->dtype), nb = p->n_blocks, R = p->rows_per_block;
     const ncclDataType_t dt = nccl_type(p->dtype);
@@ -256,7 +280,7 @@ int exchange_rccl(smh_par *p, smh_par_vec *v, int mode) {
             ParBlock &blk = p->b[k];
             SMH_TRY(use(blk));
             char *buf = (char *)v->d[k];
-            SMH_NCCL(ncclAllGather(buf + blk.index * R * vs, buf, R, dt, comm_of(p, blk), blk.s));
+            SMH_NCCL(ncclAllGather(buf + blk.index * R * vs, buf, R, dt, comm_of(p, blk), xs(blk, side)));
         }
         SMH_NCCL(ncclGroupEnd());
         // ... and the last block's remainder rows [n_blocks R, n_rows) follow as one broadcast from their owner
@@ -267,7 +291,7 @@ int exchange_rccl(smh_par *p, smh_par_vec *v, int mode) {
                 ParBlock &blk = p->b[k];
                 SMH_TRY(use(blk));
                 char *tail = (char *)v->d[k] + nb * R * vs;
-                SMH_NCCL(ncclBroadcast(tail, tail, rem, dt, (int)(nb - 1), comm_of(p, blk), blk.s));
+                SMH_NCCL(ncclBroadcast(tail, tail, rem, dt, (int)(nb - 1), comm_of(p, blk), xs(blk, side)));
             }
             SMH_NCCL(ncclGroupEnd());
         }
@@ -284,22 +308,22 @@ int exchange_rccl(smh_par *p, smh_par_vec *v, int mode) {
             if (q == blk.index) continue;
             size_t a, e;
             recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), blk.index, q, &a, &e);  // what I need of q's slice
-            if (a < e) SMH_NCCL(ncclRecv(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), blk.s));
+            if (a < e) SMH_NCCL(ncclRecv(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), xs(blk, side)));
             recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q, blk.index, &a, &e);  // what q needs of mine
-            if (a < e) SMH_NCCL(ncclSend(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), blk.s));
+            if (a < e) SMH_NCCL(ncclSend(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), xs(blk, side)));
         }
     }
     SMH_NCCL(ncclGroupEnd());
     return SMH_OK;
 }
 
-int exchange_peer(smh_par *p, smh_par_vec *v, int mode) {
+int exchange_peer(smh_par *p, smh_par_vec *v, int mode, bool side) {
     const size_t vs = dtype_size(p->dtype), nb = p->n_blocks, nl = p->b.size();
     const size_t wpe = vs / 4;  // 32-bit words per entry
     // 1. every block's slice is complete once what its stream holds so far has run
     for (ParBlock &blk : p->b) {
         SMH_TRY(use(blk));
-        SMH_HIP(hipEventRecord(blk.ev_slice, blk.s));
+        SMH_HIP(hipEventRecord(blk.ev_slice, xs(blk, side)));
     }
     // 2. every block pulls what it needs from the owners' buffers
     std::vector<uint8_t> pulled(nl * nl, 0);  // [q * nl + src]: q read from src
@@ -313,7 +337,7 @@ int exchange_peer(smh_par *p, smh_par_vec *v, int mode) {
             if (args.n == 0) return SMH_OK;
             uint64_t blocks = (words / 4 + kBlock - 1) / kBlock;
             blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-            hipLaunchKernelGGL(k_peer_pull, dim3((unsigned)blocks), dim3(kBlock), 0, q.s, (uint32_t *)v->d[qi], args);
+            hipLaunchKernelGGL(k_peer_pull, dim3((unsigned)blocks), dim3(kBlock), 0, xs(q, side), (uint32_t *)v->d[qi], args);
             SMH_HIP(hipGetLastError());
             args.n = 0;
             words = 0;
@@ -327,7 +351,7 @@ int exchange_peer(smh_par *p, smh_par_vec *v, int mode) {
                 recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q.index, src.index, &a, &e);
             if (a >= e) continue;
             pulled[qi * nl + si] = 1;
-            SMH_HIP(hipStreamWaitEvent(q.s, src.ev_slice, 0));
+            SMH_HIP(hipStreamWaitEvent(xs(q, side), src.ev_slice, 0));
             if (p->peer_ok[qi * nl + si]) {
                 args.src[args.n] = (const uint32_t *)v->d[si];
                 args.w0[args.n] = (uint64_t)a * wpe;
@@ -335,29 +359,112 @@ int exchange_peer(smh_par *p, smh_par_vec *v, int mode) {
                 words += (uint64_t)(e - a) * wpe;
                 if (++args.n == kMaxPull) SMH_TRY(flush());
             } else {  // no direct access between the two devices: the runtime stages the copy
-                SMH_HIP(hipMemcpyPeerAsync((char *)v->d[qi] + a * vs, q.device, (const char *)v->d[si] + a * vs, src.device, (e - a) * vs, q.s));
+                SMH_HIP(hipMemcpyPeerAsync((char *)v->d[qi] + a * vs, q.device, (const char *)v->d[si] + a * vs, src.device, (e - a) * vs, xs(q, side)));
             }
         }
         SMH_TRY(flush());
-        SMH_HIP(hipEventRecord(q.ev_done, q.s));
+        SMH_HIP(hipEventRecord(q.ev_done, xs(q, side)));
     }
     // 3. nobody overwrites its slice while a peer may still be reading it
     for (size_t si = 0; si < nl; ++si) {
         ParBlock &src = p->b[si];
         SMH_TRY(use(src));
         for (size_t qi = 0; qi < nl; ++qi)
-            if (pulled[qi * nl + si]) SMH_HIP(hipStreamWaitEvent(src.s, p->b[qi].ev_done, 0));
+            if (pulled[qi * nl + si]) SMH_HIP(hipStreamWaitEvent(xs(src, side), p->b[qi].ev_done, 0));
     }
     return SMH_OK;
 }
 
-int exchange(smh_par *p, smh_par_vec *v, int mode) {
+int exchange(smh_par *p, smh_par_vec *v, int mode, bool side = false) {
     int m = SMH_EXCHANGE_NONE;
     SMH_TRY(resolve_mode(p, mode, &m));
     if (m == SMH_EXCHANGE_NONE) return SMH_OK;
     if (v->n != p->n_rows)
         return fail(SMH_ERR_DIM_MISMATCH, "exchange: the vector has %zu entries, the partition owns %zu rows", v->n, p->n_rows);
-    return p->backend == SMH_PAR_BACKEND_RCCL ? exchange_rccl(p, v, m) : exchange_peer(p, v, m);
+    return p->backend == SMH_PAR_BACKEND_RCCL ? exchange_rccl(p, v, m, side) : exchange_peer(p, v, m, side);
+}
+
+// ---- the exchange beside the product ("overlap the gather with the next block of rows") ----------------------
+// The blocks are independent (sparsemat_par.rs:54-64: every block multiplies on its own, results at b R), so WHICH of a block's
+// rows are multiplied first is free of semantics.  A WINDOW exchange moves only what blocks reference of each other; a block's
+// interior rows [in0, in1) neither feed it nor need it.  So the exchange runs on a second stream per block while the interior
+// rows are multiplied: fork() after what the exchange reads is written, join() before what it writes is read.
+int fork_side(smh_par *p) {
+    for (ParBlock &blk : p->b) {
+        SMH_TRY(use(blk));
+        SMH_HIP(hipEventRecord(blk.ev_fork, blk.s));
+        SMH_HIP(hipStreamWaitEvent(blk.sx, blk.ev_fork, 0));
+    }
+    return SMH_OK;
+}
+int join_side(smh_par *p) {
+    for (ParBlock &blk : p->b) {
+        SMH_TRY(use(blk));
+        SMH_HIP(hipEventRecord(blk.ev_join, blk.sx));
+        SMH_HIP(hipStreamWaitEvent(blk.s, blk.ev_join, 0));
+    }
+    return SMH_OK;
+}
+
+// the interior of a block as ITS kernel for `variant` can launch it: [*a, *e) (local rows; *a == *e: the product is not split)
+int interior_for(ParBlock &blk, int variant, size_t *a, size_t *e) {
+    *a = *e = 0;
+    if (blk.in1 <= blk.in0) return SMH_OK;
+    size_t gran = 0;
+    SMH_TRY(spmv_rows_granularity(blk.m, variant, &gran));
+    if (gran == 0) return SMH_OK;
+    const size_t n_loc = blk.r1 - blk.r0;
+    const size_t lo = (blk.in0 + gran - 1) / gran * gran, hi = blk.in1 == n_loc ? n_loc : blk.in1 / gran * gran;
+    if (lo < hi && (lo > 0 || hi < n_loc)) { *a = lo; *e = hi; }
+    return SMH_OK;
+}
+
+// does a window exchange run beside the products for this call?  (every local block decides the same way: the mode is global)
+bool overlapped(const smh_par *p, int resolved_mode) {
+    static const bool off = getenv("SMH_PAR_OVERLAP") && atoi(getenv("SMH_PAR_OVERLAP")) == 0;  // tuning knob
+    return p->overlap && !off && resolved_mode == SMH_EXCHANGE_WINDOW && !lone_block_skips(p);
+}
+
+// a block's interior: the largest run of 256-row tiles that holds no row another block references and no row that references
+// another block's columns (square matrices: the window exchange's precondition)
+int find_interiors(smh_par *p) {
+    const size_t nb = p->n_blocks;
+    for (ParBlock &blk : p->b) {
+        blk.in0 = blk.in1 = 0;
+        const size_t n_loc = blk.r1 - blk.r0;
+        if (p->n_rows != p->n_cols || n_loc == 0 || nb <= 1) continue;
+        SMH_TRY(use(blk));
+        const size_t n_tiles = (n_loc + kBlock - 1) / kBlock;
+        std::vector<uint8_t> dirty(n_tiles, 0);
+        if (smh_crs_nnz(blk.m)) {
+            uint8_t *d_flag = nullptr;
+            SMH_HIP(hipMalloc((void **)&d_flag, n_tiles));
+            hipLaunchKernelGGL(k_par_remote_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, blk.s, blk.m->d_off, blk.m->d_col, (uint64_t)n_loc,
+                               (uint32_t)blk.r0, (uint32_t)blk.r1, d_flag);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(dirty.data(), d_flag, n_tiles, hipMemcpyDeviceToHost, blk.s);
+            if (e == hipSuccess) e = hipStreamSynchronize(blk.s);
+            (void)hipFree(d_flag);
+            SMH_HIP(e);
+        }
+        for (size_t q = 0; q < nb; ++q) {  // what block q references of my slice
+            size_t a, e;
+            recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q, blk.index, &a, &e);
+            if (a < e)
+                for (size_t t = (a - blk.r0) / kBlock; t <= (e - 1 - blk.r0) / kBlock; ++t) dirty[t] = 1;
+        }
+        size_t best0 = 0, best1 = 0, run0 = 0;
+        for (size_t t = 0; t <= n_tiles; ++t) {
+            if (t == n_tiles || dirty[t]) {
+                if (t - run0 > best1 - best0) { best0 = run0; best1 = t; }
+                run0 = t + 1;
+            }
+        }
+        blk.in0 = best0 * kBlock;
+        blk.in1 = best1 * kBlock < n_loc ? best1 * kBlock : n_loc;
+        if (blk.in1 <= blk.in0) blk.in0 = blk.in1 = 0;
+    }
+    return SMH_OK;
 }
 
 // ---- cross-block folds of device-resident scalars ---------------------------------------------------------------------
@@ -464,6 +571,9 @@ int finish_par(smh_par *p) {
     for (ParBlock &blk : p->b) {
         SMH_TRY(use(blk));
         SMH_HIP(hipStreamCreateWithFlags(&blk.s, hipStreamNonBlocking));
+        SMH_HIP(hipStreamCreateWithFlags(&blk.sx, hipStreamNonBlocking));
+        SMH_HIP(hipEventCreateWithFlags(&blk.ev_fork, hipEventDisableTiming));
+        SMH_HIP(hipEventCreateWithFlags(&blk.ev_join, hipEventDisableTiming));
         SMH_HIP(hipEventCreateWithFlags(&blk.ev_slice, hipEventDisableTiming));
         SMH_HIP(hipEventCreateWithFlags(&blk.ev_done, hipEventDisableTiming));
         SMH_HIP(hipEventCreateWithFlags(&blk.ev_red[0], hipEventDisableTiming));
@@ -632,7 +742,8 @@ int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size
                                    values ? (const char *)values + (size_t)base * vs : nullptr, validate, &blk.m));
             SMH_TRY(own_interval(blk, n_cols, &p->needs[k], &p->lo[k], &p->hi[k]));
         }
-        return finish_par(p);
+        SMH_TRY(finish_par(p));
+        return find_interiors(p);
     };
     const int rc = go();
     if (rc != SMH_OK) return par_fail_cleanup(p, rc, prev);
@@ -671,7 +782,8 @@ int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_pa
             SMH_TRY(use(blk));
             SMH_TRY(own_interval(blk, p->n_cols, &p->needs[k], &p->lo[k], &p->hi[k]));
         }
-        return finish_par(p);
+        SMH_TRY(finish_par(p));
+        return find_interiors(p);
     };
     const int rc = go();
     if (rc != SMH_OK) return par_fail_cleanup(p, rc, prev);
@@ -723,7 +835,7 @@ int smh_par_create_rank(smh_comm *comm, size_t n_rows, smh_crs *block, smh_par *
         (void)hipFree(d_table);
         SMH_TRY(grc);
         for (size_t q = 0; q < n_blocks; ++q) { p->needs[q] = (uint8_t)table[3 * q]; p->lo[q] = table[3 * q + 1]; p->hi[q] = table[3 * q + 2]; }
-        return SMH_OK;
+        return find_interiors(p);
     };
     const int rc = go();
     if (rc != SMH_OK) return par_fail_cleanup(p, rc, prev);
@@ -744,7 +856,10 @@ int smh_par_destroy(smh_par *p) {
     for (ParBlock &blk : p->b) {
         (void)hipSetDevice(blk.device);
         if (blk.comm) (void)ncclCommDestroy(blk.comm);
+        if (blk.sx) { (void)hipStreamSynchronize(blk.sx); (void)hipStreamDestroy(blk.sx); }
         if (blk.s) (void)hipStreamDestroy(blk.s);
+        if (blk.ev_fork) (void)hipEventDestroy(blk.ev_fork);
+        if (blk.ev_join) (void)hipEventDestroy(blk.ev_join);
         if (blk.ev_slice) (void)hipEventDestroy(blk.ev_slice);
         if (blk.ev_done) (void)hipEventDestroy(blk.ev_done);
         if (blk.ev_red[0]) (void)hipEventDestroy(blk.ev_red[0]);
@@ -924,12 +1039,55 @@ int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int varia
     if (y->n != p->n_rows) return fail(SMH_ERR_DIM_MISMATCH, "Dimension mismatch");
     DeviceGuard g;
     const size_t vs = dtype_size(p->dtype);
+    int m = SMH_EXCHANGE_NONE;
+    SMH_TRY(resolve_mode(p, mode, &m));
+    if (!overlapped(p, m)) {
+        for (size_t k = 0; k < p->b.size(); ++k) {
+            ParBlock &blk = p->b[k];
+            SMH_TRY(use(blk));
+            SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s));  // results at b R (:64)
+        }
+        return exchange(p, y, mode);
+    }
+    // the rows other blocks reference first, then the exchange on the side streams while the interior rows are multiplied
+    std::vector<size_t> ia(p->b.size(), 0), ie(p->b.size(), 0);
     for (size_t k = 0; k < p->b.size(); ++k) {
         ParBlock &blk = p->b[k];
         SMH_TRY(use(blk));
-        SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s));  // results at b R (:64)
+        SMH_TRY(interior_for(blk, variant, &ia[k], &ie[k]));
+        char *yk = (char *)y->d[k] + blk.r0 * vs;
+        if (ie[k] > ia[k]) {
+            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.s, 0, ia[k]));
+            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.s, ie[k], blk.r1 - blk.r0));
+        } else {
+            SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, yk, variant, blk.s));
+        }
     }
-    return exchange(p, y, mode);
+    SMH_TRY(fork_side(p));
+    SMH_TRY(exchange(p, y, mode, true));
+    for (size_t k = 0; k < p->b.size(); ++k) {
+        ParBlock &blk = p->b[k];
+        if (ie[k] <= ia[k]) continue;
+        SMH_TRY(use(blk));
+        SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s, ia[k], ie[k]));
+    }
+    return join_side(p);
+}
+
+int smh_par_set_overlap(smh_par *p, int on) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    DeviceGuard g;
+    SMH_TRY(sync_all(p));
+    p->overlap = on != 0;
+    return SMH_OK;
+}
+
+int smh_par_interior(const smh_par *p, size_t local_block, int variant, size_t *row_begin, size_t *row_end) {
+    if (!p || local_block >= p->b.size() || !row_begin || !row_end) return fail(SMH_ERR_INVALID, "bad argument");
+    DeviceGuard g;
+    ParBlock &blk = const_cast<smh_par *>(p)->b[local_block];
+    SMH_TRY(use(blk));
+    return interior_for(blk, variant, row_begin, row_end);
 }
 
 int smh_par_exchange(smh_par *p, smh_par_vec *v, int mode) {
@@ -1031,20 +1189,41 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
         while (launched < iter_max) {
             const size_t batch = iter_max - launched < check_every ? iter_max - launched : check_every;
             for (size_t i = 0; i < batch; ++i) {
-                SMH_TRY(exchange(p, pv, mode));  // the entries of p a block references and another owns
-                for (size_t k = 0; k < p->b.size(); ++k) {
-                    ParBlock &blk = p->b[k];
-                    SMH_TRY(use(blk));
-                    // :43 and :45 -- with the CSR-stream kernel p.Ap rides the product's epilogue (one partial per tile, lhs = this
-                    // block's slice of p) as in the single-matrix solver: no second pass over p and Ap
-                    const size_t n_dot = spmv_fused_dot_partials(blk.m, n, variant, true);
-                    if (n_dot && n_dot <= blk.dotp_cap) {
-                        SMH_TRY(spmv_enqueue(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, blk.d_dotp, (const char *)pv->d[k] + blk.r0 * vs));
-                        SMH_TRY(launch_fold2(dt, blk.d_dotp, n_dot, blk.d_partials, red_mine(p, blk, 0), blk.s));
-                    } else {
-                        SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));
-                        SMH_TRY(launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, blk.r1 - blk.r0, blk.d_partials,
-                                           red_mine(p, blk, 0), blk.s));
+                // the entries of p a block references and another owns -- beside the product of the interior rows, which need none
+                // of them, when the exchange is a window (the rows that do wait for it at the join)
+                const bool side = overlapped(p, mode);
+                if (side) SMH_TRY(fork_side(p));
+                SMH_TRY(exchange(p, pv, mode, side));
+                for (int part = side ? 0 : 1; part < 2; ++part) {  // 0: interior rows (before the join), 1: the rest / everything
+                    if (part == 1 && side) SMH_TRY(join_side(p));
+                    for (size_t k = 0; k < p->b.size(); ++k) {
+                        ParBlock &blk = p->b[k];
+                        SMH_TRY(use(blk));
+                        const size_t n_loc = blk.r1 - blk.r0;
+                        size_t ia = 0, ie = 0;
+                        if (side) SMH_TRY(interior_for(blk, variant, &ia, &ie));
+                        const bool split = ie > ia;
+                        if (part == 0 && !split) continue;
+                        // :43 and :45 -- with the CSR-stream kernel p.Ap rides the product's epilogue (one partial per tile, lhs = this
+                        // block's slice of p) as in the single-matrix solver: no second pass over p and Ap
+                        const size_t n_dot = spmv_fused_dot_partials(blk.m, n, variant, true);
+                        const bool fused = n_dot && n_dot <= blk.dotp_cap;
+                        void *dotp = fused ? blk.d_dotp : nullptr;
+                        const void *lhs = fused ? (const char *)pv->d[k] + blk.r0 * vs : nullptr;
+                        if (part == 0) {
+                            SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ia, ie, dotp, lhs));
+                            continue;
+                        }
+                        if (split) {
+                            SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, 0, ia, dotp, lhs));
+                            SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ie, n_loc, dotp, lhs));
+                        } else if (fused) {
+                            SMH_TRY(spmv_enqueue(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, blk.d_dotp, lhs));
+                        } else {
+                            SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));
+                        }
+                        if (fused) SMH_TRY(launch_fold2(dt, blk.d_dotp, n_dot, blk.d_partials, red_mine(p, blk, 0), blk.s));
+                        else SMH_TRY(launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, n_loc, blk.d_partials, red_mine(p, blk, 0), blk.s));
                     }
                 }
                 SMH_TRY(combine(p, 0));

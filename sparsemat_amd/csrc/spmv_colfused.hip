@@ -182,6 +182,9 @@ k_spmv_colfused(const uint32_t *__restrict__ tile_row, const uint32_t *__restric
     for (int j = 0; j < RT; ++j) acc[j] = T(0);
     const uint32_t row_first = tile_row[tile];
     const uint32_t h = (tile_row[tile + 1] - row_first + 63u) / 64u;  // rows per lane of this tile (<= RT)
+    // (build_colfused verifies the tile table before any kernel sees it; a tile of more than 64 RT rows -- the inconsistency behind
+    // round 2's memory fault during bring-up, DESIGN.md "K2f" -- would make the lane ranges below walk past the count table)
+    if (h > (uint32_t)RT) return;
     const uint32_t *seg_t = seg + tile * n_blocks;
     const uint8_t *cnt_t = cnt + (tile * n_blocks * kWave + lane) * RT;
     for (uint32_t b = 0; b < n_blocks; ++b) {

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__((Ring2Cfg<T, RING>::kThreads), 4)  // 4 waves 
 k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint16_t *__restrict__ col16,
              const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
              const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases, uint32_t bands,
-             T *__restrict__ dot_partials) {
+             T *__restrict__ dot_partials, uint32_t lb0, uint32_t lb_n) {
     T dacc_v = T(0);
     T *dacc = DOT ? &dacc_v : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];  // RING * sizeof(T), dynamic
@@ -277,7 +277,11 @@ k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
     const uint32_t MASK = (bands == 4u ? (uint32_t)RING / 4u : (uint32_t)RING) - 1u;
     constexpr int kRing2Threads = Ring2Cfg<T, RING>::kThreads;
     const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);  // XCD-aware: neighbours share an L2
+    // XCD-aware: neighbours share an L2.  A launch covers the plan's row ranges [lb0, lb0 + lb_n) (all of them, or -- the
+    // partitioned product, par.hip -- a block's boundary / interior ranges); the grid is lb_n rounded up to a multiple of 8
+    const uint32_t lb_rel = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (lb_rel >= lb_n) return;  // (whole workgroup, before any barrier)
+    const uint32_t lb = lb0 + lb_rel;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t p0 = phase_ptr[lb], p1 = phase_ptr[lb + 1];
@@ -374,17 +378,23 @@ int launch_narrow_columns(const uint32_t *col, size_t nnz, uint16_t *col16, size
 template <typename T, int RING>
 static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16, const T *val,
                           const T *x, T *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
-                          const uint32_t *phase_ptr, const RingPhase *phases, uint32_t bands, T *dot_partials, hipStream_t s) {
+                          const uint32_t *phase_ptr, const RingPhase *phases, uint32_t bands, T *dot_partials, hipStream_t s,
+                          unsigned block_begin, unsigned block_end) {
     if (bands == 4u && !col16) return fail(SMH_ERR_INVALID, "banded ring plan without the 16-bit slot array");
+    // the plan's row ranges [lb0, lb1) (default: all of them)
+    const unsigned lb0 = block_begin < n_blocks ? block_begin : n_blocks, lb1 = block_end < n_blocks ? block_end : n_blocks;
+    const bool whole = lb0 == 0 && lb1 == n_blocks;
+    if (!whole && dot_partials) return fail(SMH_ERR_INVALID, "ring kernel: the DOT form takes the whole plan");
+    if (lb1 <= lb0) return SMH_OK;
     // entries the streaming kernel may touch: everything when the arrays are padded to a multiple of 4,
     // else only whole chunks (the rest goes to k_ring2_tail)
     const uint64_t nnz_lim = padded ? nnz : (nnz & ~uint64_t(3));
     if (dot_partials) SMH_HIP(hipMemsetAsync(dot_partials, 0, ((size_t)n_blocks + 1) * sizeof(T), s));
     if (nnz_lim == 0) {
-        if (!dot_partials) SMH_HIP(hipMemsetAsync(y, 0, n_rows * sizeof(T), s));
+        if (!dot_partials && lb1 == n_blocks) SMH_HIP(hipMemsetAsync(y, 0, n_rows * sizeof(T), s));  // (<= 3 entries: the tail kernel below writes them)
     } else {
         const uint64_t last_chunk = (nnz_lim - 1) & ~uint64_t(3);
-        dim3 grid(n_blocks), block(Ring2Cfg<T, RING>::kThreads);
+        dim3 grid(((lb1 - lb0) + 7u) & ~7u), block(Ring2Cfg<T, RING>::kThreads);
         constexpr size_t lds_bytes = (size_t)RING * sizeof(T);
         // dynamic LDS above 64 KiB must be allowed per kernel (idempotent, cheap)
 #define SMH_R2_LAUNCH2(L, C, N, D)                                                                                       \
@@ -400,7 +410,8 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
             attr_mask.fetch_or(dev_bit, std::memory_order_release);                                                      \
         }                                                                                                                \
         hipLaunchKernelGGL((k_spmv_ring2<T, L, C, N, RING, D>), grid, block, lds_bytes, s, off, col, col16, val, x, y,   \
-                           (uint32_t)nnz_lim, last_chunk, phase_ptr, phases, bands, dot_partials);                       \
+                           (uint32_t)nnz_lim, last_chunk, phase_ptr, phases, bands, dot_partials, (uint32_t)lb0,         \
+                           (uint32_t)(lb1 - lb0));                                                                       \
     } while (0)
 #define SMH_R2_LAUNCH1(L, C, N)                                                            \
     do {                                                                                   \
@@ -429,7 +440,7 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
 #undef SMH_R2_LAUNCH2
         SMH_HIP(hipGetLastError());
     }
-    if (nnz_lim != nnz) {
+    if (nnz_lim != nnz && lb1 == n_blocks) {  // (the last <= 3 entries belong to the last rows: with the launch that covers them)
         if (dot_partials)
             hipLaunchKernelGGL(k_ring2_tail_dot<T>, dim3(1), dim3(64), 0, s, off, col, val, x, (const T *)y, dot_partials + n_blocks,
                                (uint64_t)n_rows, nnz_lim, (uint64_t)nnz);
@@ -445,22 +456,22 @@ static int launch_ring2_t(int lanes, int chunks, const uint32_t *off, const uint
 int launch_spmv_ring2(int dtype, int lanes, int chunks, const uint32_t *off, const uint32_t *col, const uint16_t *col16,
                       const void *val, const void *x, void *y, size_t n_rows, size_t nnz, bool padded, unsigned n_blocks,
                       const uint32_t *phase_ptr, const RingPhase *phases, unsigned ring_entries, unsigned bands,
-                      hipStream_t s, void *dot_partials) {
+                      hipStream_t s, void *dot_partials, unsigned block_begin, unsigned block_end) {
     if (n_rows == 0) return SMH_OK;
     if (bands != 1u && bands != 4u) return fail(SMH_ERR_INVALID, "ring kernel: %u bands", bands);
     if (dtype == SMH_F64) {
         if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "f64 ring kernel: ring of %u columns", ring_entries);
         return launch_ring2_t<double, kRingEntries>(lanes, chunks, off, col, col16, (const double *)val, (const double *)x,
                                                     (double *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands,
-                                                    (double *)dot_partials, s);
+                                                    (double *)dot_partials, s, block_begin, block_end);
     }
     if (ring_entries == (unsigned)kRingEntriesWide)
         return launch_ring2_t<float, kRingEntriesWide>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x,
                                                        (float *)y, n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands,
-                                                       (float *)dot_partials, s);
+                                                       (float *)dot_partials, s, block_begin, block_end);
     if (ring_entries != (unsigned)kRingEntries) return fail(SMH_ERR_INVALID, "ring kernel: ring of %u columns", ring_entries);
     return launch_ring2_t<float, kRingEntries>(lanes, chunks, off, col, col16, (const float *)val, (const float *)x, (float *)y,
-                                               n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, (float *)dot_partials, s);
+                                               n_rows, nnz, padded, n_blocks, phase_ptr, phases, bands, (float *)dot_partials, s, block_begin, block_end);
 }
 
 }  // namespace smh

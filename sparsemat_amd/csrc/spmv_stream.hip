@@ -198,7 +198,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
               uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials,
               const uint16_t *__restrict__ code, const uint32_t *__restrict__ cwin, const uint8_t *__restrict__ len8,
-              const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs) {
+              const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs, uint64_t tile0) {
     static_assert(!C16 || (RPT == 1 && !XWIN), "the code table describes 256-row tiles");
     static_assert(!L8 || (C16 && !MULTI), "row lengths as bytes: single-pass 256-row tiles with column codes");
     static_assert(!XS || (L8 && !XWIN), "x staged in LDS: the coded single-pass body");
@@ -212,7 +212,9 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     __shared__ T s_x[XWIN ? kStreamXWin : 1];
     // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of tiles
     const uint64_t q = n_tiles >> 3, rm = n_tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const uint64_t tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
+    // (n_tiles = the tiles of THIS launch, tile0 = the first of them: a launch may cover a run of the matrix's tiles only -- the
+    // partitioned product multiplies a block's boundary rows before its interior ones, par.hip)
+    const uint64_t tile = tile0 + (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
     constexpr uint64_t TILE_ROWS = (uint64_t)kStreamRows * RPT;
     const uint64_t r0 = tile * TILE_ROWS;
     const uint64_t r1 = r0 + TILE_ROWS < n_rows ? r0 + TILE_ROWS : n_rows;
@@ -497,9 +499,13 @@ template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
                            size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
                            const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs,
-                           hipStream_t s, bool small_tiles, int xs) {
+                           hipStream_t s, bool small_tiles, int xs, uint64_t tile_begin, uint64_t tile_end) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
-    const uint64_t n_tiles = stream_tiles(n_rows, win ? 1 : rpt);
+    const uint64_t all_tiles = stream_tiles(n_rows, win ? 1 : rpt);
+    // tiles [tile_begin, tile_end) of the matrix (default: all of them)
+    const uint64_t tile0 = tile_begin < all_tiles ? tile_begin : all_tiles, tile1 = tile_end < all_tiles ? tile_end : all_tiles;
+    if (tile1 <= tile0) return SMH_OK;
+    const uint64_t n_tiles = tile1 - tile0;
     const dim3 grid((unsigned)n_tiles), block(kBlock);
     // experiment knob: unused dynamic LDS per block, to cap the blocks a CU holds at once (0: whatever fits).  Unlike the
     // element-wise kernels (fewer, fatter grids stream faster) this kernel wants every block it can get: 512^3 Laplacian,
@@ -509,7 +515,7 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
 #define SMH_ST_LAUNCH(XW, R, D, M, C)                                                                                    \
     hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M, kStreamCap, C>), grid, block, lds_pad, s, off, col, val, x, y, \
                        (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin,                   \
-                       (const uint8_t *)nullptr, (const uint32_t *)nullptr, dot_lhs)
+                       (const uint8_t *)nullptr, (const uint32_t *)nullptr, dot_lhs, tile0)
 #define SMH_ST_PICK(XW, R, C)                                                     \
     do {                                                                          \
         if (single_pass) {                                                        \
@@ -522,7 +528,7 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     else if (rpt == 2) SMH_ST_PICK(false, 2, false);
 #define SMH_ST_XS(D, P)                                                                                                                     \
     hipLaunchKernelGGL((k_spmv_stream<T, false, 1, D, false, false, kStreamCapSmall, true, true, P>), grid, block, lds_pad, s, off, col, val, x, y, \
-                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs)
+                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0)
     else if (code && cwin && len8 && tbase && single_pass && small_tiles && xs == 2) {  // ... and x staged in LDS (2048 entries)
         if (dot_partials) SMH_ST_XS(true, 2); else SMH_ST_XS(false, 2);
     }
@@ -537,18 +543,18 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
         // kernel: rocprofv3 shows the texture addresser busy 70 % of the time (8 gather instructions per thread and tile)
         if (dot_partials)
             hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
         else
             hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
     }
     else if (code && cwin && len8 && tbase && single_pass) {  // column codes + byte row lengths
         if (dot_partials)
             hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
         else
             hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs);
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
     }
     else if (code && cwin) SMH_ST_PICK(false, 1, true);  // 16-bit column codes (every tile described)
     else SMH_ST_PICK(false, 1, false);
@@ -571,7 +577,7 @@ static int launch_stream_block_t(const uint32_t *off, const uint32_t *col, const
     hipLaunchKernelGGL((k_spmv_stream<T, false, R, false, A, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
                        (uint64_t)nnz_total, readable, n_tiles, (const uint32_t *)nullptr, (T *)nullptr,         \
                        (const uint16_t *)nullptr, (const uint32_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr,  \
-                       (const T *)nullptr)
+                       (const T *)nullptr, (uint64_t)0)
 #define SMH_SB_PICK(R)                                                                      \
     do {                                                                                     \
         if (single_pass) { if (acc) SMH_SB_LAUNCH(R, true, false); else SMH_SB_LAUNCH(R, false, false); } \
@@ -609,15 +615,15 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
                        size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
                        void *dot_partials, const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase,
-                       const void *dot_lhs, hipStream_t s, bool small_tiles, int xs) {
+                       const void *dot_lhs, hipStream_t s, bool small_tiles, int xs, uint64_t tile_begin, uint64_t tile_end) {
     if (n_rows == 0) return SMH_OK;
     if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
     if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
     if (dtype == SMH_F64)
         return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
-                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s, small_tiles, xs);
+                                       rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s, small_tiles, xs, tile_begin, tile_end);
     return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
-                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s, small_tiles, xs);
+                                  single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s, small_tiles, xs, tile_begin, tile_end);
 }
 
 // row lengths as bytes (rows padded to whole 256-row tiles with zeros) and the tiles' first entries (n_tiles + 1 values);

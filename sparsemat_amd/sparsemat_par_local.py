@@ -198,6 +198,16 @@ class SparseMatParLocal:
     def backend(self):
         return {v: k for k, v in _lib.PAR_BACKENDS.items()}[lib().smh_par_backend(self._h)]
 
+    def set_overlap(self, on):
+        """Window exchanges beside the interior rows' product (``smh_par_set_overlap``; on by default)."""
+        check(lib().smh_par_set_overlap(self._h, 1 if on else 0))
+
+    def interior(self, local_block, variant="auto"):
+        """Local rows [begin, end) of a local block that its kernel for ``variant`` multiplies beside the exchange (equal: none)."""
+        a, e = C.c_size_t(), C.c_size_t()
+        check(lib().smh_par_interior(self._h, local_block, _lib.VARIANTS[variant], C.byref(a), C.byref(e)))
+        return a.value, e.value
+
     def exchange_mode(self, mode="auto"):
         """(what ``mode`` resolves to, largest number of entries any block receives in a window exchange)."""
         m, worst = C.c_int(), C.c_size_t()

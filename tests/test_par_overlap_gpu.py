@@ -1,0 +1,104 @@
+"""The exchange beside the product (csrc/par.hip; SURVEY 5 / 8e "overlap the gather with the next block of rows"): a block's rows
+other blocks reference are multiplied first, the window exchange runs on a second stream per block, the block's INTERIOR rows are
+multiplied meanwhile.  The reference's blocks are independent (sparsemat_par.rs:54-64, results at b R), so the order of a block's
+rows is free of semantics -- and here it is free of arithmetic too: the same kernels take the same rows with the same lanes, so y
+and every CG iterate must be BIT-IDENTICAL with the overlap on and off, and equal to the oracle where the kernel is bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+import sparsemat_amd as sm
+from sparsemat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def banded(rng, n, k, band, dtype):
+    off = np.arange(n + 1, dtype=np.uint32) * k
+    base = np.arange(n, dtype=np.int64)[:, None] + rng.integers(-band, band + 1, (n, k))
+    col = np.clip(base, 0, n - 1).astype(np.uint32).reshape(-1)
+    return off, col, rng.uniform(-1, 1, n * k).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("n_blocks", [2, 4, 7])
+def test_interior_rows_and_bit_identical_products(gpu, dtype, n_blocks):
+    rng = np.random.default_rng(40 + n_blocks)
+    n, k, band = 120_011, 16, 700
+    off, col, val = banded(rng, n, k, band, dtype)
+    m = sm.SparseMatParLocal.with_sub_matrices(n_blocks, n, n, off, col, val, device_ids=[0] * n_blocks)
+    assert m.exchange_mode("auto")[0] == "window"
+    r = n // n_blocks
+    cols2d = col.reshape(n, k).astype(np.int64)
+    for variant in ("stream", "vector"):
+        for b in range(n_blocks):
+            r0, r1 = b * r, (n if b == n_blocks - 1 else (b + 1) * r)
+            a, e = m.interior(b, variant)
+            assert 0 < e - a < r1 - r0, (variant, b, a, e)        # there is an interior, and there are boundary rows
+            inner = cols2d[r0 + a:r0 + e]
+            assert inner.min() >= r0 and inner.max() < r1           # interior rows reference the block's own slice only
+            others = np.concatenate([cols2d[:r0].reshape(-1), cols2d[r1:].reshape(-1)])
+            assert not ((others >= r0 + a) & (others < r0 + e)).any()  # ... and no other block references them
+            assert e - a > (r1 - r0) - 2 * (2 * band + 2048)        # not much more than the band is held back
+    with pytest.raises(sm.SparseMatPanic):
+        m.interior(n_blocks, "stream")
+    assert m.interior(0, "merge") == (0, 0)                         # a kernel that cannot be launched by runs of rows: no split
+    x_host = rng.uniform(-1, 1, n).astype(dtype)
+    want = oracle.spmv(off, col, val, x_host)
+    want2 = oracle.spmv(off, col, val, want)
+    for variant in ("stream", "vector", "auto", "merge"):
+        got = {}
+        for on in (True, False):
+            m.set_overlap(on)
+            x, y, z = m.vec(host=x_host), m.vec(), m.vec()
+            m.mvp_dev(x, y, variant=variant)
+            m.mvp_dev(y, z, variant=variant)   # the exchanged y IS the next x: every block must hold what it references
+            m.synchronize()
+            got[on] = (y.download(), z.download(), [z.download_block(b) for b in range(n_blocks)])
+        assert got[True][0].tobytes() == got[False][0].tobytes() and got[True][1].tobytes() == got[False][1].tobytes(), variant
+        for b in range(n_blocks):  # ... including the halo every block received
+            r0, r1 = b * r, (n if b == n_blocks - 1 else (b + 1) * r)
+            lo, hi = int(cols2d[r0:r1].min()), int(cols2d[r0:r1].max()) + 1
+            assert got[True][2][b][lo:hi].tobytes() == got[False][2][b][lo:hi].tobytes(), (variant, b)
+        if variant == "stream":  # K1s: the reference's order of additions
+            assert got[True][0].tobytes() == want.tobytes() and got[True][1].tobytes() == want2.tobytes()
+    m.set_overlap(True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_cg_iterates_are_bit_identical_with_and_without_the_overlap(gpu, dtype):
+    g = 40
+    off, col, val = oracle.laplace3d(g, g, g, dtype)
+    n = g * g * g
+    b_host = oracle.spmv(off, col, val, np.ones(n, dtype))
+    for n_blocks in (2, 5):
+        m = sm.SparseMatParLocal.with_sub_matrices(n_blocks, n, n, off, col, val, device_ids=[0] * n_blocks)
+        assert all(m.interior(b)[1] > m.interior(b)[0] for b in range(n_blocks))  # AUTO = K1s: 256-row tiles
+        res = {}
+        for on in (True, False):
+            m.set_overlap(on)
+            for iters in (1, 7, 400):
+                b, x = m.vec(host=b_host), m.vec()
+                res[(on, iters)] = (m.cg_solve_vec(b, x, tol=1e-6 if dtype == np.float32 else 1e-10, iter_max=iters, check_every=3), x.download())
+        for iters in (1, 7, 400):
+            (it_a, rr_a), xa = res[(True, iters)]
+            (it_b, rr_b), xb = res[(False, iters)]
+            assert it_a == it_b and rr_a == rr_b and xa.tobytes() == xb.tobytes(), (n_blocks, iters)
+        assert res[(True, 400)][0][0] < 400 and np.abs(res[(True, 400)][1] - 1).max() < 1e-3
+
+
+def test_blocks_without_an_interior_still_multiply(gpu):
+    """Scattered columns: every row references other blocks -- AUTO's exchange is the all-gather (no overlap), and a forced window
+    finds no interior: the call is then simply not split."""
+    rng = np.random.default_rng(44)
+    n, k = 30_000, 8
+    off = np.arange(n + 1, dtype=np.uint32) * k
+    col = rng.integers(0, n, n * k).astype(np.uint32)
+    val = rng.uniform(-1, 1, n * k).astype(np.float32)
+    m = sm.SparseMatParLocal.with_sub_matrices(3, n, n, off, col, val, device_ids=[0, 0, 0])
+    assert m.exchange_mode("auto")[0] == "allgather" and all(m.interior(b, "stream") == (0, 0) for b in range(3))
+    x_host = rng.uniform(-1, 1, n).astype(np.float32)
+    x, y = m.vec(host=x_host), m.vec()
+    m.mvp_dev(x, y, variant="stream", exchange="window")
+    m.synchronize()
+    assert y.download().tobytes() == oracle.spmv(off, col, val, x_host).tobytes()
