@@ -189,12 +189,6 @@ int smh_crs_scale(smh_crs *m, double a);
 int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out);
 /* override the VECTOR kernel's lanes-per-row (1,2,4,...,64; 0 = automatic) */
 int smh_crs_set_vector_lanes(smh_crs *m, int lanes);
-/* K1s-w, the STREAM kernel with the tile's x entries staged in LDS: an inspector describes
- * the columns of every 256-row tile as <= 4 disjoint intervals; mode -1 = automatic (used when at
- * least half of the tiles have such a description), 0 = never, 1 = always.  The table (integer
- * structure, invariants checked in tests): 8 u32 per tile {lo0,hi0,...,lo3,hi3}, all zero = none. */
-int smh_crs_set_stream_windows(smh_crs *m, int mode);
-int smh_crs_stream_windows(smh_crs *m, double *fraction_out, uint32_t *table_out);
 /* K1s XS, the STREAM kernel for coded single-pass tiles with the tile's column intervals of x staged in LDS by 16-byte loads
  * issued before the tile's own: mode -1 = automatic (x beyond the L2s; 2048 entries of x per tile, 4096 on f32),
  * 0 = never, 1 = whenever every tile's intervals fit a stage.  smh_crs_stream_layout reports what a STREAM launch of this

@@ -63,8 +63,6 @@ SIGNATURES = {
     "smh_crs_scale": (_int, [_vp, C.c_double]),
     "smh_crs_resolved_variant": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "smh_crs_set_vector_lanes": (_int, [_vp, _int]),
-    "smh_crs_set_stream_windows": (_int, [_vp, _int]),
-    "smh_crs_stream_windows": (_int, [_vp, C.POINTER(C.c_double), _vp]),
     "smh_crs_set_vector_chunks": (_int, [_vp, _int]),
     "smh_crs_set_ring": (_int, [_vp, _int]),
     "smh_crs_ring_entries": (_int, [_vp, _u32p]),

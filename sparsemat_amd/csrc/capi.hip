@@ -149,8 +149,8 @@ static void drop_colblock(smh_crs *m) {
     m->d_cb_val = nullptr;
     m->cb_built = false;
     (void)hipFree(m->d_cf_seg); (void)hipFree(m->d_cf_cnt); (void)hipFree(m->d_cf_col); (void)hipFree(m->d_cf_val);
-    (void)hipFree(m->d_cf_tile_row); (void)hipFree(m->d_cf_progress);
-    m->d_cf_seg = m->d_cf_col = m->d_cf_tile_row = m->d_cf_progress = nullptr;
+    (void)hipFree(m->d_cf_tile_row);
+    m->d_cf_seg = m->d_cf_col = m->d_cf_tile_row = nullptr;
     m->d_cf_cnt = nullptr;
     m->d_cf_val = nullptr;
     m->cf_built = m->cf_ok = false;
@@ -396,27 +396,6 @@ static int ensure_ring_plan(smh_crs *m, bool with_bands = true) {
     return SMH_OK;
 }
 
-// K1s-w: per-tile column intervals, once per matrix
-static int ensure_stream_windows(smh_crs *m) {
-    if (m->stream_planned) return SMH_OK;
-    const size_t n_tiles = (m->n_rows + kStreamRows - 1) / kStreamRows;
-    if (n_tiles) {
-        uint32_t *d_count = nullptr, h_count = 0;
-        SMH_HIP(hipMalloc((void **)&m->d_stream_win, n_tiles * 8 * sizeof(uint32_t)));
-        SMH_HIP(hipMalloc((void **)&d_count, sizeof(uint32_t)));
-        int rc = launch_stream_windows(m->d_off, m->d_col, m->n_rows, false, m->d_stream_win, d_count, m->stream);
-        hipError_t e = hipSuccess;
-        if (rc == SMH_OK) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, m->stream);
-        if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);
-        (void)hipFree(d_count);
-        if (rc == SMH_OK && e != hipSuccess) rc = hip_fail(e, "stream window readback", __FILE__, __LINE__);
-        SMH_TRY(rc);
-        m->stream_win_fraction = (double)h_count / (double)n_tiles;
-    }
-    m->stream_planned = true;
-    return SMH_OK;
-}
-
 // The column-blocked / tiled builders size their tables from n_cols and index them with col >> shift (col / slice): a handle
 // created without validation (smh_crs_create_dev's default) may hold columns >= n_cols, which would walk past those tables.
 // Every such build starts here (max_col is a create-time statistic: no per-call cost).
@@ -479,7 +458,6 @@ static int ensure_colfused(smh_crs *m) {
     bool fits = false;
     SMH_TRY(build_colfused(m->dtype, m->d_off, m->d_col, m->d_val, m->n_rows, m->nnz, cf_shift_for(m), blocks, rt, &m->cf_tiles,
                            &m->d_cf_tile_row, &m->d_cf_seg, &m->d_cf_cnt, &m->d_cf_col, &m->d_cf_val, &fits, m->stream));
-    if (fits) SMH_HIP(hipMalloc((void **)&m->d_cf_progress, 8 * blocks * 16 * sizeof(uint32_t)));  // per (XCD, block) lock-step counters, 16 slots each
     m->cf_shift = cf_shift_for(m);
     m->cf_blocks = blocks;
     m->cf_rt = rt;
@@ -644,42 +622,31 @@ static int stream_rpt(const smh_crs *m) {
 // returns the number of partials it would write (0: not fused -- run a separate dot).
 // K1s configuration the STREAM variant runs with for this handle (builds the code tables on first use)
 struct StreamCfg {
-    const uint32_t *win = nullptr;
     int rpt = 1;
     bool single_pass = false;
     const uint16_t *code = nullptr;
     const uint32_t *cwin = nullptr;
     const uint8_t *len8 = nullptr;
     const uint32_t *tbase = nullptr;
-    bool pipe = false;  // K1s-p: persistent blocks, three tiles in flight
     bool small = false; // no tile beyond kStreamCapSmall entries: the two-chunk body
     int xs = 0;         // ... and every tile's column intervals fit an LDS stage of x: 16-byte chunks per thread (2 or 4), 0 = no
 };
 static int stream_cfg(smh_crs *m, StreamCfg *c) {
     *c = StreamCfg();
-    if (m->use_stream_win == 1) {
-        SMH_TRY(ensure_stream_windows(m));
-        // measured (512^3 Laplacian): the windowed body is SLOWER (2.77 vs 1.80 ms: an extra barrier,
-        // 5 instead of 8 blocks per CU, as many window-load as gather instructions), so only on request
-        c->win = m->d_stream_win;
-    }
     // a 512-row tiling is only chosen when every such tile fits the LDS stage; the 256-row tiling takes
     // tiles of any density (loop-free body when the create-time statistic says that none overflows)
-    c->rpt = c->win ? 1 : stream_rpt(m);
+    c->rpt = stream_rpt(m);
     c->single_pass = m->have_stats && (c->rpt == 2 || m->max_tile_entries <= (uint32_t)kStreamCap);
     // 16-bit column codes when every tile's columns fall into <= 4 intervals of <= 16384 (stencils, bands)
     const char *c16_env = getenv("SMH_STREAM_C16");  // tuning knob: 0 = always the u32 columns
     // (single-pass tiles only: on dense multi-pass tiles -- banded C2 through K1s -- the decode costs more than
     // the bytes save, 0.83 vs 0.80 ms)
-    if (!(c16_env && atoi(c16_env) == 0) && !c->win && c->rpt == 1 && c->single_pass) {
+    if (!(c16_env && atoi(c16_env) == 0) && c->rpt == 1 && c->single_pass) {
         SMH_TRY(ensure_stream_codes(m));
         c->code = m->d_stream_code;
         c->cwin = m->d_stream_code ? m->d_stream_cwin : nullptr;
         static const bool l8_off = getenv("SMH_STREAM_L8") && atoi(getenv("SMH_STREAM_L8")) == 0;  // tuning knob
         if (c->cwin && !l8_off) { c->len8 = m->d_stream_len8; c->tbase = m->d_stream_tbase; }
-        // K1s-p (persistent blocks, several tiles in flight; spmv_stream_pipe.hip) is an experiment kept behind a knob: on the
-        // 512^3 Laplacian it measured 1.86-2.01 ms against K1s's 1.50-1.55 ms (profiles/r02_k1s_pipe_ab.log)
-        static const bool pipe_on = getenv("SMH_STREAM_PIPE") && atoi(getenv("SMH_STREAM_PIPE")) == 1;
         static const bool small_off = getenv("SMH_STREAM_SMALL") && atoi(getenv("SMH_STREAM_SMALL")) == 0;  // tuning knob
         c->small = !small_off && m->have_stats && m->max_tile_entries <= (uint32_t)kStreamCapSmall;
         static const bool xs_off = getenv("SMH_STREAM_XS") && atoi(getenv("SMH_STREAM_XS")) == 0;  // tuning knob
@@ -692,7 +659,6 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         c->xs = (xs_off || m->use_stream_xs == 0 || !c->small || !c->len8) ? 0
                 : (m->stream_xs_chunks <= 2u * kBlock && on2) ? 2
                 : (m->stream_xs_chunks <= 4u * kBlock && on4) ? 4 : 0;
-        c->pipe = pipe_on && c->cwin && c->len8 && c->tbase && m->max_tile_entries <= stream_pipe_cap() && (m->owns || m->nnz % 4 == 0);
     }
     return SMH_OK;
 }
@@ -707,7 +673,6 @@ size_t spmv_fused_dot_partials(smh_crs *m, size_t x_len, int variant, bool any_l
     if (!any_lhs && (m->n_rows != m->n_cols || x_len < m->n_rows)) return 0;
     StreamCfg c;
     if (stream_cfg(m, &c) != SMH_OK) return 0;
-    if (c.pipe) return stream_pipe_blocks(m->dtype, m->device);  // one partial per persistent block
     return stream_tiles(m->n_rows, c.rpt);
 }
 
@@ -732,10 +697,7 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
         case SMH_SPMV_STREAM: {
             StreamCfg c;
             SMH_TRY(stream_cfg(m, &c));
-            if (c.pipe)
-                return launch_spmv_stream_pipe(m->dtype, m->d_val, x, y, m->n_rows, m->nnz, dot_partials, c.code, c.cwin, c.len8, c.tbase,
-                                               dot_lhs, m->device, s);
-            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt,
+            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt,
                                       c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
                                       // the staged chunks are groups of 4 entries of x fetched with 16-byte loads (f32: one load, f64: two, entries
                                       // [g, g+2) and [g+2, g+4)); with x itself 16-byte aligned a load that holds at least one valid entry may reach past
@@ -785,7 +747,7 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
             SMH_TRY(ensure_colfused(m));
             if (m->cf_ok)
                 return launch_spmv_colfused(m->dtype, m->cf_rt, m->d_cf_tile_row, m->cf_tiles, m->d_cf_seg, m->d_cf_cnt, m->d_cf_col, m->d_cf_val,
-                                            x, y, m->n_rows, m->nnz, (uint32_t)m->cf_blocks, m->d_cf_progress, m->device, s);
+                                            x, y, m->n_rows, m->nnz, (uint32_t)m->cf_blocks, m->device, s);
         }
         [[fallthrough]];  // a (row, block) pair with more than 255 entries: the per-block launches
         case SMH_SPMV_COLBLOCK: {
@@ -826,7 +788,7 @@ int spmv_rows_granularity(smh_crs *m, int variant, size_t *gran_out) {
     if (v == SMH_SPMV_STREAM) {
         StreamCfg c;
         SMH_TRY(stream_cfg(m, &c));
-        if (!c.pipe) *gran_out = (size_t)kStreamRows * (size_t)(c.win ? 1 : c.rpt);
+        *gran_out = (size_t)kStreamRows * (size_t)c.rpt;
     } else if (v == SMH_SPMV_VECTOR) {
         bool ring = false;
         SMH_TRY(vector_uses_ring(m, &ring));
@@ -854,7 +816,7 @@ int spmv_enqueue_rows(smh_crs *m, const void *x, size_t x_len, void *y, int vari
     if (v == SMH_SPMV_STREAM) {
         StreamCfg c;
         SMH_TRY(stream_cfg(m, &c));
-        return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.win, c.rpt, c.single_pass,
+        return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt, c.single_pass,
                                   dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
                                   (((m->dtype == SMH_F64 ? x_len + 1 : ((x_len + 3) & ~(size_t)3)) >= (size_t)m->stream_xs_end) &&
                                    (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0,
@@ -1278,11 +1240,11 @@ int smh_crs_destroy(smh_crs *m) {
     if (m->owns) { (void)hipFree(m->d_off); (void)hipFree(m->d_col); (void)hipFree(m->d_val); }
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
     (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16); (void)hipFree(m->d_ring_win);
-    (void)hipFree(m->d_stream_win); (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
+    (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
     (void)hipFree(m->d_stream_len8); (void)hipFree(m->d_stream_tbase);
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);
     (void)hipFree(m->d_cf_seg); (void)hipFree(m->d_cf_cnt); (void)hipFree(m->d_cf_col); (void)hipFree(m->d_cf_val);
-    (void)hipFree(m->d_cf_tile_row); (void)hipFree(m->d_cf_progress);
+    (void)hipFree(m->d_cf_tile_row);
     (void)smh_crs_destroy(m->split_long); (void)smh_crs_destroy(m->split_short);
     (void)hipFree(m->d_split_rows); (void)hipFree(m->d_split_y);
     tiled_free(m);
@@ -1428,23 +1390,6 @@ int smh_crs_resolved_variant(const smh_crs *m, int *variant_out, int *lanes_out)
     return SMH_OK;
 }
 
-int smh_crs_set_stream_windows(smh_crs *m, int mode) {
-    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
-    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "window mode must be -1 (auto), 0 (off) or 1 (on)");
-    m->use_stream_win = mode;
-    return SMH_OK;
-}
-
-int smh_crs_stream_windows(smh_crs *m, double *fraction_out, uint32_t *table_out) {
-    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
-    SMH_TRY(ensure_stream_windows(m));
-    if (fraction_out) *fraction_out = m->stream_win_fraction;
-    const size_t n_tiles = (m->n_rows + kStreamRows - 1) / kStreamRows;
-    if (table_out && n_tiles)
-        SMH_HIP(hipMemcpy(table_out, m->d_stream_win, n_tiles * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return SMH_OK;
-}
-
 int smh_crs_set_stream_xs(smh_crs *m, int mode) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic), 0 (never) or 1 (whenever the tiles allow)");
@@ -1535,7 +1480,7 @@ int smh_crs_prepare(smh_crs *m, int variant) {
             if (!m->split_ok) return ensure_colblock(m);
             SMH_TRY(smh_crs_prepare(m->split_short, SMH_SPMV_AUTO));
             return smh_crs_prepare(m->split_long, SMH_SPMV_AUTO);
-        case SMH_SPMV_STREAM: return m->use_stream_win == 1 ? ensure_stream_windows(m) : ensure_stream_codes(m);
+        case SMH_SPMV_STREAM: return ensure_stream_codes(m);
         case SMH_SPMV_TILED: return tiled_build(m);
         case SMH_SPMV_SEQ: return SMH_OK;
         default: return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);

@@ -60,7 +60,7 @@ int launch_spmv_merge(int dtype, const uint32_t *off, const uint32_t *col, const
                       const uint32_t *tile_nz, uint32_t *carry_row, void *carry_val, hipStream_t s);
 // K1s (CSR-stream for short rows)
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
-                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rows_per_thread,
+                       size_t n_rows, size_t nnz, bool padded, int rows_per_thread,
                        bool single_pass /* no tile holds more than kStreamCap entries */,
                        void *dot_partials /* optional: x.y per tile, stream_tiles() entries */,
                        const uint16_t *code, const uint32_t *cwin /* optional: 16-bit column codes + their interval table */,
@@ -71,12 +71,6 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
                        uint64_t tile_begin = 0, uint64_t tile_end = ~uint64_t(0) /* the matrix's tiles [begin, end) only (default: all) */);
 int launch_stream_xs_stats(const uint32_t *win, size_t n_tiles, uint32_t *d_out2, hipStream_t s);
 int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
-// K1s-p (persistent blocks, three tiles in flight; spmv_stream_pipe.hip)
-uint32_t stream_pipe_cap();
-unsigned stream_pipe_blocks(int dtype, int device);
-int launch_spmv_stream_pipe(int dtype, const void *val, const void *x, void *y, size_t n_rows, size_t nnz, void *dot_partials,
-                            const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs,
-                            int device, hipStream_t s);
 size_t stream_tiles(size_t n_rows, int rows_per_thread);
 int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, bool for_codes, uint32_t *win,
                           uint32_t *d_count, hipStream_t s);
@@ -96,7 +90,7 @@ int build_colfused(int dtype, const uint32_t *off, const uint32_t *col, const vo
                    uint32_t **col2_out, void **val2_out, bool *fits_out, hipStream_t s);
 int launch_spmv_colfused(int dtype, uint32_t rt, const uint32_t *tile_row, size_t n_tiles, const uint32_t *seg, const uint8_t *cnt,
                          const uint32_t *col, const void *val, const void *x, void *y, size_t n_rows, size_t nnz, uint32_t n_blocks,
-                         uint32_t *progress, int device, hipStream_t s);
+                         int device, hipStream_t s);
 // K2s (a skewed matrix as a long-row and a short-row column-blocked matrix; spmv_colsplit.hip)
 int build_colsplit(int dtype, const uint32_t *off, const uint32_t *col, const void *val, size_t n_rows, size_t nnz, uint32_t min_long,
                    size_t *n_long_out, size_t *nnz_long_out, uint32_t **long_rows_out, uint32_t **off_l_out, uint32_t **col_l_out, void **val_l_out,
@@ -207,11 +201,6 @@ struct smh_crs {
     size_t n_tiles = 0;
     uint32_t *d_tile_row = nullptr, *d_tile_nz = nullptr, *d_carry_row = nullptr;
     void *d_carry_val = nullptr;
-    // K1s-w window table (lazy)
-    bool stream_planned = false;
-    uint32_t *d_stream_win = nullptr;
-    double stream_win_fraction = 0.0;  // share of tiles whose columns fit 4 intervals of <= kStreamXWin entries
-    int use_stream_win = -1;           // -1/0 never (measured slower), 1 always
     int stream_rows_per_thread = 0;    // 0 automatic (2 when every 512-row tile fits), 1 force one
     // K1s 16-bit column codes (lazy; kept only when every tile has a description)
     bool stream_coded = false;         // inspected
@@ -243,7 +232,7 @@ struct smh_crs {
     bool cf_ok = false;
     uint32_t cf_shift = 0, cf_rt = 0;
     size_t cf_blocks = 0, cf_tiles = 0;
-    uint32_t *d_cf_seg = nullptr, *d_cf_col = nullptr, *d_cf_tile_row = nullptr, *d_cf_progress = nullptr;
+    uint32_t *d_cf_seg = nullptr, *d_cf_col = nullptr, *d_cf_tile_row = nullptr;
     uint8_t *d_cf_cnt = nullptr;
     void *d_cf_val = nullptr;
     // K2t 2-D tiled copy (lazy; spmv_tiled.hip): entries by column slice, within a slice by row
@@ -252,7 +241,6 @@ struct smh_crs {
     uint64_t t2_tot = 0;                   // entries of the copy (slices padded to 8)
     void *d_t2_val = nullptr, *d_t2_prod = nullptr;  // values in copy order; the products of the last launch
     uint16_t *d_t2_code = nullptr, *d_t2_row = nullptr;  // column within the slice; row within the row block
-    uint64_t *d_t2_cbptr = nullptr;        // first entry of each slice (n_cb + 1)
     uint32_t *d_t2_tstart = nullptr;       // (n_rb + 1) x n_cb tile starts, relative to the slice
     uint32_t *d_t2_rbstart = nullptr;      // first row of each row block (n_rb + 1); blocks hold equal entry counts
     uint32_t *d_t3_cptr = nullptr;         // (round 3's form) first chunk of each slice (n_cb + 1)

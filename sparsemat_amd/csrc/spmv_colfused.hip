@@ -26,12 +26,11 @@
 // 1.98-2.05 ms against K2c's 2.19 ms, at the L2-hit gather rate (~160 G gathers/s).  Skewed rows do not: on BASELINE C3
 // (f64, power law 1..2048 -- two thirds of the entries sit in rows of 256 and more) the waves drift over all blocks at
 // once (5.3-5.6 ms, K2c 3.25 ms): a lane folds its rows sequentially, so a wave with a 2048-entry row falls behind, misses
-// more, and falls further behind.  An optional LOCK STEP (per-(XCD, block) counters in the XCD's L2, 16 slots per block
-// so the adds do not serialise on one address; a wave enters block b when all waves of its XCD have finished block
-// b - lag) was measured to cost more than it recovers: a barrier aligns the phases of all waves -- everyone streams, then
-// everyone gathers -- and the two stop overlapping (C2-uniform 3.75 ms with lag 1, 2.37 with lag 3; C3 10.7 / 5.2 ms).
-// It stays in the kernel as a knob (SMH_COLFUSED_LAG), off by default, bounded so that it can never hang; AUTO takes K2f
-// only for matrices whose longest row is within 2x the mean and leaves the rest to K2c.
+// more, and falls further behind.  (A lock step between the waves of an XCD -- per-(XCD, block) counters, a wave entering block b
+// only when all waves of its XCD had left block b - lag -- was built and measured in round 2 and cost more than it recovered: a
+// barrier aligns the phases of all waves, everyone streams, then everyone gathers, and the two stop overlapping: C2-uniform 3.75 ms
+// with lag 1, 2.37 with lag 3; C3 10.7 / 5.2 ms.  Removed in round 3; profiles/r02_k2f_sweep.log.)  AUTO takes K2f only for matrices
+// whose longest row is within 2x the mean and leaves the rest to K2c / K2t.
 //
 // A row's sum is formed block by block (ascending column block, storage order inside a block): not the reference's
 // order, so tolerance parity like K1r/K2/K2c -- and bit-exact against the oracle applied to the permuted rows, which the
@@ -151,18 +150,12 @@ k_cf_scatter(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col,
 }
 
 // ---- the product ------------------------------------------------------------------------------------------------------
-constexpr uint32_t kCfSpinCap = 1u << 15;  // polls of ~0.5 us before a wave stops waiting for its XCD (locality only)
-constexpr uint32_t kCfSlots = 16;          // lock-step counters per (XCD, column block)
-
 // RT rows per lane at most, NIT 16-byte chunks per lane and pass (a pass stages 256 * NIT entries per wave).
-// progress[(xcd * n_blocks + b) * 16 + slot] = waves of the XCD (those with in-XCD index % 16 == slot) that finished column
-// block b (zeroed before the launch); lag = D above (0: no waiting).
 template <typename T, int RT, int NIT>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_colfused(const uint32_t *__restrict__ tile_row, const uint32_t *__restrict__ seg, const uint8_t *__restrict__ cnt,
                 const uint32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
-                uint32_t n_blocks, uint64_t tile_begin, uint64_t tile_end, uint64_t nnz_readable, uint32_t *__restrict__ progress,
-                uint32_t lag) {
+                uint32_t n_blocks, uint64_t tile_begin, uint64_t tile_end, uint64_t nnz_readable) {
     static_assert(RT == 8 || RT == 16, "counts of a lane are read as one 8- or 16-byte word");
     constexpr uint32_t P = 4u * kWave * NIT;  // entries per pass
     __shared__ T s_prod[kBlock / kWave][P + 8];
@@ -173,9 +166,6 @@ k_spmv_colfused(const uint32_t *__restrict__ tile_row, const uint32_t *__restric
     const uint64_t in_xcd = (uint64_t)(blockIdx.x >> 3) * (kBlock / kWave) + wave;
     const uint64_t tile = tile_begin + xcd * q + in_xcd;
     if (tile >= tile_end) return;  // wave-uniform; the kernel has no block-wide barrier
-    const uint64_t first_of_xcd = tile_begin + xcd * q;
-    const uint32_t expected = (uint32_t)(tile_end - first_of_xcd < q ? tile_end - first_of_xcd : q);  // waves of this XCD at work
-    uint32_t *prog = progress + xcd * n_blocks * kCfSlots;
     T *stage = s_prod[wave];
     T acc[RT];
 #pragma unroll
@@ -188,18 +178,6 @@ k_spmv_colfused(const uint32_t *__restrict__ tile_row, const uint32_t *__restric
     const uint32_t *seg_t = seg + tile * n_blocks;
     const uint8_t *cnt_t = cnt + (tile * n_blocks * kWave + lane) * RT;
     for (uint32_t b = 0; b < n_blocks; ++b) {
-        if (lag && b >= lag) {  // all waves of this XCD have left block b - lag?
-            // (16 counters per (XCD, block), one cache line: 512 waves adding to ONE address serialise in the L2 -- measured
-            // ~29 us per block step; lanes 0..15 read one counter each and the wave adds them up)
-            const uint32_t *line = prog + (uint64_t)(b - lag) * kCfSlots;
-            for (uint32_t spins = 0; spins < kCfSpinCap; ++spins) {
-                uint32_t v = lane < kCfSlots ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-                for (int o = kCfSlots / 2; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o, kWave);
-                if ((uint32_t)__shfl((int)v, 0, kWave) >= expected) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
         const uint32_t s0 = seg_t[b], s1 = seg_t[b + 1];  // wave-uniform (scalar loads)
         if (s1 != s0) {
             // this lane's RT counts, its total, and where its entries start (exclusive wave scan of the totals)
@@ -280,8 +258,6 @@ k_spmv_colfused(const uint32_t *__restrict__ tile_row, const uint32_t *__restric
                 ps = pe;
             }
         }
-        if (lag && lane == 0)
-            __hip_atomic_fetch_add(prog + (uint64_t)b * kCfSlots + (in_xcd & (kCfSlots - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint64_t r0 = (uint64_t)row_first + (uint64_t)lane * h, r_end = tile_row[tile + 1];
 #pragma unroll
@@ -382,7 +358,7 @@ int build_colfused(int dtype, const uint32_t *off, const uint32_t *col, const vo
 
 template <typename T, int RT, int NIT>
 static int cf_launch(const uint32_t *tile_row, size_t n_tiles, const uint32_t *seg, const uint8_t *cnt, const uint32_t *col, const T *val,
-                     const T *x, T *y, size_t nnz, uint32_t n_blocks, uint32_t *progress, int device, hipStream_t s) {
+                     const T *x, T *y, size_t nnz, uint32_t n_blocks, int device, hipStream_t s) {
     // a round = the waves the chip holds at once (so that all of them walk the column blocks together)
     static int per_cu_cache[64] = {0};  // per device; (racing threads compute the same value)
     static int cus_cache[64] = {0};
@@ -396,12 +372,7 @@ static int cf_launch(const uint32_t *tile_row, size_t n_tiles, const uint32_t *s
         cus_cache[device & 63] = cus;
     }
     static const int per_cu_env = getenv("SMH_COLFUSED_BLOCKS_PER_CU") ? atoi(getenv("SMH_COLFUSED_BLOCKS_PER_CU")) : 0;  // tuning knob
-    if (per_cu_env >= 1 && per_cu_env <= per_cu) per_cu = per_cu_env;  // (never more than fit: the lock step needs co-residency)
-    // Lock step OFF by default: measured (profiles/r02_k2f_sweep.log) it costs more than it recovers -- a barrier per block
-    // aligns the phases of all waves (everyone streams, then everyone gathers: the two no longer overlap), C2-uniform 2.05
-    // -> 3.75 ms with lag 1, 2.37 ms with lag 3; C3 5.6 -> 10.7 / 5.2 ms.  Kept as a knob for experiments.
-    static const int lag_env = getenv("SMH_COLFUSED_LAG") ? atoi(getenv("SMH_COLFUSED_LAG")) : 0;
-    const uint32_t lag = lag_env < 0 ? 0u : (uint32_t)lag_env;
+    if (per_cu_env >= 1 && per_cu_env <= per_cu) per_cu = per_cu_env;
     const uint64_t wpb = kBlock / kWave;
     uint64_t cap_blocks = ((uint64_t)per_cu * (uint64_t)cus) & ~uint64_t(7);
     if (cap_blocks < 8) cap_blocks = 8;
@@ -414,9 +385,8 @@ static int cf_launch(const uint32_t *tile_row, size_t n_tiles, const uint32_t *s
         blocks = (blocks + 7) & ~uint64_t(7);  // a multiple of 8: every XCD gets the same number of waves
         if (blocks > cap_blocks) blocks = cap_blocks;
         const uint64_t t_end = t + blocks * wpb < n_tiles ? t + blocks * wpb : n_tiles;
-        if (lag) SMH_HIP(hipMemsetAsync(progress, 0, (size_t)8 * n_blocks * kCfSlots * sizeof(uint32_t), s));
         hipLaunchKernelGGL((k_spmv_colfused<T, RT, NIT>), dim3((unsigned)blocks), dim3(kBlock), 0, s, tile_row, seg, cnt, col, val, x, y,
-                           n_blocks, t, t_end, nnz_readable, progress, lag);
+                           n_blocks, t, t_end, nnz_readable);
         SMH_HIP(hipGetLastError());
         t = t_end;
     }
@@ -425,14 +395,14 @@ static int cf_launch(const uint32_t *tile_row, size_t n_tiles, const uint32_t *s
 
 int launch_spmv_colfused(int dtype, uint32_t rt, const uint32_t *tile_row, size_t n_tiles, const uint32_t *seg, const uint8_t *cnt,
                          const uint32_t *col, const void *val, const void *x, void *y, size_t n_rows, size_t nnz, uint32_t n_blocks,
-                         uint32_t *progress, int device, hipStream_t s) {
+                         int device, hipStream_t s) {
     if (n_rows == 0 || n_tiles == 0) return SMH_OK;
     if (dtype == SMH_F64) {
-        if (rt == 16) return cf_launch<double, 16, 2>(tile_row, n_tiles, seg, cnt, col, (const double *)val, (const double *)x, (double *)y, nnz, n_blocks, progress, device, s);
-        if (rt == 8) return cf_launch<double, 8, 2>(tile_row, n_tiles, seg, cnt, col, (const double *)val, (const double *)x, (double *)y, nnz, n_blocks, progress, device, s);
+        if (rt == 16) return cf_launch<double, 16, 2>(tile_row, n_tiles, seg, cnt, col, (const double *)val, (const double *)x, (double *)y, nnz, n_blocks, device, s);
+        if (rt == 8) return cf_launch<double, 8, 2>(tile_row, n_tiles, seg, cnt, col, (const double *)val, (const double *)x, (double *)y, nnz, n_blocks, device, s);
     } else {
-        if (rt == 16) return cf_launch<float, 16, 4>(tile_row, n_tiles, seg, cnt, col, (const float *)val, (const float *)x, (float *)y, nnz, n_blocks, progress, device, s);
-        if (rt == 8) return cf_launch<float, 8, 4>(tile_row, n_tiles, seg, cnt, col, (const float *)val, (const float *)x, (float *)y, nnz, n_blocks, progress, device, s);
+        if (rt == 16) return cf_launch<float, 16, 4>(tile_row, n_tiles, seg, cnt, col, (const float *)val, (const float *)x, (float *)y, nnz, n_blocks, device, s);
+        if (rt == 8) return cf_launch<float, 8, 4>(tile_row, n_tiles, seg, cnt, col, (const float *)val, (const float *)x, (float *)y, nnz, n_blocks, device, s);
     }
     return fail(SMH_ERR_INVALID, "K2f: rows per lane must be 8 or 16 (got %u)", rt);
 }

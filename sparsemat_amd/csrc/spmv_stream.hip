@@ -191,17 +191,22 @@ __device__ __forceinline__ uint32_t decode_col(uint32_t cd, uint32_t b0, uint32_
 // one u32 per tile (where its entries start) instead of the u32 offset_rows stream -- 1 instead of 4 bytes per row from HBM
 // (512^3 Laplacian: 537 -> 136 MB of the 7.2 GB a product moves).  The in-tile prefix sum of the lengths is a wave scan
 // whose cross-wave part rides on the barrier the kernel has anyway.
-template <typename T, bool XWIN, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false, bool L8 = false,
+// (Round 3 tried a bank skew of the staged x -- entry i at i + 4 (i / 128 + i / 1024), so that the neighbours i - N and i + N of a
+// row, which share a bank on grids with N a multiple of 32 and are read by ONE wavefront instruction, stop colliding: 28 % of this
+// kernel's LDS cycles are conflicts.  It measured SLOWER, 1.34-1.36 against 1.29-1.31 ms on the 512^3 Laplacian
+// (profiles/r03_ab_k1s_xs_skew_negative.log): the body is bound by vector-ALU issue, and the three extra instructions per entry
+// cost more than the conflicts they remove.)
+template <typename T, int RPT, bool DOT, bool ACC = false, bool MULTI = true, int CAP = kStreamCap, bool C16 = false, bool L8 = false,
           int XS = 0 /* 16-byte chunks of x per thread staged in LDS: 0 (none), 2 or 4 */>
 __global__ void SMH_STREAM_BOUNDS
 k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const T *__restrict__ val,
               const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t nnz, uint64_t nnz_readable,
-              uint64_t n_tiles, const uint32_t *__restrict__ win, T *__restrict__ dot_partials,
+              uint64_t n_tiles, T *__restrict__ dot_partials,
               const uint16_t *__restrict__ code, const uint32_t *__restrict__ cwin, const uint8_t *__restrict__ len8,
               const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs, uint64_t tile0) {
-    static_assert(!C16 || (RPT == 1 && !XWIN), "the code table describes 256-row tiles");
+    static_assert(!C16 || RPT == 1, "the code table describes 256-row tiles");
     static_assert(!L8 || (C16 && !MULTI), "row lengths as bytes: single-pass 256-row tiles with column codes");
-    static_assert(!XS || (L8 && !XWIN), "x staged in LDS: the coded single-pass body");
+    static_assert(!XS || L8, "x staged in LDS: the coded single-pass body");
     // XS: the tile's column intervals of x (the code table's <= 4 intervals, <= 2048 or 4096 entries in 16-byte chunks) are
     // copied to LDS with 16-byte loads issued BEFORE the tile's chunk loads, and the gathers become LDS reads: two vector-memory
     // instructions per thread instead of eight, and no second, dependent trip to memory.
@@ -209,7 +214,6 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
     __shared__ __attribute__((aligned(16))) T s_xs[kXsCap];
     __shared__ uint32_t s_wtot[L8 ? kBlock / kWave : 1];
     __shared__ T s_prod[CAP + CAP / 32 + 8];
-    __shared__ T s_x[XWIN ? kStreamXWin : 1];
     // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of tiles
     const uint64_t q = n_tiles >> 3, rm = n_tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     // (n_tiles = the tiles of THIS launch, tile0 = the first of them: a launch may cover a run of the matrix's tiles only -- the
@@ -255,29 +259,6 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         for (int rr = 0; rr < RPT; ++rr) {
             const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
             dl[rr] = r < r1 ? dot_lhs[r] : T(0);
-        }
-    }
-    // interval k of the window sits at s_x[b_k ..), b_k = total length of the intervals before it;
-    // a column c of interval k is at s_x[c - sh_k] with sh_k = lo_k - b_k
-    uint32_t lo1 = 0xFFFFFFFFu, lo2 = 0xFFFFFFFFu, lo3 = 0xFFFFFFFFu, sh0 = 0, sh1 = 0, sh2 = 0, sh3 = 0;
-    bool windowed = false;
-    if constexpr (XWIN) {
-        if (k1 - k0 <= (uint32_t)kStreamCap) {  // the inspector describes single-pass tiles only
-            const uint32_t *w = win + 8 * tile;  // tile-uniform: scalar loads
-            const uint32_t a0 = w[0], e0 = w[1], a1 = w[2], e1 = w[3], a2 = w[4], e2 = w[5], a3 = w[6], e3 = w[7];
-            windowed = e0 > a0;
-            if (windowed) {
-                const uint32_t b1 = e0 - a0, b2 = b1 + (e1 - a1), b3 = b2 + (e2 - a2);
-                sh0 = a0;
-                if (e1 > a1) { lo1 = a1; sh1 = a1 - b1; }
-                if (e2 > a2) { lo2 = a2; sh2 = a2 - b2; }
-                if (e3 > a3) { lo3 = a3; sh3 = a3 - b3; }
-                for (uint32_t c = a0 + tid; c < e0; c += kBlock) s_x[c - sh0] = x[c];
-                for (uint32_t c = a1 + tid; c < e1; c += kBlock) s_x[c - sh1] = x[c];
-                for (uint32_t c = a2 + tid; c < e2; c += kBlock) s_x[c - sh2] = x[c];
-                for (uint32_t c = a3 + tid; c < e3; c += kBlock) s_x[c - sh3] = x[c];
-                __syncthreads();
-            }
         }
     }
     // The tile's entries [k0, k1) are taken in passes of <= kStreamCap entries (stencil/FEM tiles: one pass).  Per
@@ -412,11 +393,7 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
                 const uint32_t i = j + e;
                 xv[it][e] = T(0);
                 if (i >= lo && i < hi) {
-                    if (XWIN && windowed) {
-                        const uint32_t cc = c[it][e];
-                        const uint32_t sh = cc >= lo3 ? sh3 : (cc >= lo2 ? sh2 : (cc >= lo1 ? sh1 : sh0));
-                        xv[it][e] = s_x[cc - sh];
-                    } else if constexpr (C16) {
+                    if constexpr (C16) {
                         const uint32_t cd = (e & 1) ? (c[it][e >> 1] >> 16) : (c[it][e >> 1] & 0xFFFFu);
                         if constexpr (XS) xv[it][e] = s_xs[decode_col(cd, sb0, sb1, sb2, sb3)];
                         else xv[it][e] = x[decode_col(cd, cb0, cb1, cb2, cb3)];
@@ -497,11 +474,11 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
 // single_pass: the caller knows that no tile holds more than kStreamCap entries (statistic taken at create time)
 template <typename T>
 static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *val, const T *x, T *y, size_t n_rows,
-                           size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass, T *dot_partials,
+                           size_t nnz, bool padded, int rpt, bool single_pass, T *dot_partials,
                            const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs,
                            hipStream_t s, bool small_tiles, int xs, uint64_t tile_begin, uint64_t tile_end) {
     const uint64_t readable = padded ? ((nnz + 3) & ~uint64_t(3)) : nnz;
-    const uint64_t all_tiles = stream_tiles(n_rows, win ? 1 : rpt);
+    const uint64_t all_tiles = stream_tiles(n_rows, rpt);
     // tiles [tile_begin, tile_end) of the matrix (default: all of them)
     const uint64_t tile0 = tile_begin < all_tiles ? tile_begin : all_tiles, tile1 = tile_end < all_tiles ? tile_end : all_tiles;
     if (tile1 <= tile0) return SMH_OK;
@@ -512,23 +489,22 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
     // one box, 1.54 ms unconstrained, 1.64 / 2.10 / 2.62 / 3.64 ms with 8 / 16 / 24 / 36 KiB of padding
     // (profiles/r01_k1s_blocks_per_cu.log)
     static const unsigned lds_pad = getenv("SMH_STREAM_LDS_PAD") ? (unsigned)atoi(getenv("SMH_STREAM_LDS_PAD")) : 0u;
-#define SMH_ST_LAUNCH(XW, R, D, M, C)                                                                                    \
-    hipLaunchKernelGGL((k_spmv_stream<T, XW, R, D, false, M, kStreamCap, C>), grid, block, lds_pad, s, off, col, val, x, y, \
-                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin,                   \
+#define SMH_ST_LAUNCH(R, D, M, C)                                                                                        \
+    hipLaunchKernelGGL((k_spmv_stream<T, R, D, false, M, kStreamCap, C>), grid, block, lds_pad, s, off, col, val, x, y, \
+                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, dot_partials, code, cwin,                   \
                        (const uint8_t *)nullptr, (const uint32_t *)nullptr, dot_lhs, tile0)
-#define SMH_ST_PICK(XW, R, C)                                                     \
+#define SMH_ST_PICK(R, C)                                                         \
     do {                                                                          \
         if (single_pass) {                                                        \
-            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, false, C); else SMH_ST_LAUNCH(XW, R, false, false, C); \
+            if (dot_partials) SMH_ST_LAUNCH(R, true, false, C); else SMH_ST_LAUNCH(R, false, false, C); \
         } else {                                                                  \
-            if (dot_partials) SMH_ST_LAUNCH(XW, R, true, true, C); else SMH_ST_LAUNCH(XW, R, false, true, C);   \
+            if (dot_partials) SMH_ST_LAUNCH(R, true, true, C); else SMH_ST_LAUNCH(R, false, true, C);   \
         }                                                                         \
     } while (0)
-    if (win) SMH_ST_PICK(true, 1, false);  // the window table describes 256-row tiles
-    else if (rpt == 2) SMH_ST_PICK(false, 2, false);
+    if (rpt == 2) SMH_ST_PICK(2, false);
 #define SMH_ST_XS(D, P)                                                                                                                     \
-    hipLaunchKernelGGL((k_spmv_stream<T, false, 1, D, false, false, kStreamCapSmall, true, true, P>), grid, block, lds_pad, s, off, col, val, x, y, \
-                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0)
+    hipLaunchKernelGGL((k_spmv_stream<T, 1, D, false, false, kStreamCapSmall, true, true, P>), grid, block, lds_pad, s, off, col, val, x, y, \
+                       (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0)
     else if (code && cwin && len8 && tbase && single_pass && small_tiles && xs == 2) {  // ... and x staged in LDS (2048 entries)
         if (dot_partials) SMH_ST_XS(true, 2); else SMH_ST_XS(false, 2);
     }
@@ -542,22 +518,22 @@ static int launch_stream_t(const uint32_t *off, const uint32_t *col, const T *va
         // 1.412 -> 1.330 ms; 512^3 f32 unchanged (1.503 / 1.515 ms) -- neither registers nor instruction count bound the f32
         // kernel: rocprofv3 shows the texture addresser busy 70 % of the time (8 gather instructions per thread and tile)
         if (dot_partials)
-            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
+            hipLaunchKernelGGL((k_spmv_stream<T, 1, true, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
         else
-            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
+            hipLaunchKernelGGL((k_spmv_stream<T, 1, false, false, false, kStreamCapSmall, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
     }
     else if (code && cwin && len8 && tbase && single_pass) {  // column codes + byte row lengths
         if (dot_partials)
-            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, true, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
+            hipLaunchKernelGGL((k_spmv_stream<T, 1, true, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
         else
-            hipLaunchKernelGGL((k_spmv_stream<T, false, 1, false, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
-                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, win, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
+            hipLaunchKernelGGL((k_spmv_stream<T, 1, false, false, false, kStreamCap, true, true>), grid, block, lds_pad, s, off, col, val,
+                               x, y, (uint64_t)n_rows, (uint64_t)nnz, readable, n_tiles, dot_partials, code, cwin, len8, tbase, dot_lhs, tile0);
     }
-    else if (code && cwin) SMH_ST_PICK(false, 1, true);  // 16-bit column codes (every tile described)
-    else SMH_ST_PICK(false, 1, false);
+    else if (code && cwin) SMH_ST_PICK(1, true);  // 16-bit column codes (every tile described)
+    else SMH_ST_PICK(1, false);
 #undef SMH_ST_PICK
 #undef SMH_ST_LAUNCH
     SMH_HIP(hipGetLastError());
@@ -574,8 +550,8 @@ static int launch_stream_block_t(const uint32_t *off, const uint32_t *col, const
     const uint64_t readable = (nnz_total + 3) & ~uint64_t(3);
     const dim3 grid((unsigned)n_tiles), block(kBlock);
 #define SMH_SB_LAUNCH(R, A, M)                                                                                          \
-    hipLaunchKernelGGL((k_spmv_stream<T, false, R, false, A, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
-                       (uint64_t)nnz_total, readable, n_tiles, (const uint32_t *)nullptr, (T *)nullptr,         \
+    hipLaunchKernelGGL((k_spmv_stream<T, R, false, A, M>), grid, block, 0, s, off, col, val, x, y, (uint64_t)n_rows, \
+                       (uint64_t)nnz_total, readable, n_tiles, (T *)nullptr,         \
                        (const uint16_t *)nullptr, (const uint32_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr,  \
                        (const T *)nullptr, (uint64_t)0)
 #define SMH_SB_PICK(R)                                                                      \
@@ -613,16 +589,16 @@ size_t stream_tiles(size_t n_rows, int rpt) {
 }
 
 int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
-                       size_t n_rows, size_t nnz, bool padded, const uint32_t *win, int rpt, bool single_pass,
+                       size_t n_rows, size_t nnz, bool padded, int rpt, bool single_pass,
                        void *dot_partials, const uint16_t *code, const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase,
                        const void *dot_lhs, hipStream_t s, bool small_tiles, int xs, uint64_t tile_begin, uint64_t tile_end) {
     if (n_rows == 0) return SMH_OK;
     if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
     if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
     if (dtype == SMH_F64)
-        return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded, win,
+        return launch_stream_t<double>(off, col, (const double *)val, (const double *)x, (double *)y, n_rows, nnz, padded,
                                        rpt, single_pass, (double *)dot_partials, code, cwin, len8, tbase, (const double *)dot_lhs, s, small_tiles, xs, tile_begin, tile_end);
-    return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, win, rpt,
+    return launch_stream_t<float>(off, col, (const float *)val, (const float *)x, (float *)y, n_rows, nnz, padded, rpt,
                                   single_pass, (float *)dot_partials, code, cwin, len8, tbase, (const float *)dot_lhs, s, small_tiles, xs, tile_begin, tile_end);
 }
 

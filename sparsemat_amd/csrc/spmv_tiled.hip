@@ -40,16 +40,6 @@
 
 namespace smh {
 
-// round 2's kernels (spmv_tiled_v1.hip), kept beside the new ones while both are measured: SMH_TILED_V1=1 selects them
-void tiled_v1_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *R, uint32_t *n_rb);
-int tiled_v1_build(::smh_crs *m);
-void tiled_v1_free(::smh_crs *m);
-int launch_spmv_tiled_v1(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s);
-static bool tiled_use_v1() {
-    static const bool v1 = getenv("SMH_TILED_V1") && atoi(getenv("SMH_TILED_V1")) == 1;
-    return v1;
-}
-
 int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s, uint64_t *total_out);  // spmv_colblock.hip
 
 constexpr uint32_t kT3Slice = 16384;     // columns per slice: 64 KiB (f32) / 128 KiB (f64) of x in LDS
@@ -178,6 +168,7 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
     using V = typename T3<T>::V1;
     using V2 = typename T3<T>::V2;
     constexpr int E = T3<T>::E1, E2 = T3<T>::E2;
+    static_assert(sizeof(V2) == 16, "16 bytes per store");
     constexpr uint32_t CH = 64u * E;
     extern __shared__ __attribute__((aligned(16))) char t3_smem[];
     T *xs = (T *)t3_smem;
@@ -621,7 +612,6 @@ struct T3Scratch {
 // the geometry for rows of equal length and no two entries of a row in one slice (AUTO's estimate; the build cuts the row blocks
 // by the products the rows really have)
 void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *R, uint32_t *n_rb) {
-    if (tiled_use_v1()) return tiled_v1_geometry(n_rows, n_cols, nnz, dtype, n_cb, R, n_rb);
     const uint64_t cb = ((uint64_t)n_cols + kT3Slice - 1) / kT3Slice;
     *n_cb = (uint32_t)(cb ? cb : 1);
     const double per_row_and_slice = n_rows ? (double)nnz / (double)n_rows / (double)*n_cb : 0.0;
@@ -778,7 +768,6 @@ static int build_t(::smh_crs *m) {
 }
 
 void tiled_free(::smh_crs *m) {
-    if (tiled_use_v1()) return tiled_v1_free(m);
     (void)hipFree(m->d_t2_val); (void)hipFree(m->d_t2_prod); (void)hipFree(m->d_t2_code); (void)hipFree(m->d_t2_row);
     (void)hipFree(m->d_t3_cptr); (void)hipFree(m->d_t3_chunk); (void)hipFree(m->d_t2_tstart); (void)hipFree(m->d_t2_rbstart);
     m->d_t2_val = m->d_t2_prod = nullptr;
@@ -790,7 +779,6 @@ void tiled_free(::smh_crs *m) {
 }
 
 int tiled_build(::smh_crs *m) {
-    if (tiled_use_v1()) return tiled_v1_build(m);
     if (m->t2_built) return m->t2_ok ? SMH_OK : fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
     SMH_TRY(columns_within_n_cols(m, "tiled variant"));  // (the slice tables are sized from n_cols)
     m->t2_built = true;
@@ -807,7 +795,6 @@ int tiled_build(::smh_crs *m) {
 
 // the plan's integer structure (and the copy) for inspection: `which` as in include/sparsemat_hip.h (smh_crs_tiled_array)
 int tiled_array(::smh_crs *m, int which, void *out, size_t capacity_bytes, size_t *bytes_out) {
-    if (tiled_use_v1()) return fail(SMH_ERR_INVALID, "smh_crs_tiled_array: not available with SMH_TILED_V1=1");
     const size_t vs = dtype_size(m->dtype), chunk_slots = m->dtype == SMH_F64 ? t3_chunk<double>() : t3_chunk<float>();
     const void *src = nullptr;
     size_t bytes = 0;
@@ -868,7 +855,6 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
 }
 
 int launch_spmv_tiled(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
-    if (tiled_use_v1()) return launch_spmv_tiled_v1(m, x, x_len, y, s);
     if (m->n_rows == 0) return SMH_OK;
     return m->dtype == SMH_F64 ? launch_t<double>(m, x, x_len, y, s) : launch_t<float>(m, x, x_len, y, s);
 }

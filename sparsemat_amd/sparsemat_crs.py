@@ -294,10 +294,6 @@ class SparseMatCRS:
     def set_vector_lanes(self, lanes):
         check(lib().smh_crs_set_vector_lanes(self._h, lanes))
 
-    def set_stream_windows(self, mode):
-        """K1s-w (x intervals of a tile staged in LDS): -1 automatic, 0 off, 1 on."""
-        check(lib().smh_crs_set_stream_windows(self._h, mode))
-
     def set_stream_xs(self, mode):
         """K1s XS (the tile's column intervals of x staged in LDS): -1 automatic, 0 never, 1 whenever the tiles allow."""
         check(lib().smh_crs_set_stream_xs(self._h, mode))
@@ -307,14 +303,6 @@ class SparseMatCRS:
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(lib().smh_crs_stream_layout(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return {"coded": bool(a.value), "byte_lengths": bool(b.value), "small_tiles": bool(c.value), "xs_chunks": d.value}
-
-    def stream_windows(self):
-        """(fraction of tiles with a window, table[n_tiles, 4, 2] of [lo, hi) intervals)."""
-        frac = C.c_double()
-        n_tiles = (self.n_rows() + 255) // 256
-        table = np.zeros((n_tiles, 4, 2), dtype=np.uint32)
-        check(lib().smh_crs_stream_windows(self._h, C.byref(frac), table.ctypes.data if n_tiles else None))
-        return frac.value, table
 
     def set_vector_chunks(self, chunks):
         check(lib().smh_crs_set_vector_chunks(self._h, chunks))

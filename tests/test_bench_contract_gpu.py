@@ -52,7 +52,7 @@ def test_n_gpus_rehearsal_checks_its_exchange(gpu):
     assert x["ok"] is True and x["rows_per_rank"] == 2 * 64 + 2 * 128 and x["max_abs_err"] <= x["tol"]
     # the window exchange ran beside the interior rows' product; the same steps with that switched off are reported next to it
     assert d["ms_per_step_no_overlap"] > 0 and "exchange_hidden_ms" in d and d["step_ms_block0_events"] > 0
-    assert 0 < d["interior_rows_block0"][0] < d["interior_rows_block0"][1] <= 500000
+    assert 0 == d["interior_rows_block0"][0] < d["interior_rows_block0"][1] < 500000  # (block 0: only its last rows are referenced)
     a = d["allgather_leg"]  # configs[4]'s literal exchange, timed beside the headline
     assert a["exchange"] == "allgather" and a["exchange_check"]["ok"] is True and a["ms_per_step"] > 0
     assert a["received_bytes_per_gpu_step"] == 3 * 500000 * 4

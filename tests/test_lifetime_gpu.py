@@ -42,8 +42,6 @@ def _exercise(rng, kind):
     m.set_colblock_shift(12)  # at most 39 column blocks for these sizes
     for variant in ("auto", "vector", "merge", "stream", "colblock", "colfused", "colsplit", "tiled", "seq"):
         m.mvp(x, variant=variant)
-    m.set_stream_windows(1)
-    m.mvp(x, variant="stream")
     m.set_vector_lanes(4)
     m.mvp(x, variant="vector")
     m.inner_prod(np.ones(n, val.dtype), x)

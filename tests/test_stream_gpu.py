@@ -63,45 +63,18 @@ def test_stream_on_laplacians_and_borrowed_unpadded_arrays(gpu):
     assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
 
 
-def check_windows(m, off, col):
-    """Table invariants: intervals sorted, disjoint, <= 3072 entries in total, and they contain every
-    column the tile references; tiles without a description are all-zero."""
-    frac, table = m.stream_windows()
-    n_rows = len(off) - 1
-    n_win = 0
-    for t in range(len(table)):
-        r0, r1 = t * 256, min(n_rows, t * 256 + 256)
-        cols = col[off[r0]:off[r1]]
-        iv = [(int(a), int(b)) for a, b in table[t] if b > a]
-        if not iv:
-            assert not table[t].any()
-            continue
-        n_win += 1
-        assert len(cols) and len(cols) <= 4096
-        assert sum(b - a for a, b in iv) <= 3072
-        assert all(iv[i][1] <= iv[i + 1][0] for i in range(len(iv) - 1)), iv
-        assert table[t][0][1] > table[t][0][0]  # interval 0 is always used
-        inside = np.zeros(len(cols), bool)
-        for a, b in iv:
-            inside |= (cols >= a) & (cols < b)
-        assert inside.all(), (t, iv)
-    assert abs(frac - n_win / max(len(table), 1)) < 1e-12
-    return frac
-
-
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
-def test_stream_windows_table_and_bit_exact(gpu, dtype):
-    # 7-point Laplacian: 3 planes -> 3 intervals per tile
+def test_stream_bit_exact_on_clustered_and_scattered_columns(gpu, dtype):
+    """(Round 1-2 also carried K1s-w, a per-tile LDS window of x filled with 4-byte loads -- measured slower and removed in round 3;
+    what staging x in LDS became is K1s XS, tested below.)"""
+    # 7-point Laplacian: 3 planes -> 3 column intervals per tile
     nx, ny, nz = 40, 36, 9
     off, col, val = oracle.laplace3d(nx, ny, nz, dtype)
     n = nx * ny * nz
     x = oracle.gen_x(synth.SEED_X, n, dtype)
     m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
-    assert check_windows(m, off, col) == 1.0
     y_ref = oracle.spmv(off, col, val, x)
-    for mode in (1, 0, -1):
-        m.set_stream_windows(mode)
-        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), mode
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref))
     # mixed: narrow clusters, 5 clusters (too many intervals -> widest gaps win, may or may not fit), random rows
     rng = np.random.default_rng(21)
     n_rows, n_cols = 4000, 2_000_000
@@ -123,12 +96,8 @@ def test_stream_windows_table_and_bit_exact(gpu, dtype):
     val = rng.uniform(-1, 1, len(col)).astype(dtype)
     x = rng.uniform(-1, 1, n_cols).astype(dtype)
     m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
-    frac = check_windows(m, off, col)
-    assert 0.3 < frac < 0.8
     y_ref = oracle.spmv(off, col, val, x)
-    for mode in (1, 0):
-        m.set_stream_windows(mode)
-        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), mode
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref))
 
 
 def test_stream_edge_shapes(gpu):

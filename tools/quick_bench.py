@@ -87,11 +87,9 @@ def main():
         if not args.only_blocked:
             med, mn = time_variant(m, xptr, nr, ybuf.ptr, "merge")
             report("merge", B, med, mn)
-        for mode, tag in (() if args.only_blocked else ((0, "stream (K1s)"), (1, "stream (K1s-w)"))):
-            m.set_stream_windows(mode)
+        if not args.only_blocked:
             med, mn = time_variant(m, xptr, nr, ybuf.ptr, "stream", reps=8 if case != "lap512" and not case.startswith("lap") else 20)
-            report(tag + " win=%.2f" % m.stream_windows()[0] if mode else tag, B, med, mn)
-        m.set_stream_windows(-1)
+            report("stream (K1s)", B, med, mn)
         for shift in [int(v) for v in args.cb_shifts.split(",") if v]:
             m.set_colblock_shift(shift)
             try:
