@@ -418,6 +418,22 @@ int smh_comm_max_f64(smh_comm *c, double *value_inout);
 int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size_t n_rows,
                    size_t n_cols, const uint32_t *offset_rows, const uint32_t *columns,
                    const void *values, int validate, smh_par **out);
+/* WHERE the rows are cut ("nnz-balanced split points ... as an option for skewed matrices").  SMH_SPLIT_ROWS: the
+ * reference's arithmetic -- R = n_rows / n_blocks rows per block (sparsemat_par.rs:21), the remainder to the last one.
+ * SMH_SPLIT_NNZ: block k starts at the first row whose entries begin at or beyond k nnz / n_blocks (every block keeps at least one
+ * row): equal work per GPU for skewed matrices.  The partition is then a table of n_blocks + 1 row boundaries (smh_par_split);
+ * smh_par_get_block_and_row_id searches it, the window plan and the interior rows follow it, and the all-gather exchange -- whose
+ * in-place ncclAllGather needs equal counts -- becomes one grouped launch of n_blocks ncclBroadcast, each slice from its owner.
+ * smh_par_adopt_split / smh_par_create_rank_split take blocks cut elsewhere: split_rows = the n_blocks + 1 boundaries (NULL: the
+ * reference's partition); row_begin = this rank's first row ((size_t)-1: the reference's partition; all ranks or none). */
+enum { SMH_SPLIT_ROWS = 0, SMH_SPLIT_NNZ = 1 };
+int smh_par_create_split(smh_dtype dtype, size_t n_blocks, const int *device_ids, size_t n_rows,
+                         size_t n_cols, const uint32_t *offset_rows, const uint32_t *columns,
+                         const void *values, int validate, int split_mode, smh_par **out);
+int smh_par_adopt_split(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, const size_t *split_rows, smh_par **out);
+int smh_par_create_rank_split(smh_comm *comm, size_t n_rows, smh_crs *block, size_t row_begin, smh_par **out);
+/* rows_out[k] .. rows_out[k + 1]: the rows of block k (n_blocks + 1 values, whichever way the partition was cut) */
+int smh_par_split(const smh_par *p, size_t *rows_out);
 /* blocks that already live on their devices (device-born inputs): blocks[b] = rows [b R, (b+1) R) of
  * an n_rows-row matrix, all with the same n_cols and dtype.  Borrowed: they must outlive the handle. */
 int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_par **out);
@@ -467,6 +483,10 @@ int smh_par_exchange_mode(const smh_par *p, int mode, int *resolved_out, size_t 
 int smh_par_plan(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo,
                  const uint32_t *hi, size_t block, size_t *recv_begin, size_t *recv_end,
                  size_t *send_begin, size_t *send_end, int *auto_mode_out, size_t *max_recv_out);
+/* ... for a partition given by its n_blocks + 1 row boundaries (NULL: as smh_par_plan) */
+int smh_par_plan_split(size_t n_blocks, size_t n_rows, const size_t *split_rows, const uint8_t *needs, const uint32_t *lo,
+                       const uint32_t *hi, size_t block, size_t *recv_begin, size_t *recv_end,
+                       size_t *send_begin, size_t *send_end, int *auto_mode_out, size_t *max_recv_out);
 
 /* distributed DenseVec: n entries in one device buffer per local block.  upload replicates a host
  * vector into every local buffer; download collects the OWNED slices (n == n_rows) of the local

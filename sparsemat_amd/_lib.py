@@ -119,6 +119,11 @@ SIGNATURES = {
     "smh_comm_barrier": (_int, [_vp]),
     "smh_comm_max_f64": (_int, [_vp, C.POINTER(C.c_double)]),
     "smh_par_create": (_int, [_int, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
+    "smh_par_create_split": (_int, [_int, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _int, _int, C.POINTER(_vp)]),
+    "smh_par_adopt_split": (_int, [_sz, C.POINTER(_vp), _sz, _vp, C.POINTER(_vp)]),
+    "smh_par_create_rank_split": (_int, [_vp, _sz, _vp, _sz, C.POINTER(_vp)]),
+    "smh_par_split": (_int, [_vp, _vp]),
+    "smh_par_plan_split": (_int, [_sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_int), C.POINTER(_sz)]),
     "smh_par_adopt": (_int, [_sz, C.POINTER(_vp), _sz, C.POINTER(_vp)]),
     "smh_par_create_rank": (_int, [_vp, _sz, _vp, C.POINTER(_vp)]),
     "smh_par_n_local_blocks": (_sz, [_vp]),

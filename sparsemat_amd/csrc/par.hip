@@ -151,6 +151,7 @@ struct smh_par {
     // column intervals of ALL blocks: block q references [lo[q], hi[q]] when needs[q]
     std::vector<uint32_t> lo, hi;
     std::vector<uint8_t> needs;
+    std::vector<size_t> split;      // empty: the reference's partition (R rows per block); else n_blocks + 1 row boundaries
     std::vector<uint8_t> peer_ok;   // [dst local * n_local + src local]: dst's device can read src's memory directly
     void *h_red = nullptr;          // PEER backend: 2 x n_blocks fold slots in pinned host memory (all devices map it)
     void *h_sc = nullptr;           // pinned copy of block 0's CG scalars
@@ -186,38 +187,47 @@ int sync_all(smh_par *p) {
     return SMH_OK;
 }
 
-void block_rows(size_t n_blocks, size_t n_rows, size_t k, size_t *r0, size_t *r1) {
-    const size_t rpb = n_rows / n_blocks;  // sparsemat_par.rs:21
+// Which rows a block owns.  split == NULL: the reference's arithmetic -- R = n_rows / n_blocks (sparsemat_par.rs:21), block k owns
+// [k R, (k + 1) R), the last one also the remainder.  split != NULL (n_blocks + 1 ascending rows, split[0] = 0, split[n_blocks] =
+// n_rows): block k owns [split[k], split[k + 1]) -- SURVEY 8e's "nnz-balanced split points ... for skewed matrices".
+struct Part {
+    size_t n_blocks, n_rows;
+    const size_t *split;
+};
+
+void block_rows(const Part &pt, size_t k, size_t *r0, size_t *r1) {
+    if (pt.split) { *r0 = pt.split[k]; *r1 = pt.split[k + 1]; return; }
+    const size_t rpb = pt.n_rows / pt.n_blocks;  // sparsemat_par.rs:21
     *r0 = k * rpb;
-    *r1 = k + 1 == n_blocks ? n_rows : (k + 1) * rpb;  // the last block takes the remainder
+    *r1 = k + 1 == pt.n_blocks ? pt.n_rows : (k + 1) * rpb;  // the last block takes the remainder
 }
 
 // the part of block src's slice that block q's columns reference (empty: *a == *e == 0)
-void recv_range(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, size_t q, size_t src,
-                size_t *a, size_t *e) {
+void recv_range(const Part &pt, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, size_t q, size_t src, size_t *a, size_t *e) {
     *a = *e = 0;
     if (q == src || !needs[q]) return;
     size_t s0, s1;
-    block_rows(n_blocks, n_rows, src, &s0, &s1);
+    block_rows(pt, src, &s0, &s1);
     const size_t x0 = lo[q] > s0 ? lo[q] : s0, x1 = (size_t)hi[q] + 1 < s1 ? (size_t)hi[q] + 1 : s1;
     if (x0 < x1) { *a = x0; *e = x1; }
 }
 
-void plan_summary(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, int *auto_mode,
-                  size_t *max_recv) {
+void plan_summary(const Part &pt, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, int *auto_mode, size_t *max_recv) {
     size_t worst = 0;
-    for (size_t q = 0; q < n_blocks; ++q) {
+    for (size_t q = 0; q < pt.n_blocks; ++q) {
         size_t got = 0;
-        for (size_t src = 0; src < n_blocks; ++src) {
+        for (size_t src = 0; src < pt.n_blocks; ++src) {
             size_t a, e;
-            recv_range(n_blocks, n_rows, needs, lo, hi, q, src, &a, &e);
+            recv_range(pt, needs, lo, hi, q, src, &a, &e);
             got += e - a;
         }
         worst = got > worst ? got : worst;
     }
     if (max_recv) *max_recv = worst;
-    if (auto_mode) *auto_mode = n_blocks <= 1 ? SMH_EXCHANGE_NONE : (worst * 2 < n_rows ? SMH_EXCHANGE_WINDOW : SMH_EXCHANGE_ALLGATHER);
+    if (auto_mode) *auto_mode = pt.n_blocks <= 1 ? SMH_EXCHANGE_NONE : (worst * 2 < pt.n_rows ? SMH_EXCHANGE_WINDOW : SMH_EXCHANGE_ALLGATHER);
 }
+
+Part part_of(const smh_par *p) { return Part{p->n_blocks, p->n_rows, p->split.empty() ? nullptr : p->split.data()}; }
 
 // One block has nobody to exchange with.  SMH_PAR_EXCHANGE_SINGLE=1 (test knob) still sends a lone RANK through the RCCL
 // calls -- an in-place all-gather of one rank, an empty send/receive group, the 1-element gathers of the folds -- so that
@@ -235,7 +245,7 @@ int resolve_mode(const smh_par *p, int mode, int *out) {
     if (mode == SMH_EXCHANGE_AUTO) {
         int m = SMH_EXCHANGE_ALLGATHER;
         // a window is addressed by column AND owned by row: only meaningful when the vector is both (square matrix)
-        if (p->n_rows == p->n_cols) plan_summary(p->n_blocks, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), &m, nullptr);
+        if (p->n_rows == p->n_cols) plan_summary(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), &m, nullptr);
         *out = m;
         return SMH_OK;
     }
@@ -273,6 +283,20 @@ int exchange_rccl(smh_par *p, smh_par_vec *v, int mode, bool side) {
     SMH_TRY(ensure_comms(p));
     const size_t vs = dtype_size(p->dtype), nb = p->n_blocks, R = p->rows_per_block;
     const ncclDataType_t dt = nccl_type(p->dtype);
+    if (mode == SMH_EXCHANGE_ALLGATHER && !p->split.empty()) {
+        // blocks of unequal size (a split table): every slice is broadcast from its owner, all of them in ONE group
+        SMH_NCCL(ncclGroupStart());
+        for (size_t k = 0; k < p->b.size(); ++k) {
+            ParBlock &blk = p->b[k];
+            SMH_TRY(use(blk));
+            for (size_t j = 0; j < nb; ++j) {
+                const size_t a = p->split[j], e = p->split[j + 1];
+                if (e > a) SMH_NCCL(ncclBroadcast((char *)v->d[k] + a * vs, (char *)v->d[k] + a * vs, e - a, dt, (int)j, comm_of(p, blk), xs(blk, side)));
+            }
+        }
+        SMH_NCCL(ncclGroupEnd());
+        return SMH_OK;
+    }
     if (mode == SMH_EXCHANGE_ALLGATHER) {
         // in place: block b's slice already sits at b R of every gathered vector (count R from every rank) ...
         SMH_NCCL(ncclGroupStart());
@@ -307,9 +331,9 @@ int exchange_rccl(smh_par *p, smh_par_vec *v, int mode, bool side) {
         for (size_t q = 0; q < nb; ++q) {
             if (q == blk.index) continue;
             size_t a, e;
-            recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), blk.index, q, &a, &e);  // what I need of q's slice
+            recv_range(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), blk.index, q, &a, &e);  // what I need of q's slice
             if (a < e) SMH_NCCL(ncclRecv(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), xs(blk, side)));
-            recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q, blk.index, &a, &e);  // what q needs of mine
+            recv_range(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), q, blk.index, &a, &e);  // what q needs of mine
             if (a < e) SMH_NCCL(ncclSend(buf + a * vs, e - a, dt, (int)q, comm_of(p, blk), xs(blk, side)));
         }
     }
@@ -348,7 +372,7 @@ int exchange_peer(smh_par *p, smh_par_vec *v, int mode, bool side) {
             ParBlock &src = p->b[si];
             size_t a = src.r0, e = src.r1;
             if (mode == SMH_EXCHANGE_WINDOW)
-                recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q.index, src.index, &a, &e);
+                recv_range(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), q.index, src.index, &a, &e);
             if (a >= e) continue;
             pulled[qi * nl + si] = 1;
             SMH_HIP(hipStreamWaitEvent(xs(q, side), src.ev_slice, 0));
@@ -449,7 +473,7 @@ int find_interiors(smh_par *p) {
         }
         for (size_t q = 0; q < nb; ++q) {  // what block q references of my slice
             size_t a, e;
-            recv_range(nb, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), q, blk.index, &a, &e);
+            recv_range(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), q, blk.index, &a, &e);
             if (a < e)
                 for (size_t t = (a - blk.r0) / kBlock; t <= (e - 1 - blk.r0) / kBlock; ++t) dirty[t] = 1;
         }
@@ -704,9 +728,42 @@ static int par_fail_cleanup(smh_par *p, int rc, int prev_device) {
     return fail(rc, "%s", keep);
 }
 
+// nnz-balanced boundaries: block k starts at the first row whose entries begin at or beyond k nnz / n_blocks (every block keeps at
+// least one row)
+static void split_by_nnz(size_t n_blocks, size_t n_rows, const uint32_t *off, std::vector<size_t> &split) {
+    split.assign(n_blocks + 1, 0);
+    const uint64_t nnz = (uint64_t)off[n_rows] - off[0];
+    for (size_t k = 1; k < n_blocks; ++k) {
+        const uint64_t want = (uint64_t)off[0] + nnz * k / n_blocks;
+        size_t lo = 0, hi = n_rows;  // first row r with off[r] >= want
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (off[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        size_t r = lo;
+        if (r < split[k - 1] + 1) r = split[k - 1] + 1;
+        if (r > n_rows - (n_blocks - k)) r = n_rows - (n_blocks - k);
+        split[k] = r;
+    }
+    split[n_blocks] = n_rows;
+}
+
+static int check_split(size_t n_blocks, size_t n_rows, const size_t *split) {
+    if (split[0] != 0 || split[n_blocks] != n_rows) return fail(SMH_ERR_INVALID, "split table: must run from 0 to n_rows (%zu)", n_rows);
+    for (size_t k = 0; k < n_blocks; ++k)
+        if (split[k + 1] < split[k]) return fail(SMH_ERR_INVALID, "split table: block %zu ends before it begins", k);
+    return SMH_OK;
+}
+
 int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size_t n_rows, size_t n_cols,
                    const uint32_t *offset_rows, const uint32_t *columns, const void *values, int validate, smh_par **out) {
+    return smh_par_create_split(dtype, n_blocks, device_ids, n_rows, n_cols, offset_rows, columns, values, validate, SMH_SPLIT_ROWS, out);
+}
+
+int smh_par_create_split(smh_dtype dtype, size_t n_blocks, const int *device_ids, size_t n_rows, size_t n_cols,
+                         const uint32_t *offset_rows, const uint32_t *columns, const void *values, int validate, int split_mode, smh_par **out) {
     if (!out) return fail(SMH_ERR_INVALID, "NULL out pointer");
+    if (split_mode != SMH_SPLIT_ROWS && split_mode != SMH_SPLIT_NNZ) return fail(SMH_ERR_INVALID, "unknown split mode %d", split_mode);
     if (dtype != SMH_F32 && dtype != SMH_F64) return fail(SMH_ERR_INVALID, "unknown dtype %d", (int)dtype);
     if (n_blocks == 0) return fail(SMH_ERR_INVALID, "SparseMatPar needs at least one block");
     if (!offset_rows) return fail(SMH_ERR_INVALID, "NULL offset_rows");
@@ -722,6 +779,7 @@ int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size
     p->dtype = dtype; p->n_rows = n_rows; p->n_cols = n_cols; p->rows_per_block = rpb; p->n_blocks = n_blocks;
     p->b.resize(n_blocks);
     p->lo.assign(n_blocks, 0); p->hi.assign(n_blocks, 0); p->needs.assign(n_blocks, 0);
+    if (split_mode == SMH_SPLIT_NNZ) split_by_nnz(n_blocks, n_rows, offset_rows, p->split);
     const size_t vs = dtype_size(dtype);
     auto go = [&]() -> int {
         std::vector<uint32_t> off;
@@ -730,7 +788,7 @@ int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size
             blk.index = k;
             blk.device = device_ids ? device_ids[k] : (int)(k % (size_t)n_dev);
             if (blk.device < 0 || blk.device >= n_dev) return fail(SMH_ERR_INVALID, "block %zu: device %d of %d", k, blk.device, n_dev);
-            block_rows(n_blocks, n_rows, k, &blk.r0, &blk.r1);
+            block_rows(part_of(p), k, &blk.r0, &blk.r1);
             SMH_TRY(use(blk));
             const size_t rows = blk.r1 - blk.r0;
             const uint32_t base = offset_rows[blk.r0];
@@ -753,7 +811,12 @@ int smh_par_create(smh_dtype dtype, size_t n_blocks, const int *device_ids, size
 }
 
 int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_par **out) {
+    return smh_par_adopt_split(n_blocks, blocks, n_rows, nullptr, out);
+}
+
+int smh_par_adopt_split(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, const size_t *split_rows, smh_par **out) {
     if (!out || !blocks) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (split_rows && n_blocks) SMH_TRY(check_split(n_blocks, n_rows, split_rows));
     if (n_blocks == 0) return fail(SMH_ERR_INVALID, "SparseMatPar needs at least one block");
     const size_t rpb = n_rows / n_blocks;
     if (rpb == 0) return fail(SMH_ERR_INVALID, "fewer rows (%zu) than blocks (%zu): rows per block would be 0 (sparsemat_par.rs:21,32)", n_rows, n_blocks);
@@ -766,6 +829,7 @@ int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_pa
     p->dtype = blocks[0]->dtype; p->n_rows = n_rows; p->n_cols = blocks[0]->n_cols; p->rows_per_block = rpb; p->n_blocks = n_blocks;
     p->b.resize(n_blocks);
     p->lo.assign(n_blocks, 0); p->hi.assign(n_blocks, 0); p->needs.assign(n_blocks, 0);
+    if (split_rows) p->split.assign(split_rows, split_rows + n_blocks + 1);
     auto go = [&]() -> int {
         for (size_t k = 0; k < n_blocks; ++k) {
             ParBlock &blk = p->b[k];
@@ -773,7 +837,7 @@ int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_pa
             blk.m = blocks[k];
             blk.owns_m = false;
             blk.device = blk.m->device;
-            block_rows(n_blocks, n_rows, k, &blk.r0, &blk.r1);
+            block_rows(part_of(p), k, &blk.r0, &blk.r1);
             if (blk.m->dtype != p->dtype || blk.m->n_cols != p->n_cols)
                 return fail(SMH_ERR_INVALID, "block %zu: dtype / n_cols differ from block 0", k);
             if (blk.m->n_rows != blk.r1 - blk.r0)
@@ -793,7 +857,15 @@ int smh_par_adopt(size_t n_blocks, smh_crs *const *blocks, size_t n_rows, smh_pa
 }
 
 int smh_par_create_rank(smh_comm *comm, size_t n_rows, smh_crs *block, smh_par **out) {
+    return smh_par_create_rank_split(comm, n_rows, block, (size_t)-1, out);
+}
+
+// row_begin == (size_t)-1: the reference's partition (this rank's block must hold rows [rank R, (rank + 1) R), the last rank also
+// the remainder); else this rank's block holds the rows [row_begin, row_begin + its row count) and the ranks' ranges, all-gathered
+// here, must tile [0, n_rows) in rank order (every rank passes a row_begin, or none does)
+int smh_par_create_rank_split(smh_comm *comm, size_t n_rows, smh_crs *block, size_t row_begin, smh_par **out) {
     if (!out || !comm || !block) return fail(SMH_ERR_INVALID, "NULL argument");
+    const bool own_split = row_begin != (size_t)-1;
     const size_t n_blocks = (size_t)comm->n_ranks, k = (size_t)comm->rank;
     const size_t rpb = n_rows / n_blocks;
     if (rpb == 0) return fail(SMH_ERR_INVALID, "fewer rows (%zu) than blocks (%zu): rows per block would be 0 (sparsemat_par.rs:21,32)", n_rows, n_blocks);
@@ -812,29 +884,40 @@ int smh_par_create_rank(smh_comm *comm, size_t n_rows, smh_crs *block, smh_par *
         blk.m = block;
         blk.owns_m = false;
         blk.device = block->device;
-        block_rows(n_blocks, n_rows, k, &blk.r0, &blk.r1);
-        if (block->n_rows != blk.r1 - blk.r0)
+        if (own_split) { blk.r0 = row_begin; blk.r1 = row_begin + block->n_rows; }
+        else block_rows(part_of(p), k, &blk.r0, &blk.r1);
+        if (block->n_rows != blk.r1 - blk.r0 || blk.r1 > n_rows)
             return fail(SMH_ERR_DIM_MISMATCH, "rank %zu holds %zu rows, the partition of %zu rows into %zu blocks gives it %zu", k, block->n_rows,
                         n_rows, n_blocks, blk.r1 - blk.r0);
         SMH_TRY(use(blk));
         SMH_TRY(own_interval(blk, p->n_cols, &p->needs[k], &p->lo[k], &p->hi[k]));
         SMH_TRY(finish_par(p));
-        // the ranks publish their column intervals (the exchange plan is global): 3 u32 per rank, all-gathered in place
-        std::vector<uint32_t> table(3 * n_blocks, 0);
-        table[3 * k] = p->needs[k]; table[3 * k + 1] = p->lo[k]; table[3 * k + 2] = p->hi[k];
+        // the ranks publish their column intervals and row ranges (the exchange plan is global): 6 u32 per rank, all-gathered in place
+        constexpr size_t W = 6;  // needs, lo, hi, row_begin (low, high word), has its own split
+        std::vector<uint32_t> table(W * n_blocks, 0);
+        table[W * k] = p->needs[k]; table[W * k + 1] = p->lo[k]; table[W * k + 2] = p->hi[k];
+        table[W * k + 3] = (uint32_t)blk.r0; table[W * k + 4] = (uint32_t)((uint64_t)blk.r0 >> 32); table[W * k + 5] = own_split;
         uint32_t *d_table = nullptr;
-        SMH_HIP(hipMalloc((void **)&d_table, 3 * n_blocks * sizeof(uint32_t)));
+        SMH_HIP(hipMalloc((void **)&d_table, W * n_blocks * sizeof(uint32_t)));
         auto gather = [&]() -> int {
-            SMH_HIP(hipMemcpyAsync(d_table, table.data(), 3 * n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, blk.s));
-            SMH_NCCL(ncclAllGather(d_table + 3 * k, d_table, 3, ncclUint32, comm->comm, blk.s));
-            SMH_HIP(hipMemcpyAsync(table.data(), d_table, 3 * n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, blk.s));
+            SMH_HIP(hipMemcpyAsync(d_table, table.data(), W * n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, blk.s));
+            SMH_NCCL(ncclAllGather(d_table + W * k, d_table, W, ncclUint32, comm->comm, blk.s));
+            SMH_HIP(hipMemcpyAsync(table.data(), d_table, W * n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, blk.s));
             SMH_HIP(hipStreamSynchronize(blk.s));
             return SMH_OK;
         };
         const int grc = gather();
         (void)hipFree(d_table);
         SMH_TRY(grc);
-        for (size_t q = 0; q < n_blocks; ++q) { p->needs[q] = (uint8_t)table[3 * q]; p->lo[q] = table[3 * q + 1]; p->hi[q] = table[3 * q + 2]; }
+        for (size_t q = 0; q < n_blocks; ++q) { p->needs[q] = (uint8_t)table[W * q]; p->lo[q] = table[W * q + 1]; p->hi[q] = table[W * q + 2]; }
+        for (size_t q = 0; q < n_blocks; ++q)
+            if ((table[W * q + 5] != 0) != own_split) return fail(SMH_ERR_INVALID, "rank %zu passes a row_begin, rank %zu does not (all or none)", own_split ? k : q, own_split ? q : k);
+        if (own_split) {
+            p->split.assign(n_blocks + 1, n_rows);
+            for (size_t q = 0; q < n_blocks; ++q) p->split[q] = (size_t)((uint64_t)table[W * q + 3] | (uint64_t)table[W * q + 4] << 32);
+            SMH_TRY(check_split(n_blocks, n_rows, p->split.data()));
+            if (p->split[k + 1] != blk.r1) return fail(SMH_ERR_INVALID, "rank %zu: its rows end at %zu, rank %zu begins at %zu", k, blk.r1, k + 1, p->split[k + 1]);
+        }
         return find_interiors(p);
     };
     const int rc = go();
@@ -906,10 +989,32 @@ int smh_par_block_stream(const smh_par *p, size_t block, void **stream_out) {
 
 int smh_par_get_block_and_row_id(const smh_par *p, size_t row, size_t *block_out, size_t *row_out) {
     if (!p || !block_out || !row_out) return fail(SMH_ERR_INVALID, "NULL argument");
+    if (!p->split.empty()) {  // a split table: the last block whose first row is <= row
+        size_t lo = 0, hi = p->n_blocks;
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) / 2;
+            if (p->split[mid] <= row) lo = mid; else hi = mid;
+        }
+        *block_out = lo;
+        *row_out = row - p->split[lo];
+        return SMH_OK;
+    }
     size_t k = row / p->rows_per_block;  // sparsemat_par.rs:32, clamped to the last block instead of one past it
     if (k > p->n_blocks - 1) k = p->n_blocks - 1;
     *block_out = k;
     *row_out = row - k * p->rows_per_block;
+    return SMH_OK;
+}
+
+int smh_par_split(const smh_par *p, size_t *rows_out) {
+    if (!p || !rows_out) return fail(SMH_ERR_INVALID, "NULL argument");
+    const Part pt = part_of(p);
+    for (size_t k = 0; k < p->n_blocks; ++k) {
+        size_t r0, r1;
+        block_rows(pt, k, &r0, &r1);
+        rows_out[k] = r0;
+        rows_out[k + 1] = r1;
+    }
     return SMH_OK;
 }
 
@@ -951,24 +1056,32 @@ int smh_par_exchange_mode(const smh_par *p, int mode, int *resolved_out, size_t 
     int m = SMH_EXCHANGE_NONE;
     SMH_TRY(resolve_mode(p, mode, &m));
     if (resolved_out) *resolved_out = m;
-    if (max_recv_out) plan_summary(p->n_blocks, p->n_rows, p->needs.data(), p->lo.data(), p->hi.data(), nullptr, max_recv_out);
+    if (max_recv_out) plan_summary(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), nullptr, max_recv_out);
     return SMH_OK;
 }
 
 int smh_par_plan(size_t n_blocks, size_t n_rows, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi, size_t block,
                  size_t *recv_begin, size_t *recv_end, size_t *send_begin, size_t *send_end, int *auto_mode_out, size_t *max_recv_out) {
-    if (n_blocks == 0 || n_rows / n_blocks == 0) return fail(SMH_ERR_INVALID, "rows per block would be 0 (sparsemat_par.rs:21,32)");
+    return smh_par_plan_split(n_blocks, n_rows, nullptr, needs, lo, hi, block, recv_begin, recv_end, send_begin, send_end, auto_mode_out, max_recv_out);
+}
+
+int smh_par_plan_split(size_t n_blocks, size_t n_rows, const size_t *split_rows, const uint8_t *needs, const uint32_t *lo, const uint32_t *hi,
+                       size_t block, size_t *recv_begin, size_t *recv_end, size_t *send_begin, size_t *send_end, int *auto_mode_out,
+                       size_t *max_recv_out) {
+    if (n_blocks == 0 || (!split_rows && n_rows / n_blocks == 0)) return fail(SMH_ERR_INVALID, "rows per block would be 0 (sparsemat_par.rs:21,32)");
     if (!needs || !lo || !hi || block >= n_blocks) return fail(SMH_ERR_INVALID, "bad plan arguments");
+    if (split_rows) SMH_TRY(check_split(n_blocks, n_rows, split_rows));
+    const Part pt{n_blocks, n_rows, split_rows};
     for (size_t q = 0; q < n_blocks; ++q) {
         size_t a, e;
-        recv_range(n_blocks, n_rows, needs, lo, hi, block, q, &a, &e);
+        recv_range(pt, needs, lo, hi, block, q, &a, &e);
         if (recv_begin) recv_begin[q] = a;
         if (recv_end) recv_end[q] = e;
-        recv_range(n_blocks, n_rows, needs, lo, hi, q, block, &a, &e);
+        recv_range(pt, needs, lo, hi, q, block, &a, &e);
         if (send_begin) send_begin[q] = a;
         if (send_end) send_end[q] = e;
     }
-    plan_summary(n_blocks, n_rows, needs, lo, hi, auto_mode_out, max_recv_out);
+    plan_summary(pt, needs, lo, hi, auto_mode_out, max_recv_out);
     return SMH_OK;
 }
 

@@ -110,9 +110,10 @@ class SparseMatParLocal:
         self._keep = keep  # adopted blocks / communicator must outlive the handle
 
     @classmethod
-    def with_sub_matrices(cls, n_blocks, n_rows, n_cols, offset_rows, columns, values, device_ids=None, validate=True):
+    def with_sub_matrices(cls, n_blocks, n_rows, n_cols, offset_rows, columns, values, device_ids=None, validate=True, split="rows"):
         """``SparseMatPar::with_sub_matrices(n_blocks, max_n_rows)`` (sparsemat_par.rs:20-28) filled from a global CRS:
-        block b = rows [b R, (b+1) R), R = n_rows // n_blocks, the last block taking the remainder."""
+        block b = rows [b R, (b+1) R), R = n_rows // n_blocks, the last block taking the remainder (``split="rows"``); or blocks of
+        equal entry counts (``split="nnz"``, ``smh_par_create_split``: SURVEY 8e's option for skewed matrices)."""
         values = np.ascontiguousarray(values)
         if values.dtype not in (np.float32, np.float64):
             raise TypeError("the HIP path handles f32/f64 values only (got %s)" % values.dtype)
@@ -124,25 +125,35 @@ class SparseMatParLocal:
         if device_ids is not None:
             dev = (C.c_int * n_blocks)(*[int(d) for d in device_ids])
         h = C.c_void_p()
-        check(lib().smh_par_create(_lib.dtype_code(values.dtype), n_blocks, dev, n_rows, n_cols, off.ctypes.data,
-                                   col.ctypes.data if len(col) else None, values.ctypes.data if len(values) else None,
-                                   1 if validate else 0, C.byref(h)))
+        check(lib().smh_par_create_split(_lib.dtype_code(values.dtype), n_blocks, dev, n_rows, n_cols, off.ctypes.data,
+                                         col.ctypes.data if len(col) else None, values.ctypes.data if len(values) else None,
+                                         1 if validate else 0, {"rows": 0, "nnz": 1}[split], C.byref(h)))
         return cls(h, values.dtype)
 
     @classmethod
-    def adopt(cls, blocks, n_rows):
-        """Blocks (``SparseMatCRS``) that already live on their devices: block b = rows [b R, (b+1) R)."""
+    def adopt(cls, blocks, n_rows, split_rows=None):
+        """Blocks (``SparseMatCRS``) that already live on their devices: block b = rows [b R, (b+1) R), or -- ``split_rows``, the
+        n_blocks + 1 row boundaries -- rows [split_rows[b], split_rows[b + 1])."""
         arr = (C.c_void_p * len(blocks))(*[b._h for b in blocks])
         h = C.c_void_p()
-        check(lib().smh_par_adopt(len(blocks), arr, int(n_rows), C.byref(h)))
+        table = None if split_rows is None else np.ascontiguousarray(split_rows, dtype=np.uintp)
+        check(lib().smh_par_adopt_split(len(blocks), arr, int(n_rows), None if table is None else table.ctypes.data, C.byref(h)))
         return cls(h, blocks[0].dtype, keep=list(blocks))
 
     @classmethod
-    def for_rank(cls, comm, n_rows, block):
-        """One process per GPU: this rank's block; n_blocks = comm size, block id = comm rank.  Collective."""
+    def for_rank(cls, comm, n_rows, block, row_begin=None):
+        """One process per GPU: this rank's block; n_blocks = comm size, block id = comm rank.  Collective.  ``row_begin``: the
+        rank's first row when the blocks were not cut by the reference's arithmetic (all ranks pass one, or none does)."""
         h = C.c_void_p()
-        check(lib().smh_par_create_rank(comm._h, int(n_rows), block._h, C.byref(h)))
+        check(lib().smh_par_create_rank_split(comm._h, int(n_rows), block._h, C.c_size_t(-1).value if row_begin is None else int(row_begin),
+                                              C.byref(h)))
         return cls(h, block.dtype, keep=[comm, block])
+
+    def split(self):
+        """The n_blocks + 1 row boundaries of the partition (``smh_par_split``)."""
+        out = np.zeros(self.n_blocks() + 1, dtype=np.uintp)
+        check(lib().smh_par_split(self._h, out.ctypes.data))
+        return [int(v) for v in out]
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -255,17 +266,18 @@ class SparseMatParLocal:
         return iters.value, rr.value
 
 
-def plan(n_blocks, n_rows, needs, lo, hi, block):
-    """``smh_par_plan``: the window-exchange plan of one block (pure host arithmetic in the library; no device).
+def plan(n_blocks, n_rows, needs, lo, hi, block, split_rows=None):
+    """``smh_par_plan[_split]``: the window-exchange plan of one block (pure host arithmetic in the library; no device).
     Returns (recv, send, auto_mode, max_recv): recv[q] / send[q] = (begin, end) global ranges."""
     needs = np.ascontiguousarray(needs, dtype=np.uint8)
     lo = np.ascontiguousarray(lo, dtype=np.uint32)
     hi = np.ascontiguousarray(hi, dtype=np.uint32)
     arrs = [np.zeros(n_blocks, dtype=np.uintp) for _ in range(4)]
     mode, worst = C.c_int(), C.c_size_t()
-    check(lib().smh_par_plan(n_blocks, n_rows, needs.ctypes.data, lo.ctypes.data, hi.ctypes.data, block,
-                             arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
-                             C.byref(mode), C.byref(worst)))
+    table = None if split_rows is None else np.ascontiguousarray(split_rows, dtype=np.uintp)
+    check(lib().smh_par_plan_split(n_blocks, n_rows, None if table is None else table.ctypes.data, needs.ctypes.data, lo.ctypes.data,
+                                   hi.ctypes.data, block, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                   C.byref(mode), C.byref(worst)))
     recv = [(int(a), int(b)) for a, b in zip(arrs[0], arrs[1])]
     send = [(int(a), int(b)) for a, b in zip(arrs[2], arrs[3])]
     return recv, send, _lib.EXCHANGE_NAMES[mode.value], worst.value

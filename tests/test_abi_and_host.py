@@ -261,6 +261,40 @@ def test_library_plan_matches_the_python_plan():
         sparsemat_par_local.plan(5, 4, [1] * 5, [0] * 5, [3] * 5, 0)
 
 
+def test_library_plan_with_a_split_table():
+    """smh_par_plan_split (pure host code): the window plan of a partition cut at arbitrary row boundaries -- SURVEY 8e's nnz-balanced
+    option -- against a direct restatement: block b receives of block q's rows [split[q], split[q+1]) what its columns [lo, hi]
+    reference, and sends what q's reference of its own; with the reference's boundaries it equals smh_par_plan."""
+    from sparsemat_amd import sparsemat_par_local
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        n_blocks = int(rng.integers(1, 9))
+        n_rows = int(rng.integers(n_blocks, 500))
+        cut = [0] + sorted(int(v) for v in rng.integers(0, n_rows + 1, n_blocks - 1)) + [n_rows]  # empty blocks allowed
+        needs = rng.integers(0, 4, n_blocks) > 0
+        lo = rng.integers(0, n_rows, n_blocks)
+        hi = np.minimum(n_rows - 1, lo + rng.integers(0, n_rows, n_blocks))
+        worst = 0
+        for b in range(n_blocks):
+            recv, send, mode, max_recv = sparsemat_par_local.plan(n_blocks, n_rows, needs, lo, hi, b, split_rows=cut)
+            got = 0
+            for q in range(n_blocks):
+                a, e = max(int(lo[b]), cut[q]), min(int(hi[b]) + 1, cut[q + 1])
+                want = (a, e) if (needs[b] and q != b and a < e) else (0, 0)
+                assert recv[q] == want, (cut, b, q)
+                got += want[1] - want[0]
+                assert send[q] == sparsemat_par_local.plan(n_blocks, n_rows, needs, lo, hi, q, split_rows=cut)[0][b]
+            worst = max(worst, got)
+        assert max_recv == max(worst, max(sum(e - a for a, e in sparsemat_par_local.plan(n_blocks, n_rows, needs, lo, hi, q, split_rows=cut)[0])
+                                            for q in range(n_blocks)))
+        r = n_rows // n_blocks
+        ref_cut = [k * r for k in range(n_blocks)] + [n_rows]
+        for b in range(n_blocks):
+            assert sparsemat_par_local.plan(n_blocks, n_rows, needs, lo, hi, b, split_rows=ref_cut) == sparsemat_par_local.plan(n_blocks, n_rows, needs, lo, hi, b)
+    with pytest.raises(sm.SparseMatPanic):
+        sparsemat_par_local.plan(3, 10, [1] * 3, [0] * 3, [9] * 3, 0, split_rows=[0, 5, 4, 10])  # a block ending before it begins
+
+
 def test_exchange_plan_arithmetic():
     n_blocks, n_rows = 4, 103  # R = 25, last block 28 rows
     needs = [(0, 30), (20, 55), (45, 80), (70, 103)]

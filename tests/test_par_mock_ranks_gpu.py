@@ -124,6 +124,35 @@ for dtype, tol in ((np.float64, 1e-10), (np.float32, 1e-4)):
     assert np.max(np.abs(got[r0:r1].astype(np.float64) - o_x[r0:r1])) < 10 * tol
     all_iters = comm.max(float(iters))
     assert all_iters == iters   # every rank took the same decision
+# 6. SURVEY 8e's option for skewed matrices: blocks of equal ENTRY counts (power-law row lengths; every rank passes its first row),
+#    the plan, the exchanges (the all-gather becomes a group of broadcasts: unequal slices) and the solver's folds follow the split table
+n = 40_000
+lens = np.minimum(2000, ((rng.pareto(1.2, n) + 1) * (1 + 12 * (np.arange(n) / n) ** 3)).astype(np.int64))  # long rows crowd the end
+off = np.zeros(n + 1, np.uint32); np.cumsum(lens, out=off[1:])
+band = rng.integers(-600, 601, int(off[-1]))
+col = np.clip(np.repeat(np.arange(n), lens) + band, 0, n - 1).astype(np.uint32)
+val = rng.uniform(-1, 1, len(col)).astype(np.float64)
+nnz = int(off[-1])
+cut = [0] + [int(np.searchsorted(off, nnz * k // world, side="left")) for k in range(1, world)] + [n]
+r0, r1 = cut[rank], cut[rank + 1]
+o = off[r0:r1 + 1].astype(np.int64)
+blk = sm.SparseMatCRS.from_raw_parts(r1 - r0, n, (o - o[0]).astype(np.uint32), col[o[0]:o[-1]], val[o[0]:o[-1]])
+par = sm.SparseMatParLocal.for_rank(comm, n, blk, row_begin=r0)
+assert par.split() == cut and par.get_block_and_row_id(r0) == (rank, 0)
+assert max(cut[k + 1] - cut[k] for k in range(world)) > 1.2 * min(cut[k + 1] - cut[k] for k in range(world))  # rows differ, entries do not
+x_host = oracle.gen_x(synth.SEED_X, n, np.float64)
+y_ref = oracle.spmv(off, col, val, x_host)
+x, y = par.vec(host=x_host), par.vec()
+for exch in ("auto", "window", "allgather"):
+    par.mvp_dev(x, y, "stream", exch)
+    par.synchronize()
+    got = y.download_block(0)
+    assert got[r0:r1].tobytes() == y_ref[r0:r1].tobytes(), ("nnz split", exch)
+    if exch == "allgather":
+        assert got.tobytes() == y_ref.tobytes()
+    else:
+        lo, hi = blk.col_range()
+        assert got[lo:hi + 1].tobytes() == y_ref[lo:hi + 1].tobytes(), ("nnz split window", exch)
 comm.barrier()
 print("RANK %%d OK" %% rank)
 """
