@@ -12,4 +12,5 @@ for f in glob.glob("gpurun_out/t3_trace/**/*kernel_stats.csv", recursive=True):
         if "k_t3_expand" in r["Name"] or "k_t3_reduce" in r["Name"] or "k_t2_" in r["Name"]:
             print("%-50s calls %s avg %.1f us min %.1f max %.1f" % (r["Name"][:50], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
+find gpurun_out/t3_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/tiled_kernel_stats.csv \;
 rm -rf gpurun_out/t3_trace

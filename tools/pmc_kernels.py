@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--launches", type=int, default=3)
-    ap.add_argument("--match", default="", help="only kernels whose name contains this")
+    ap.add_argument("--match", default="", help="only kernels whose name contains one of these (comma separated)")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -108,7 +108,7 @@ def main():
     print("calibration on %s: FETCH_SIZE x %.4f, WRITE_SIZE x %.4f bytes per counted KiB/1024 (guide: 2.0 / 1.0)" % (cal[0][:40], f_fetch, f_write))
     tot = 0.0
     for name, d in sorted(per.items()):
-        if "k_ew" in name or (args.match and args.match not in name):
+        if "k_ew" in name or (args.match and not any(m in name for m in args.match.split(","))):
             continue
         fs, ws = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
         if not fs or not ws:
