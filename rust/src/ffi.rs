@@ -18,6 +18,8 @@ pub const SMH_EXCHANGE_ALLGATHER: c_int = 1;
 pub const SMH_EXCHANGE_WINDOW: c_int = 2;
 pub const SMH_EXCHANGE_AUTO: c_int = 3;
 pub const SMH_COMM_ID_BYTES: usize = 128;
+pub const SMH_SPLIT_ROWS: c_int = 0;  // the reference's partition: R = n_rows / n_blocks rows per block (sparsemat_par.rs:21)
+pub const SMH_SPLIT_NNZ: c_int = 1;   // opt-in: blocks of equal entry counts
 
 extern "C" {
     pub fn smh_abi_version() -> c_int;
@@ -61,6 +63,14 @@ extern "C" {
     pub fn smh_par_create(dtype: c_int, n_blocks: usize, device_ids: *const c_int, n_rows: usize, n_cols: usize,
                           offset_rows: *const u32, columns: *const u32, values: *const c_void, validate: c_int,
                           out: *mut *mut smh_par) -> c_int;
+    // the same with the rows cut by entry count (SMH_SPLIT_NNZ): the partition becomes a table of n_blocks + 1 row boundaries
+    pub fn smh_par_create_split(dtype: c_int, n_blocks: usize, device_ids: *const c_int, n_rows: usize, n_cols: usize,
+                                offset_rows: *const u32, columns: *const u32, values: *const c_void, validate: c_int,
+                                split_mode: c_int, out: *mut *mut smh_par) -> c_int;
+    pub fn smh_par_split(p: *const smh_par, rows_out: *mut usize) -> c_int;
+    // exchange overlapped with the product of the rows that reference no other block (default on; bit-identical either way)
+    pub fn smh_par_set_overlap(p: *mut smh_par, on: c_int) -> c_int;
+    pub fn smh_par_interior(p: *const smh_par, local_block: usize, variant: c_int, row_begin: *mut usize, row_end: *mut usize) -> c_int;
     pub fn smh_par_destroy(p: *mut smh_par) -> c_int;
     pub fn smh_par_spmv(p: *mut smh_par, x_host: *const c_void, x_len: usize, y_host: *mut c_void, variant: c_int) -> c_int;
     pub fn smh_par_cg_solve(p: *mut smh_par, b_host: *const c_void, b_len: usize, x_host_inout: *mut c_void, x_len: usize,
@@ -82,6 +92,8 @@ extern "C" {
     pub fn smh_comm_create(id: *const c_void, n_ranks: c_int, rank: c_int, out: *mut *mut smh_comm) -> c_int;
     pub fn smh_comm_destroy(c: *mut smh_comm) -> c_int;
     pub fn smh_par_create_rank(comm: *mut smh_comm, n_rows: usize, block: *mut smh_crs, out: *mut *mut smh_par) -> c_int;
+    // row_begin = this rank's first row (usize::MAX: the reference's partition; all ranks or none)
+    pub fn smh_par_create_rank_split(comm: *mut smh_comm, n_rows: usize, block: *mut smh_crs, row_begin: usize, out: *mut *mut smh_par) -> c_int;
     pub fn smh_crs_n_rows(m: *const smh_crs) -> usize;
     pub fn smh_crs_n_cols(m: *const smh_crs) -> usize;
     pub fn smh_crs_nnz(m: *const smh_crs) -> usize;

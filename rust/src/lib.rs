@@ -193,6 +193,21 @@ impl DevicePar {
         DevicePar { handle, n_rows }
     }
 
+    /// Not in the reference: the same matrix cut into blocks of equal ENTRY counts (for skewed matrices; block lookup, exchanges
+    /// and the solver follow the table of row boundaries `split()` returns).
+    pub fn new_nnz_balanced<T: HipValue>(n_blocks: usize, devices: Option<&[i32]>, n_rows: usize, n_cols: usize, offset_rows: &[u32],
+                                         columns: &[u32], values: &[T]) -> Self {
+        assert_eq!(offset_rows.len(), n_rows + 1);
+        if let Some(d) = devices { assert_eq!(d.len(), n_blocks); }
+        let mut handle = std::ptr::null_mut();
+        check(unsafe {
+            ffi::smh_par_create_split(T::DTYPE, n_blocks, devices.map_or(std::ptr::null(), |d| d.as_ptr()), n_rows, n_cols,
+                                      offset_rows.as_ptr(), columns.as_ptr(), values.as_ptr() as *const c_void, 1,
+                                      ffi::SMH_SPLIT_NNZ, &mut handle)
+        });
+        DevicePar { handle, n_rows }
+    }
+
     /// `SparseMatrix::mvp` through `iter_row` (src/sparsemat_par.rs:86-89): all blocks run concurrently.
     pub fn mvp<T: HipValue + Default>(&self, x: &[T]) -> Vec<T> {
         let mut y = vec![T::default(); self.n_rows];

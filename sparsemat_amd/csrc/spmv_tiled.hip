@@ -10,15 +10,15 @@
 // and an L2 round trip -- 150-190 G gathers/s however the work is arranged ("gather wall").  Here no gather
 // leaves the CU:
 //   pass 1 "expand":  the entries are stored by column slice (16384 columns), inside a slice by (row, storage order), cut into
-//                     CHUNKS of at most 64 E entries (E = 16 bytes of values: 4 f32 / 2 f64) that one wavefront takes at a time, E
-//                     consecutive entries per lane.  A workgroup stages its slice of x in LDS, multiplies (16-bit column codes),
+//                     CHUNKS of at most 256 entries that one wavefront takes at a time, E = 4 consecutive entries per lane (one
+//                     16-byte load of f32 values, two of f64).  A workgroup stages its slice of x in LDS, multiplies (16-bit column codes),
 //                     and FOLDS the entries of a chunk that belong to one row (adjacent after the sort) with a segmented scan over
 //                     the wavefront; the sums -- one per (row, slice, chunk) -- leave compacted, 16 bytes per lane.  Chunks start
 //                     at row boundaries (the build snaps every chunk start forward to the next one, up to 16 entries), so a
 //                     (row, slice) pair almost always yields ONE product whatever the row's length.
 //   pass 2 "reduce":  inside a slice the products are ordered by row, so those of a block of consecutive rows are one contiguous
 //                     TILE per slice.  The row blocks are cut (host, once) so that each holds the same number of PRODUCTS.  One
-//                     wavefront per row block walks its tiles slice by slice, E products per lane (16-byte loads), and adds them
+//                     wavefront per row block walks its tiles slice by slice, 16 bytes of products per lane (4 f32 / 2 f64), and adds them
 //                     into wave-private sums in LDS; the rows of a tile are distinct (checked per tile with one ballot; else a
 //                     segmented scan merges equal neighbours first), so the adds of a tile are independent: no atomics, no
 //                     barriers, a fixed order -- bitwise reproducible.  The loads of the next tiles are in flight meanwhile.
@@ -56,14 +56,14 @@ template <> struct T3<float> {
     typedef float V1 __attribute__((ext_vector_type(4)));
     typedef float V2 __attribute__((ext_vector_type(4)));
     typedef uint32_t C2 __attribute__((ext_vector_type(2))); // 4 x u16
-    static constexpr uint32_t kCapRows = 3328;               // rows of a row block: 4 x 3329 sums = 52 KiB -> three workgroups per CU
+    static constexpr uint32_t kCapRows = 3328;               // most rows of a row block: 3329 sums = 13 KiB of LDS per (one-wavefront) workgroup; measured, profiles/r03_k2t_rewrite_sweep1.log
 };
 template <> struct T3<double> {
     static constexpr int E1 = 4, E2 = 2;                     // (pass 1: two 16-byte loads of values per lane; pass 2: one)
     typedef double V1 __attribute__((ext_vector_type(4)));
     typedef double V2 __attribute__((ext_vector_type(2)));
     typedef uint32_t C2;                                     // 2 x u16
-    static constexpr uint32_t kCapRows = 1664;               // 4 x 1665 x 8 B = 52 KiB
+    static constexpr uint32_t kCapRows = 1664;               // 1665 x 8 B = 13 KiB
 };
 typedef uint32_t T3C1 __attribute__((ext_vector_type(2)));   // pass 1: the 4 codes of a lane
 typedef uint32_t t3_u4 __attribute__((ext_vector_type(4)));
