@@ -198,6 +198,13 @@ int smh_crs_set_vector_lanes(smh_crs *m, int lanes);
  * and page -- that holds x's last entry; those values are never used).  Same bits as K1s in every form. */
 int smh_crs_set_stream_xs(smh_crs *m, int mode);
 int smh_crs_stream_layout(smh_crs *m, int *coded_out, int *byte_lengths_out, int *small_tiles_out, int *xs_chunks_out);
+/* K1s XD: the XS kernel with its per-entry address arithmetic moved into the build -- the 16-bit code array holds the byte offset
+ * of x[col] inside the tile's LDS stage instead of (interval, offset), the products are staged unskewed, 16 bytes per store.  Same
+ * bits again.  The unskewed stage collides on rows of even length, hence mode -1 = automatic (when x is staged and most rows have
+ * an odd length: stencils with a diagonal), 0 = never, 1 = whenever x is staged.  A launch whose x cannot be staged (alignment,
+ * length) streams the u32 columns instead.  smh_crs_stream_direct: does a STREAM launch of this matrix run in that form? */
+int smh_crs_set_stream_direct(smh_crs *m, int mode);
+int smh_crs_stream_direct(smh_crs *m, int *direct_out);
 /* 16-B chunks per lane and pass of the pipelined VECTOR body (1..3; 0 = automatic): a lane group
  * covers 4*lanes*chunks entry slots of its row per pass */
 int smh_crs_set_vector_chunks(smh_crs *m, int chunks);

@@ -164,6 +164,8 @@ SIGNATURES = {
     "smh_synth_fill": (_int, [_int, C.c_uint64, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
     "smh_synth_laplace3d": (_int, [_int, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
     "smh_crs_set_stream_xs": (_int, [_vp, _int]),
+    "smh_crs_set_stream_direct": (_int, [_vp, _int]),
+    "smh_crs_stream_direct": (_int, [_vp, C.POINTER(_int)]),
     "smh_crs_stream_layout": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "smh_last_transpose_route": (_int, []),
     "smh_pool_trim": (_int, []),

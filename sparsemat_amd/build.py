@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsparsemat_hip.so")
-SOURCES = ["capi.hip", "spmv_vector.hip", "spmv_ring.hip", "spmv_ring2.hip", "spmv_stream.hip", "spmv_colblock.hip", "spmv_colfused.hip", "spmv_colsplit.hip", "spmv_tiled.hip", "spmv_merge.hip", "blas1.hip", "cg.hip", "synth.hip", "assemble.hip", "matops.hip", "par.hip", "pcg.hip", "pool.hip", "transpose_bucket.hip"]
+SOURCES = ["capi.hip", "spmv_vector.hip", "spmv_ring.hip", "spmv_ring2.hip", "spmv_stream.hip", "spmv_stream_xd.hip", "spmv_colblock.hip", "spmv_colfused.hip", "spmv_colsplit.hip", "spmv_tiled.hip", "spmv_merge.hip", "blas1.hip", "cg.hip", "synth.hip", "assemble.hip", "matops.hip", "par.hip", "pcg.hip", "pool.hip", "transpose_bucket.hip"]
 HEADERS = [os.path.join(CSRC, "internal.hpp"), os.path.join(HERE, "..", "include", "sparsemat_hip.h")]
 # -ffp-contract=off: the element-wise / SEQ kernels must round a*b and (a*b)+c separately, like the
 # reference; where an FMA is wanted (K1's accumulation) the kernels call __builtin_fma explicitly.

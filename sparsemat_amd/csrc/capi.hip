@@ -548,6 +548,7 @@ static int ensure_stream_codes(smh_crs *m) {
     SMH_HIP(hipMalloc((void **)&m->d_stream_code, n_out * sizeof(uint16_t)));
     SMH_HIP(hipMemsetAsync(m->d_stream_code, 0, n_out * sizeof(uint16_t), m->stream));
     SMH_TRY(launch_stream_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, m->d_stream_code, m->stream));
+    m->stream_direct = false;
     // ... and with rows of at most 255 entries the row boundaries shrink from a u32 offset to a byte per row
     if (m->max_row_len <= 255u) {
         SMH_HIP(hipMalloc((void **)&m->d_stream_len8, n_tiles * kStreamRows));
@@ -564,6 +565,16 @@ static int ensure_stream_codes(smh_crs *m) {
         if (e2 != hipSuccess) return hip_fail(e2, "stream window statistics", __FILE__, __LINE__);
         m->stream_xs_chunks = h_xs[0];
         m->stream_xs_end = h_xs[1];
+        // ... and how many rows have an odd length (decides whether the unskewed product stage of K1s XD applies)
+        unsigned long long *d_odd = nullptr, h_odd = 0;
+        SMH_HIP(hipMalloc((void **)&d_odd, sizeof(unsigned long long)));
+        int rc3 = launch_stream_odd_rows(m->d_stream_len8, n_tiles * kStreamRows, d_odd, m->stream);
+        hipError_t e3 = rc3 == SMH_OK ? hipMemcpyAsync(&h_odd, d_odd, sizeof h_odd, hipMemcpyDeviceToHost, m->stream) : hipSuccess;
+        if (rc3 == SMH_OK && e3 == hipSuccess) e3 = hipStreamSynchronize(m->stream);
+        (void)hipFree(d_odd);
+        SMH_TRY(rc3);
+        if (e3 != hipSuccess) return hip_fail(e3, "stream row-length statistics", __FILE__, __LINE__);
+        m->stream_odd_rows = (uint64_t)h_odd;
     }
     SMH_HIP(hipStreamSynchronize(m->stream));
     return SMH_OK;
@@ -630,6 +641,7 @@ struct StreamCfg {
     const uint32_t *tbase = nullptr;
     bool small = false; // no tile beyond kStreamCapSmall entries: the two-chunk body
     int xs = 0;         // ... and every tile's column intervals fit an LDS stage of x: 16-byte chunks per thread (2 or 4), 0 = no
+    bool direct = false;  // `code` holds byte offsets into that stage, not column codes: only K1s XD (spmv_stream_xd.hip) reads it
 };
 static int stream_cfg(smh_crs *m, StreamCfg *c) {
     *c = StreamCfg();
@@ -659,8 +671,45 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         c->xs = (xs_off || m->use_stream_xs == 0 || !c->small || !c->len8) ? 0
                 : (m->stream_xs_chunks <= 2u * kBlock && on2) ? 2
                 : (m->stream_xs_chunks <= 4u * kBlock && on4) ? 4 : 0;
+        // K1s XD: the code array as stage offsets.  The unskewed product stage it goes with collides on rows of even length, so
+        // automatic = most rows odd (stencils with a diagonal); the array is rewritten in place when the choice changes
+        static const bool xd_off = getenv("SMH_STREAM_XD") && atoi(getenv("SMH_STREAM_XD")) == 0;  // tuning knob
+        const bool want_direct = c->code && c->xs != 0 && !xd_off && m->use_stream_direct != 0 &&
+                                 (m->use_stream_direct == 1 || 2 * m->stream_odd_rows >= (uint64_t)m->n_rows);
+        if (c->code && want_direct != m->stream_direct) {
+            SMH_HIP(hipDeviceSynchronize());  // (a product enqueued on any stream may still read the array)
+            if (want_direct)
+                SMH_TRY(launch_stream_stage_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, (uint32_t)dtype_size(m->dtype), m->d_stream_code, m->stream));
+            else
+                SMH_TRY(launch_stream_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, m->d_stream_code, m->stream));
+            SMH_HIP(hipStreamSynchronize(m->stream));
+            m->stream_direct = want_direct;
+        }
+        c->direct = c->code && m->stream_direct;
     }
     return SMH_OK;
+}
+
+// one K1s launch over the tiles [t0, t1) with the configuration `c`
+static int stream_launch(smh_crs *m, const StreamCfg &c, const void *x, size_t x_len, void *y, hipStream_t s, void *dot_partials,
+                         const void *dot_lhs, uint64_t t0, uint64_t t1) {
+    // the staged chunks are groups of 4 entries of x fetched with 16-byte loads (f32: one load, f64: two, entries [g, g+2) and
+    // [g+2, g+4)); with x itself 16-byte aligned a load that holds at least one valid entry may reach past x_len but never past the
+    // 16-byte block (hence page, hence allocation granule) its valid entry lies in.  f32: the last chunk holds a valid entry when
+    // x_len rounded up to 4 reaches stream_xs_end; f64: its SECOND load starts at stream_xs_end - 2 and must hold a valid entry
+    // too (x_len >= stream_xs_end - 1), else the gathers stay global
+    const bool xs_ok = ((m->dtype == SMH_F64 ? x_len + 1 : ((x_len + 3) & ~(size_t)3)) >= (size_t)m->stream_xs_end) &&
+                       (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    if (c.direct) {
+        if (xs_ok && c.xs)
+            return launch_spmv_stream_xd(m->dtype, m->d_val, x, y, m->n_rows, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s,
+                                         c.xs, t0, t1);
+        // stage offsets mean nothing without the stage: this call streams the u32 columns (same arithmetic, same order)
+        return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt, c.single_pass,
+                                  dot_partials, nullptr, nullptr, nullptr, nullptr, dot_lhs, s, false, 0, t0, t1);
+    }
+    return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt, c.single_pass,
+                              dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small, xs_ok ? c.xs : 0, t0, t1);
 }
 
 // any_lhs: the dot is taken with a vector of its own (n_rows entries; SparseMatrix::inner_prod) instead of x itself, so
@@ -697,15 +746,7 @@ int spmv_enqueue(smh_crs *m, const void *x, size_t x_len, void *y, int variant, 
         case SMH_SPMV_STREAM: {
             StreamCfg c;
             SMH_TRY(stream_cfg(m, &c));
-            return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt,
-                                      c.single_pass, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
-                                      // the staged chunks are groups of 4 entries of x fetched with 16-byte loads (f32: one load, f64: two, entries
-                                      // [g, g+2) and [g+2, g+4)); with x itself 16-byte aligned a load that holds at least one valid entry may reach past
-                                      // x_len but never past the 16-byte block (hence page, hence allocation granule) its valid entry lies in.  f32: the last
-                                      // chunk holds a valid entry when x_len rounded up to 4 reaches stream_xs_end; f64: its SECOND load starts at
-                                      // stream_xs_end - 2 and must hold a valid entry too (x_len >= stream_xs_end - 1), else the gathers stay global
-                                      (((m->dtype == SMH_F64 ? x_len + 1 : ((x_len + 3) & ~(size_t)3)) >= (size_t)m->stream_xs_end) &&
-                                       (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0);
+            return stream_launch(m, c, x, x_len, y, s, dot_partials, dot_lhs, 0, ~uint64_t(0));
         }
         case SMH_SPMV_COLSPLIT: {
             {
@@ -816,11 +857,7 @@ int spmv_enqueue_rows(smh_crs *m, const void *x, size_t x_len, void *y, int vari
     if (v == SMH_SPMV_STREAM) {
         StreamCfg c;
         SMH_TRY(stream_cfg(m, &c));
-        return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt, c.single_pass,
-                                  dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s, c.small,
-                                  (((m->dtype == SMH_F64 ? x_len + 1 : ((x_len + 3) & ~(size_t)3)) >= (size_t)m->stream_xs_end) &&
-                                   (reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? c.xs : 0,
-                                  row0 / gran, (row1 + gran - 1) / gran);
+        return stream_launch(m, c, x, x_len, y, s, dot_partials, dot_lhs, row0 / gran, (row1 + gran - 1) / gran);
     }
     if (dot_partials) return fail(SMH_ERR_INVALID, "a product by parts with the dot epilogue needs the CSR-stream kernel");
     return launch_spmv_ring2(m->dtype, auto_lanes(m), auto_chunks(m), m->d_off, m->d_col, m->d_col16, m->d_val, x, y, m->n_rows, m->nnz,
@@ -1394,6 +1431,21 @@ int smh_crs_set_stream_xs(smh_crs *m, int mode) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic), 0 (never) or 1 (whenever the tiles allow)");
     m->use_stream_xs = mode;
+    return SMH_OK;
+}
+
+int smh_crs_set_stream_direct(smh_crs *m, int mode) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic), 0 (never) or 1 (whenever x is staged)");
+    m->use_stream_direct = mode;
+    return SMH_OK;
+}
+
+int smh_crs_stream_direct(smh_crs *m, int *direct_out) {
+    if (!m || !direct_out) return fail(SMH_ERR_INVALID, "NULL argument");
+    StreamCfg c;
+    SMH_TRY(stream_cfg(m, &c));
+    *direct_out = c.direct && c.xs != 0;
     return SMH_OK;
 }
 

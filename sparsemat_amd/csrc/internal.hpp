@@ -76,6 +76,13 @@ int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_row
                           uint32_t *d_count, hipStream_t s);
 int launch_stream_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint16_t *code,
                         hipStream_t s);
+// K1s XD (spmv_stream_xd.hip): the code array as byte offsets into the tile's LDS stage of x, an unskewed product stage
+int launch_spmv_stream_xd(int dtype, const void *val, const void *x, void *y, size_t n_rows, void *dot_partials, const uint16_t *scode,
+                          const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs, hipStream_t s, int xs,
+                          uint64_t tile_begin = 0, uint64_t tile_end = ~uint64_t(0));
+int launch_stream_stage_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint32_t elem_bytes,
+                              uint16_t *code, hipStream_t s);
+int launch_stream_odd_rows(const uint8_t *len8, size_t n_padded, unsigned long long *d_out, hipStream_t s);
 int launch_stream_max_tile(const uint32_t *off, size_t n_rows, size_t tile_rows, uint32_t *d_out, hipStream_t s);
 // K2c (column-blocked CSR; each block runs the K1s kernel)
 int launch_spmv_stream_block(int dtype, const uint32_t *off, const uint32_t *col, const void *val, const void *x, void *y,
@@ -262,6 +269,9 @@ struct smh_crs {
     int use_ring = -1;  // -1 automatic, 0 never, 1 always (when lanes <= 8), 2 always with the first K1r body
     int use_stream_xs = -1;  // K1s XS: -1 automatic (x beyond the L2s; the 4096-entry stage on f32 only), 0 never, 1 whenever the tiles allow
     uint32_t stream_xs_chunks = 0xFFFFFFFFu, stream_xs_end = 0;  // K1s XS: most x chunks a tile needs; largest x index + 1 they touch
+    bool stream_direct = false;   // d_stream_code holds stage byte offsets (K1s XD) instead of column codes
+    int use_stream_direct = -1;   // K1s XD: -1 automatic (most rows of odd length), 0 never, 1 whenever x is staged
+    uint64_t stream_odd_rows = 0; // rows of odd length (taken with the byte lengths)
     uint16_t *d_col16 = nullptr;  // K1r: 16-bit column array for the ring phases (lazy; null: not used)
     int use_col16 = -1;           // -1 automatic (when at least a quarter of the rows are ring rows), 0 never, 1 always
     // staging for the host-pointer API (lazy, reused)

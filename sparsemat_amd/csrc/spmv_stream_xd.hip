@@ -1,0 +1,287 @@
+// spmv_stream_xd.hip -- K1s "XD": the CSR-stream kernel for stencil-like matrices with everything a thread would have to compute
+// per entry moved into the build.  Same product, same arithmetic and same ORDER as K1s (spmv_stream.hip; reference
+// sparsematrix.rs:146-158 over sparsemat_crs.rs:102-110): products rounded, then added to the row's sum in storage order, one
+// rounded add per entry, starting from +0 -- bit-exact against the reference loop.
+//
+// Why: K1s with x staged in LDS (XS) is bound by vector-ALU issue, not by bytes -- a wavefront instruction occupies its 16-lane
+// SIMD for 4 cycles, a 256-row tile costs each of its four wavefronts ~400 of them, 2048 tiles per CU: 1.37 ms of issue time on
+// the 512^3 Laplacian for 1.30 ms measured.  Per entry the XS body spent 6 instructions turning a 16-bit column code (interval,
+// offset) into an LDS address, 7 on where the product goes (position relative to the tile, range test, bank skew, select), and
+// the row sums walked a skewed stage in two loops with a dependent LDS round trip per step.  Here
+//   * the code array holds the BYTE OFFSET of x[col] inside the tile's LDS stage of x (the stage's layout is a function of
+//     the tile's interval table alone, so the build can know it): decode = extracting 16 bits;
+//   * a thread's four products of a chunk leave as ONE 16-byte LDS store at the chunk's own position (the stage is not skewed
+//     and covers both chunks of every thread, so slots before the tile's first / after its last entry need no test: they receive
+//     products nobody reads);
+//   * the chunk loads are buffer loads whose descriptors end with the tile's entries: no branches, no tail path;
+//   * a row's first 8 products are read with 8 independent LDS loads and added under a lane mask (rows beyond 8 entries continue in
+//     a loop); the row-length prefix sum is a DPP scan.
+// Without the skew the row sums of rows of EVEN length collide in LDS (stride 8 -> 8 lanes per bank); the handle takes this form
+// only when most rows have an odd length -- every stencil with a diagonal: 5, 7, 9, 27 points -- (capi.hip, stream_direct_choice).
+#include "internal.hpp"
+
+namespace smh {
+
+namespace {
+
+typedef uint32_t xd_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t xd_u2 __attribute__((ext_vector_type(2)));
+typedef float xd_f4 __attribute__((ext_vector_type(4)));
+typedef double xd_d2 __attribute__((ext_vector_type(2)));
+constexpr int kXdRsrc = 0x00020000;  // dword 3 of a raw buffer descriptor on gfx9 (32-bit data format)
+
+__device__ __forceinline__ float xd_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double xd_mul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float xd_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double xd_add(double a, double b) { return __dadd_rn(a, b); }
+
+template <int CTRL, int ROWS> __device__ __forceinline__ uint32_t xd_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false);  // lanes without a source receive 0
+}
+// inclusive prefix sum over the wavefront
+__device__ __forceinline__ uint32_t xd_wave_scan(uint32_t v) {
+    v += xd_dpp<0x111, 0xF>(v);  // row_shr:1
+    v += xd_dpp<0x112, 0xF>(v);  // row_shr:2
+    v += xd_dpp<0x114, 0xF>(v);  // row_shr:4
+    v += xd_dpp<0x118, 0xF>(v);  // row_shr:8
+    v += xd_dpp<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += xd_dpp<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+constexpr int kXdSlots = 2 * 4 * kBlock;  // product slots of a tile: two 4-entry chunks per thread (kStreamCapSmall + 3 <= 2048)
+static_assert(kStreamCapSmall + 3 <= kXdSlots, "a tile's entries from an aligned start fit two chunks per thread");
+
+// XS: 16-byte chunks of x per thread the tile's stage holds (2 or 4)
+template <typename T, bool DOT, int XS>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t n_tiles,
+                 T *__restrict__ dot_partials, const uint16_t *__restrict__ scode, const uint32_t *__restrict__ cwin,
+                 const uint8_t *__restrict__ len8, const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs, uint64_t tile0) {
+    constexpr int kXsCap = XS * kBlock * 4;  // entries of x the stage holds (2048 / 4096)
+    __shared__ __attribute__((aligned(16))) T s_xs[kXsCap];
+    __shared__ __attribute__((aligned(16))) T s_prod[kXdSlots + 8];  // (+8: a row's eight unconditional reads may pass the tile's end)
+    __shared__ uint32_t s_wtot[kBlock / kWave];
+    // bijective XCD-aware remap: XCD g (= blockIdx % 8) walks a contiguous run of the launch's tiles (as K1s)
+    const uint64_t q8 = n_tiles >> 3, rm = n_tiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const uint64_t tile = tile0 + (xcd < rm ? xcd * (q8 + 1) : rm * (q8 + 1) + (xcd - rm) * q8) + idx;
+    const uint64_t r0 = tile * (uint64_t)kStreamRows;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));
+    const uint32_t k0 = tbase[tile], k1 = tbase[tile + 1];  // tile-uniform: scalar loads
+    const uint32_t my_len = len8[r0 + tid];                 // (the byte array is padded to whole tiles with zeros)
+    T dl = T(0);
+    if constexpr (DOT) dl = r0 + tid < n_rows ? dot_lhs[r0 + tid] : T(0);  // requested now: its latency hides behind the tile
+    // ---- the tile's intervals of x: 16-byte chunks, requested before the tile's own entries (they are needed first) ----
+    const uint32_t *w = cwin + 8 * tile;  // scalar loads
+    const uint32_t cb0 = w[0], e0 = w[1], cb1 = w[2], e1 = w[3], cb2 = w[4], e2 = w[5], cb3 = w[6], e3 = w[7];
+    const uint32_t al0 = cb0 & ~3u, al1 = cb1 & ~3u, al2 = cb2 & ~3u, al3 = cb3 & ~3u;
+    const uint32_t n0 = e0 > cb0 ? (e0 - al0 + 3u) >> 2 : 0u, n1 = e1 > cb1 ? (e1 - al1 + 3u) >> 2 : 0u;
+    const uint32_t n2 = e2 > cb2 ? (e2 - al2 + 3u) >> 2 : 0u, n3 = e3 > cb3 ? (e3 - al3 + 3u) >> 2 : 0u;
+    const uint32_t p1 = n0, p2 = p1 + n1, p3 = p2 + n2, xs_tot = p3 + n3;  // (<= XS * kBlock chunks, inside x: checked by the host)
+    const uint32_t d0 = al0 >> 2, d1 = (al1 >> 2) - p1, d2 = (al2 >> 2) - p2, d3 = (al3 >> 2) - p3;  // (mod 2^32; j + d_q is a chunk of x)
+    T xr[XS][4];
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+        const uint32_t j = tid + (uint32_t)u * kBlock;
+        xr[u][0] = xr[u][1] = xr[u][2] = xr[u][3] = T(0);
+        if (j < xs_tot) {
+            // chunk j of the stage = chunk j + d_q of x, q = the interval j falls into (tile-uniform offsets: three selects)
+            uint32_t d = d0;
+            d = j >= p1 ? d1 : d;
+            d = j >= p2 ? d2 : d;
+            d = j >= p3 ? d3 : d;
+            const T *g = x + 4ull * (uint64_t)(j + d);
+            if constexpr (sizeof(T) == 4) {
+                const xd_f4 a = *reinterpret_cast<const xd_f4 *>(g);
+                xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = a.z; xr[u][3] = a.w;
+            } else {
+                const xd_d2 a = *reinterpret_cast<const xd_d2 *>(g), b = *reinterpret_cast<const xd_d2 *>(g + 2);
+                xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = b.x; xr[u][3] = b.y;
+            }
+        }
+    }
+    // ---- the tile's entries: two chunks per thread from the aligned start `pa`; a descriptor that ends with the tile's last
+    // entry makes every slot beyond it read as zero (code 0: the stage's first entry; value 0) ----
+    const uint32_t pa = k0 & ~3u, hi = k1 - pa;  // hi <= kXdSlots (kStreamCapSmall, checked by the host)
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(scode + pa), 0, (int)(((hi + 3u) & ~3u) * 2u), kXdRsrc);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(val + pa), 0, (int)(hi * (uint32_t)sizeof(T)), kXdRsrc);
+    xd_u2 cw[2];
+    T v[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
+        cw[it] = __builtin_bit_cast(xd_u2, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(j * 2u), 0, 2 /* nt */));
+        if constexpr (sizeof(T) == 4) {
+            const xd_f4 a = __builtin_bit_cast(xd_f4, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 4u), 0, 2));
+            v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+        } else {
+            const xd_d2 a = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 8u), 0, 2));
+            const xd_d2 b = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 8u + 16u), 0, 2));
+            v[it][0] = a.x; v[it][1] = a.y; v[it][2] = b.x; v[it][3] = b.y;
+        }
+    }
+    // ---- row boundaries: prefix sum of the byte lengths (its cross-wave part rides on the barrier below) ----
+    const uint32_t incl = xd_wave_scan(my_len);
+    if (lane == kWave - 1) s_wtot[wave] = incl;
+    // ---- x into its stage ----
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+        const uint32_t j = tid + (uint32_t)u * kBlock;
+        if (j < xs_tot) {
+            if constexpr (sizeof(T) == 4) {
+                xd_f4 a; a.x = xr[u][0]; a.y = xr[u][1]; a.z = xr[u][2]; a.w = xr[u][3];
+                *reinterpret_cast<xd_f4 *>(&s_xs[4u * j]) = a;
+            } else {
+                xd_d2 a, b; a.x = xr[u][0]; a.y = xr[u][1]; b.x = xr[u][2]; b.y = xr[u][3];
+                *reinterpret_cast<xd_d2 *>(&s_xs[4u * j]) = a;
+                *reinterpret_cast<xd_d2 *>(&s_xs[4u * j + 2u]) = b;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- products: x from the stage by byte offset, four products per 16-byte store at the chunk's own position ----
+    const char *xs_bytes = reinterpret_cast<const char *>(s_xs);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
+        T p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t cword = (e >> 1) ? cw[it].y : cw[it].x;
+            const uint32_t ofs = (e & 1) ? (cword >> 16) : (cword & 0xFFFFu);
+            p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + ofs), v[it][e]);
+        }
+        if constexpr (sizeof(T) == 4) {
+            xd_f4 a; a.x = p[0]; a.y = p[1]; a.z = p[2]; a.w = p[3];
+            *reinterpret_cast<xd_f4 *>(&s_prod[j]) = a;
+        } else {
+            xd_d2 a, b; a.x = p[0]; a.y = p[1]; b.x = p[2]; b.y = p[3];
+            *reinterpret_cast<xd_d2 *>(&s_prod[j]) = a;
+            *reinterpret_cast<xd_d2 *>(&s_prod[j + 2u]) = b;
+        }
+    }
+    __syncthreads();
+    // ---- row sums: storage order, one rounded add per entry (reference: sum += product) ----
+    uint32_t before = 0;  // entries of the tile in the waves before this one (wave-uniform)
+#pragma unroll
+    for (int ww = 0; ww < kBlock / kWave - 1; ++ww) before += (uint32_t)ww < wave ? s_wtot[ww] : 0u;
+    const T *pp = s_prod + ((k0 - pa) + before + (incl - my_len));
+    T q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = pp[i];
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if ((uint32_t)i < my_len) acc = xd_add(acc, q[i]);
+    for (uint32_t i = 8; i < my_len; ++i) acc = xd_add(acc, pp[i]);
+    const uint64_t r = r0 + tid;
+    if (r < n_rows && (!DOT || y)) __builtin_nontemporal_store(acc, &y[r]);  // (DOT with y == NULL: only lhs . (A x) is wanted)
+    if constexpr (DOT) {  // fixed order: lanes (butterfly), waves (index order) -- bitwise reproducible, as K1s
+        __shared__ T s_red[kBlock / kWave];
+        T d = T(0);
+        if (r < n_rows) d += dl * acc;  // (as K1s: 0 + the product)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
+        if (lane == 0) s_red[wave] = d;
+        __syncthreads();
+        if (tid == 0) {
+            T t = T(0);
+#pragma unroll
+            for (int ww = 0; ww < kBlock / kWave; ++ww) t += s_red[ww];
+            dot_partials[tile] = t;
+        }
+    }
+}
+
+// stage offsets: code = BYTES from the start of the tile's LDS stage of x to x[column] -- the stage holds the tile's intervals
+// back to back, each from its 4-aligned start in whole 16-byte chunks (exactly what the kernel's fill does)
+__global__ void __launch_bounds__(kBlock)
+k_stream_stage_codes(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint32_t *__restrict__ win,
+                     uint64_t n_rows, uint64_t n_tiles, uint32_t elem_bytes, uint16_t *__restrict__ code) {
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t *w = win + 8 * t;
+        const uint32_t a0 = w[0], e0 = w[1], a1 = w[2], e1 = w[3], a2 = w[4], e2 = w[5], a3 = w[6], e3 = w[7];
+        const uint32_t al0 = a0 & ~3u, al1 = a1 & ~3u, al2 = a2 & ~3u, al3 = a3 & ~3u;
+        const uint32_t n0 = e0 > a0 ? (e0 - al0 + 3u) >> 2 : 0u, n1 = e1 > a1 ? (e1 - al1 + 3u) >> 2 : 0u;
+        const uint32_t n2 = e2 > a2 ? (e2 - al2 + 3u) >> 2 : 0u;
+        const uint32_t p1 = n0, p2 = p1 + n1, p3 = p2 + n2;
+        const uint64_t r0 = t * kStreamRows, r1 = r0 + kStreamRows < n_rows ? r0 + kStreamRows : n_rows;
+        const uint64_t k0 = off[r0], k1 = off[r1];
+        for (uint64_t k = k0 + threadIdx.x; k < k1; k += kBlock) {
+            const uint32_t c = col[k];
+            // the used intervals are a prefix of the table, sorted, disjoint, and contain every column of the tile
+            const uint32_t q = (uint32_t)(e1 > a1 && c >= a1) + (uint32_t)(e2 > a2 && c >= a2) + (uint32_t)(e3 > a3 && c >= a3);
+            const uint32_t al = q == 3u ? al3 : q == 2u ? al2 : q == 1u ? al1 : al0;
+            const uint32_t pq = q == 3u ? p3 : q == 2u ? p2 : q == 1u ? p1 : 0u;
+            code[k] = (uint16_t)((4u * pq + (c - al)) * elem_bytes);
+        }
+    }
+}
+
+// rows of odd length (decides whether the unskewed stage applies)
+__global__ void __launch_bounds__(kBlock)
+k_stream_odd_rows(const uint8_t *__restrict__ len8, uint64_t n, unsigned long long *__restrict__ out) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) c += len8[i] & 1u;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) c += (uint32_t)__shfl_down((int)c, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(out, (unsigned long long)c);  // integer count: exact, order independent
+}
+
+template <typename T>
+int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, const uint16_t *scode, const uint32_t *cwin,
+                const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs, hipStream_t s, int xs, uint64_t tile_begin, uint64_t tile_end) {
+    const uint64_t all_tiles = stream_tiles(n_rows, 1);
+    const uint64_t tile0 = tile_begin < all_tiles ? tile_begin : all_tiles, tile1 = tile_end < all_tiles ? tile_end : all_tiles;
+    if (tile1 <= tile0) return SMH_OK;
+    const uint64_t n_tiles = tile1 - tile0;
+    const dim3 grid((unsigned)n_tiles), block(kBlock);
+#define SMH_XD(D, P)                                                                                                              \
+    hipLaunchKernelGGL((k_spmv_stream_xd<T, D, P>), grid, block, 0, s, val, x, y, (uint64_t)n_rows, n_tiles, dot_partials, scode, \
+                       cwin, len8, tbase, dot_lhs, tile0)
+    if (xs == 2) { if (dot_partials) SMH_XD(true, 2); else SMH_XD(false, 2); }
+    else if (xs == 4) { if (dot_partials) SMH_XD(true, 4); else SMH_XD(false, 4); }
+    else return fail(SMH_ERR_INVALID, "K1s XD: the stage of x holds 2 or 4 chunks per thread");
+#undef SMH_XD
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+}  // namespace
+
+int launch_spmv_stream_xd(int dtype, const void *val, const void *x, void *y, size_t n_rows, void *dot_partials, const uint16_t *scode,
+                          const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs, hipStream_t s, int xs,
+                          uint64_t tile_begin, uint64_t tile_end) {
+    if (n_rows == 0) return SMH_OK;
+    if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
+    if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
+    if (dtype == SMH_F64)
+        return launch_xd_t<double>((const double *)val, (const double *)x, (double *)y, n_rows, (double *)dot_partials, scode, cwin, len8,
+                                   tbase, (const double *)dot_lhs, s, xs, tile_begin, tile_end);
+    return launch_xd_t<float>((const float *)val, (const float *)x, (float *)y, n_rows, (float *)dot_partials, scode, cwin, len8, tbase,
+                              (const float *)dot_lhs, s, xs, tile_begin, tile_end);
+}
+
+int launch_stream_stage_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint32_t elem_bytes,
+                              uint16_t *code, hipStream_t s) {
+    const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
+    if (n_tiles == 0) return SMH_OK;
+    const uint64_t blocks = n_tiles < 16384 ? n_tiles : 16384;
+    hipLaunchKernelGGL(k_stream_stage_codes, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, win, (uint64_t)n_rows, n_tiles, elem_bytes, code);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+// *d_out (unsigned long long, device) = rows of odd length among the n_padded byte lengths
+int launch_stream_odd_rows(const uint8_t *len8, size_t n_padded, unsigned long long *d_out, hipStream_t s) {
+    SMH_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s));
+    if (n_padded == 0) return SMH_OK;
+    uint64_t blocks = (n_padded + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_stream_odd_rows, dim3((unsigned)blocks), dim3(kBlock), 0, s, len8, (uint64_t)n_padded, d_out);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+}  // namespace smh

@@ -298,6 +298,16 @@ class SparseMatCRS:
         """K1s XS (the tile's column intervals of x staged in LDS): -1 automatic, 0 never, 1 whenever the tiles allow."""
         check(lib().smh_crs_set_stream_xs(self._h, mode))
 
+    def set_stream_direct(self, mode):
+        """K1s XD (stage offsets instead of column codes, unskewed product stage): -1 automatic, 0 never, 1 whenever x is staged."""
+        check(lib().smh_crs_set_stream_direct(self._h, mode))
+
+    def stream_direct(self):
+        """Does a STREAM launch of this matrix run as K1s XD?"""
+        a = C.c_int()
+        check(lib().smh_crs_stream_direct(self._h, C.byref(a)))
+        return bool(a.value)
+
     def stream_layout(self):
         """What a STREAM launch of this matrix uses: dict(coded, byte_lengths, small_tiles, xs_chunks)."""
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -102,3 +102,44 @@ def test_blocks_without_an_interior_still_multiply(gpu):
     m.mvp_dev(x, y, variant="stream", exchange="window")
     m.synchronize()
     assert y.download().tobytes() == oracle.spmv(off, col, val, x_host).tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_k1s_xd_blocks_launched_by_runs_of_rows(gpu, dtype):
+    """Blocks whose STREAM kernel is K1s XD (x staged in LDS, stage offsets; forced here, automatic from 8 MB of x): the overlapped
+    product launches it over a block's boundary tiles and its interior tiles separately, the CG with the dot epilogue on top --
+    same bits as the oracle / as without the overlap."""
+    g, n_blocks = 40, 3
+    off, col, val = oracle.laplace3d(g, g, g, dtype)
+    n = g * g * g
+    r = n // n_blocks
+    blocks = []
+    for b in range(n_blocks):
+        r0, r1 = b * r, (n if b == n_blocks - 1 else (b + 1) * r)
+        k0, k1 = int(off[r0]), int(off[r1])
+        blk = sm.SparseMatCRS.from_raw_parts(r1 - r0, n, (off[r0:r1 + 1] - off[r0]).astype(np.uint32), col[k0:k1], val[k0:k1])
+        blk.set_stream_xs(1)
+        assert blk.stream_direct()
+        blocks.append(blk)
+    m = sm.SparseMatParLocal.adopt(blocks, n)
+    assert all(m.interior(b, "stream")[1] > m.interior(b, "stream")[0] for b in range(n_blocks))
+    rng = np.random.default_rng(8)
+    x_host = rng.uniform(-1, 1, n).astype(dtype)
+    want = oracle.spmv(off, col, val, x_host)
+    b_host = oracle.spmv(off, col, val, np.ones(n, dtype))
+    res = {}
+    for on in (True, False):
+        m.set_overlap(on)
+        x, y = m.vec(host=x_host), m.vec()
+        m.mvp_dev(x, y, variant="stream", exchange="window")
+        m.synchronize()
+        assert y.download().tobytes() == want.tobytes(), on
+        b, xs = m.vec(host=b_host), m.vec()
+        res[on] = (m.cg_solve_vec(b, xs, tol=1e-6 if dtype == np.float32 else 1e-10, iter_max=60, check_every=3), xs.download())
+    assert res[True][0] == res[False][0] and res[True][1].tobytes() == res[False][1].tobytes()
+    # ... and the same iterates as with the classic bodies (the dot epilogue folds the same partial sums in the same order)
+    for blk in blocks:
+        blk.set_stream_direct(0)
+    b, xs = m.vec(host=b_host), m.vec()
+    again = (m.cg_solve_vec(b, xs, tol=1e-6 if dtype == np.float32 else 1e-10, iter_max=60, check_every=3), xs.download())
+    assert again[0] == res[True][0] and again[1].tobytes() == res[True][1].tobytes()

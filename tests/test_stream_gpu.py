@@ -227,3 +227,66 @@ def test_stream_x_staged_in_lds_bit_exact(gpu, dtype):
     assert m.stream_layout()["xs_chunks"] == 0
     x = rng.uniform(-1, 1, 120_000).astype(dtype)
     assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_stream_xd_stage_offsets_bit_exact(gpu, dtype):
+    """K1s XD (spmv_stream_xd.hip): the XS kernel with the code array holding byte offsets into the tile's LDS stage of x, an unskewed
+    product stage written 16 bytes at a time, buffer loads, a row's first eight products under a lane mask.  Automatic where x is
+    staged and most rows have an odd length; same bits as the oracle, as the classic XS body and as the plain kernel -- for the
+    product, for lhs . (A x) through the dot epilogue and for an x that cannot be staged (launches by runs of rows:
+    tests/test_par_overlap_gpu.py)."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    for g in ((40, 40, 40), (300, 300, 1), (1000, 30, 3), (7, 5, 3), (257, 1, 1), (48, 20, 9)):
+        off, col, val = oracle.laplace3d(*g, dtype)
+        cases.append(("laplace %dx%dx%d" % g, g[0] * g[1] * g[2], off, col, val, bool(2 * int((np.diff(off) & 1).sum()) >= len(off) - 1)))
+    n = 20_000   # rows of 5 entries with one of 23 / 40 now and then: the loop that follows the eight masked adds
+    lens = np.full(n, 5)
+    lens[::64], lens[37::640] = 23, 40
+    off = np.zeros(n + 1, np.uint32); np.cumsum(lens, out=off[1:])
+    col = np.clip(np.repeat(np.arange(n), lens) + rng.integers(-250, 250, int(off[-1])), 0, n - 1).astype(np.uint32)
+    cases.append(("long rows among short ones", n, off, col, rng.uniform(-1, 1, len(col)).astype(dtype), True))
+    n = 30_000   # rows of EVEN length only (4 and 6), a band: automatic keeps the skewed stage, forced runs (conflicts, same bits)
+    lens = rng.choice([4, 6], n)
+    off = np.zeros(n + 1, np.uint32); np.cumsum(lens, out=off[1:])
+    col = np.clip(np.repeat(np.arange(n), lens) + rng.integers(-200, 200, int(off[-1])), 0, n - 1).astype(np.uint32)
+    cases.append(("even rows", n, off, col, rng.uniform(-1, 1, len(col)).astype(dtype), False))
+    n = 50_001   # storage order with duplicates, empty rows, a ragged last tile
+    lens = rng.integers(0, 8, n)
+    lens[1000:1300] = 0
+    off = np.zeros(n + 1, np.uint32); np.cumsum(lens, out=off[1:])
+    col = np.clip(np.repeat(np.arange(n), lens) + rng.integers(-300, 300, int(off[-1])), 0, n - 1).astype(np.uint32)
+    cases.append(("band", n, off, col, rng.uniform(-1, 1, len(col)).astype(dtype), None))
+    for name, n, off, col, val, auto_direct in cases:
+        x = rng.uniform(-1, 1, n).astype(dtype)
+        lhs = rng.uniform(-1, 1, n).astype(dtype)
+        y_ref = oracle.spmv(off, col, val, x)
+        m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+        assert not m.stream_direct(), name                        # x is not staged by default at these sizes
+        y_plain, ip_plain = m.mvp(x, variant="stream"), m.inner_prod(lhs, x, variant="stream")
+        m.set_stream_xs(1)
+        assert m.stream_layout()["xs_chunks"] in (2, 4), name
+        if auto_direct is not None:
+            assert m.stream_direct() == auto_direct, name
+        m.set_stream_direct(0)
+        assert not m.stream_direct(), name
+        y_xs, ip_xs = m.mvp(x, variant="stream"), m.inner_prod(lhs, x, variant="stream")
+        m.set_stream_direct(1)
+        assert m.stream_direct(), name
+        y_xd, ip_xd = m.mvp(x, variant="stream"), m.inner_prod(lhs, x, variant="stream")
+        for y in (y_plain, y_xs, y_xd):
+            assert np.array_equal(bits(y), bits(y_ref)), name
+        assert ip_plain == ip_xs == ip_xd, name
+        # a pointer that is not 16-byte aligned: x cannot be staged, the stage offsets mean nothing -> the u32 columns, same bits
+        xbuf = synth.DeviceBuffer((n + 9) * x.itemsize)
+        xbuf.upload(np.concatenate([np.zeros(1, dtype), x, np.zeros(8, dtype)]))
+        ybuf = synth.DeviceBuffer(n * x.itemsize)
+        m.mvp_dev(xbuf.ptr + x.itemsize, n, ybuf.ptr, "stream")
+        sm.lib().smh_device_synchronize()
+        assert np.array_equal(bits(ybuf.download(dtype, n)), bits(y_ref)), name
+        # back and forth once more: the code array is rewritten in place
+        m.set_stream_direct(0)
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), name
+        m.set_stream_direct(-1)
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), name
