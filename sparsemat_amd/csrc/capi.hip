@@ -662,12 +662,14 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
         static const bool small_off = getenv("SMH_STREAM_SMALL") && atoi(getenv("SMH_STREAM_SMALL")) == 0;  // tuning knob
         c->small = !small_off && m->have_stats && m->max_tile_entries <= (uint32_t)kStreamCapSmall;
         static const bool xs_off = getenv("SMH_STREAM_XS") && atoi(getenv("SMH_STREAM_XS")) == 0;  // tuning knob
-        // worth it once x is beyond one L2 (the 1000^2 Laplacian, x = 4 MB, loses 5-20 % to the extra barrier with the 4096-entry
-        // stage); that stage pays on f32 only (grid planes 1024 wide: 1.618 -> 1.564 ms; f64, LDS-limited to three blocks per CU, 1.399 -> 1.549)
-        // (tools/dev/xs_threshold.py, cubes of 100..320: nothing at 4 MB of x -- launch-bound --, -9 .. -20 % from 8 MB on, both dtypes)
+        // worth it from ~1 MB of x on (tools/dev/xs_threshold.py, profiles/r03_xs_threshold.log: 64^3 ... 320^3 cubes and 1000^2 / 2000^2
+        // grids, -11 .. -20 % with the 2048-entry stage, -18 .. -40 % as K1s XD, both dtypes; below that the launch dominates).  The
+        // 4096-entry stage pays on f32 only (grid planes 1024 wide, x of 17-34 MB: -7 .. -9 %; f64, LDS-limited to three blocks per
+        // CU: +3 .. +10 %).  (Round 2 had 8 MB / 32 MB here: its inspector described a tile whose columns span < 16384 as ONE interval,
+        // so a 64^3 .. 100^3 cube staged its whole span or nothing.)
         const bool forced = m->use_stream_xs == 1;
         const size_t x_bytes = m->n_cols * dtype_size(m->dtype);
-        const bool on2 = forced || x_bytes >= ((size_t)8 << 20), on4 = forced || (x_bytes >= ((size_t)32 << 20) && m->dtype == SMH_F32);
+        const bool on2 = forced || x_bytes >= ((size_t)1 << 20), on4 = forced || (x_bytes >= ((size_t)8 << 20) && m->dtype == SMH_F32);
         c->xs = (xs_off || m->use_stream_xs == 0 || !c->small || !c->len8) ? 0
                 : (m->stream_xs_chunks <= 2u * kBlock && on2) ? 2
                 : (m->stream_xs_chunks <= 4u * kBlock && on4) ? 4 : 0;

@@ -50,8 +50,8 @@ __device__ __forceinline__ double st_add(double a, double b) { return __dadd_rn(
 // entries counts as described).
 __global__ void __launch_bounds__(kBlock)
 k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, uint64_t n_rows, uint64_t n_tiles,
-                 uint64_t tile_rows, uint64_t max_entries, uint64_t max_width, uint64_t max_total, bool count_empty,
-                 uint32_t *__restrict__ win, uint32_t *__restrict__ n_windowed) {
+                 uint64_t tile_rows, uint64_t max_entries, uint64_t max_width, uint64_t max_total, uint64_t split_above,
+                 bool count_empty, uint32_t *__restrict__ win, uint32_t *__restrict__ n_windowed) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
@@ -73,7 +73,11 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
                 cmax = max(cmax, (uint32_t)__shfl_xor(cmax, o, kWave));
             }
             const uint64_t span = (uint64_t)cmax - cmin + 1;
-            if (span <= max_width && span <= max_total) {
+            // one interval when the columns' span allows it -- unless it is wider than split_above: then the clusters inside it are
+            // looked for first (the column codes do not care, but what a tile stages of x in LDS is the intervals' total: a 64^3
+            // Laplacian's tile spans 8448 columns and references 896 of them), and the span stays the fallback
+            const bool single_ok = span <= max_width && span <= max_total;
+            if (single_ok && span <= split_above) {
                 lo[0] = cmin; hi[0] = cmax + 1;
             } else {
                 // occupancy of 64 equal buckets over [cmin, cmax]; the 3 widest empty runs split the columns
@@ -133,6 +137,11 @@ k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
                     }
                 }
                 ok = total <= max_total && widest <= max_width;
+                if (!ok && single_ok) {
+                    ok = true;
+                    lo[0] = cmin; hi[0] = cmax + 1;
+                    lo[1] = lo[2] = lo[3] = hi[1] = hi[2] = hi[3] = 0;
+                }
             }
         }
         if (lane < 8) {
@@ -638,8 +647,9 @@ int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_row
     const uint64_t max_entries = for_codes ? ~uint64_t(0) : (uint64_t)kStreamCap;
     const uint64_t max_width = for_codes ? (uint64_t)kStreamCodeWidth : (uint64_t)kStreamXWin;
     const uint64_t max_total = for_codes ? ~uint64_t(0) : (uint64_t)kStreamXWin;
+    // (codes: a span beyond 1024 columns is split where it has gaps -- what K1s XS / XD stage of x is the intervals' total)
     hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles,
-                       (uint64_t)kStreamRows, max_entries, max_width, max_total, for_codes, win, d_count);
+                       (uint64_t)kStreamRows, max_entries, max_width, max_total, for_codes ? (uint64_t)1024 : max_width, for_codes, win, d_count);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
@@ -654,7 +664,7 @@ int launch_tile_intervals(const uint32_t *off, const uint32_t *col, size_t n_row
     uint64_t blocks = (n_tiles * kWave + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles,
-                       (uint64_t)tile_rows, ~uint64_t(0), (uint64_t)max_width, ~uint64_t(0), true, win, d_count);
+                       (uint64_t)tile_rows, ~uint64_t(0), (uint64_t)max_width, ~uint64_t(0), (uint64_t)max_width, true, win, d_count);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }

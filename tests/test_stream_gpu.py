@@ -198,7 +198,7 @@ def test_stream_x_staged_in_lds_bit_exact(gpu, dtype):
         x = rng.uniform(-1, 1, n).astype(dtype)
         y_ref = oracle.spmv(off, col, val, x)
         m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
-        assert m.stream_layout()["xs_chunks"] == 0, name          # AUTO: x is far below 8 MB here
+        assert m.stream_layout()["xs_chunks"] == 0, name          # AUTO: x is below 1 MB here
         y_plain = m.mvp(x, variant="stream")
         m.set_stream_xs(1)
         lay = m.stream_layout()
@@ -221,11 +221,21 @@ def test_stream_x_staged_in_lds_bit_exact(gpu, dtype):
         assert np.array_equal(bits(ybuf.download(dtype, n)), bits(y_ref)), name
     assert seen == {2, 4}   # both stage sizes ran
     # a matrix whose tiles' intervals do not fit any stage keeps the gathers from memory
-    off, col, val = oracle.laplace3d(3000, 40, 1, dtype)   # rows 3000 apart: window 256 + 6000
-    m = sm.SparseMatCRS.from_raw_parts(120_000, 120_000, off, col, val)
+    # (a tile's columns are described as <= 4 intervals cut at their widest gaps: five clusters 5000 apart leave one interval of
+    # 5256 columns, 6024 in total -- beyond the 4096-entry stage; a 3000 x 40 grid, three clusters of 256, fits since round 3)
+    n = 120_000
+    off = np.arange(n + 1, dtype=np.uint32) * 5
+    col = np.clip(np.arange(n)[:, None] + np.array([-10_000, -5000, 0, 5000, 10_000]), 0, n - 1).astype(np.uint32).reshape(-1)
+    val = rng.uniform(-1, 1, 5 * n).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
     m.set_stream_xs(1)
-    assert m.stream_layout()["xs_chunks"] == 0
-    x = rng.uniform(-1, 1, 120_000).astype(dtype)
+    assert m.stream_layout()["coded"] and m.stream_layout()["xs_chunks"] == 0 and not m.stream_direct()
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
+    off, col, val = oracle.laplace3d(3000, 40, 1, dtype)   # rows 3000 apart: three clusters of 256 columns
+    m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+    m.set_stream_xs(1)
+    assert m.stream_layout()["xs_chunks"] == 2
     assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
 
 
