@@ -511,13 +511,13 @@ __global__ __launch_bounds__(kBlock) void k_t3_fill(const uint32_t *__restrict__
 }
 
 // one wavefront per chunk: prow[obase + j] = row of the chunk's j-th run (the padding of the last piece repeats the last row, so
-// that the array stays ordered by row BLOCK inside a slice); desc[c] = {obase, len}
+// that the array stays sorted inside a slice); rcount[row] += 1 per run; desc[c] = {obase, len}
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t n_chunks, const uint64_t *__restrict__ start,
                                                      const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ clen,
                                                      const uint32_t *__restrict__ obase, const uint32_t *__restrict__ rowq,
                                                      const uint16_t *__restrict__ code_a, uint32_t *__restrict__ prow, uint32_t *__restrict__ preal,
-                                                     T3Chunk *__restrict__ desc, uint32_t *__restrict__ any_cut) {
+                                                     uint32_t *__restrict__ rcount, T3Chunk *__restrict__ desc, uint32_t *__restrict__ any_cut) {
     constexpr uint32_t CH = t3_chunk<T>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -535,6 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__
         if (head) {
             const uint32_t row = rowq[q0 + j];
             prow[ob + rank] = row;
+            atomicAdd(rcount + row, 1u);
         }
         done += (uint32_t)__popcll(m);
     }
@@ -588,140 +589,6 @@ __global__ __launch_bounds__(kBlock) void k_t3_table(const uint32_t *__restrict_
             if (prow[mid] < first_row) lo = mid + 1; else hi = mid;
         }
         tstart[t] = lo;
-    }
-}
-
-// rcount[row] = the (row, slice) pairs of the row: what it contributes to pass 2 (a pair cut by a chunk boundary adds a part; the
-// row blocks are cut before the chunks are, so those are not counted)
-__global__ __launch_bounds__(kBlock) void k_t3_pair_rows(const uint32_t *__restrict__ key_s, const uint32_t *__restrict__ rowq, uint64_t nnz,
-                                                          uint32_t *__restrict__ rcount) {
-    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nnz; q += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t r = rowq[q];
-        if (q == 0 || key_s[q] != key_s[q - 1] || rowq[q - 1] != r) atomicAdd(rcount + r, 1u);  // integer counts: exact, order independent
-    }
-}
-
-// tq[rb * n_cb + cb], rb = 0 .. n_rb: the first sorted entry of slice cb whose row is >= rb_start[rb] (the slice's end for rb = n_rb)
-__global__ __launch_bounds__(kBlock) void k_t3_tile_entries(const uint32_t *__restrict__ rowq, const uint64_t *__restrict__ start, uint32_t n_cb, uint32_t n_rb,
-                                                             const uint32_t *__restrict__ rb_start, uint32_t *__restrict__ tq) {
-    const uint64_t total = (uint64_t)(n_rb + 1) * n_cb;
-    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t rb = (uint32_t)(t / n_cb), cb = (uint32_t)(t % n_cb);
-        const uint32_t first_row = rb_start[rb];
-        uint64_t lo = start[cb], hi = start[cb + 1];
-        while (lo < hi) {
-            const uint64_t mid = lo + (hi - lo) / 2;
-            if (rowq[mid] < first_row) lo = mid + 1; else hi = mid;
-        }
-        tq[t] = (uint32_t)lo;
-    }
-}
-
-// BANK ORDER.  Pass 2 adds E2 products per lane into the row sums of its block in LDS: instruction k of a round touches the rows at
-// positions E2 l + k, l = 0 .. 63.  In row order those are ~random rows -- 32 lanes of a group on 32 banks: 3.5 lanes on the busiest
-// one, 58 % of pass 2's time in LDS (profiles/r03_pmc_k2t_sq_uniform.txt).  Nothing in either pass needs the (row, slice) pairs
-// of a tile in row order (pass 1: the entries of a pair adjacent; pass 2: a tile's pairs contiguous, a pair's parts adjacent), so the
-// build orders them by bank: class b = (row - block start + 1) mod 32 (the bank of the row's sum), j = the pair's rank inside its
-// class (by row), key (j / E2, b, j mod E2).  The first stretch of a tile then holds E2 pairs of class 0, E2 of class 1, ...: lane l
-// adds into class l -- and since a class never holds more than E2 consecutive positions, positions E2 apart always differ in class,
-// whatever shifts the stretch (a short class, a padding slot): conflict-free by construction; the later stretches are shorter.
-// One wavefront per tile; a tile of more than kT3OrderMax entries keeps its row order.
-constexpr uint32_t kT3OrderMax = 1024;
-template <int E>
-__global__ __launch_bounds__(64) void k_t3_bank_order(const uint32_t *__restrict__ tq, uint32_t n_cb, uint32_t n_rb, const uint32_t *__restrict__ rb_start,
-                                                       const uint32_t *__restrict__ rowq, const uint32_t *__restrict__ perm,
-                                                       uint32_t *__restrict__ rowq_out, uint32_t *__restrict__ perm_out) {
-    __shared__ uint32_t s_row[kT3OrderMax];
-    __shared__ uint32_t s_len[kT3OrderMax];       // entries of the pair AT a new position, then their exclusive prefix sum
-    __shared__ uint16_t s_pair[kT3OrderMax];      // entry -> pair
-    __shared__ uint16_t s_head[kT3OrderMax + 1];  // pair -> its first entry
-    __shared__ uint16_t s_jb[kT3OrderMax];        // pair -> j * 32 + b, then its new position
-    __shared__ uint32_t s_cnt[32];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t t = blockIdx.x;
-    const uint32_t cb = (uint32_t)(t / n_rb), rb = (uint32_t)(t % n_rb);
-    const uint32_t row_lo = rb_start[rb];
-    const uint64_t a = tq[(size_t)rb * n_cb + cb], e = tq[(size_t)(rb + 1) * n_cb + cb];  // the tile's entries (k_t3_tile_entries)
-    const uint32_t n = (uint32_t)(e - a);
-    if (n == 0) return;
-    if (n > kT3OrderMax) {
-        for (uint32_t i = lane; i < n; i += 64) { rowq_out[a + i] = rowq[a + i]; perm_out[a + i] = perm[a + i]; }
-        return;
-    }
-    for (uint32_t i = lane; i < n; i += 64) s_row[i] = rowq[a + i];
-    if (lane < 32) s_cnt[lane] = 0;
-    __syncthreads();
-    // pairs: runs of equal rows
-    uint32_t P = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + lane;
-        const bool head = i < n && (i == 0 || s_row[i] != s_row[i - 1]);
-        const uint64_t m = __ballot(head);
-        const uint32_t upto = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) + (head ? 1u : 0u);
-        if (i < n) {
-            s_pair[i] = (uint16_t)(P + upto - 1u);
-            if (head) s_head[P + upto - 1u] = (uint16_t)i;
-        }
-        P += (uint32_t)__popcll(m);
-    }
-    if (lane == 0) s_head[P] = (uint16_t)n;
-    __syncthreads();
-    // class and rank inside the class, 64 pairs at a time (in row order)
-    for (uint32_t base = 0; base < P; base += 64) {
-        const uint32_t p = base + lane;
-        const bool valid = p < P;
-        const uint32_t b = valid ? (s_row[s_head[p]] - row_lo + 1u) & 31u : 0u;
-        uint64_t same = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 5; ++bit) {
-            const uint64_t with = __ballot((b >> bit) & 1u);
-            same &= ((b >> bit) & 1u) ? with : ~with;
-        }
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
-        const uint32_t had = valid ? s_cnt[b] : 0u;
-        __syncthreads();
-        if (valid) {
-            s_jb[p] = (uint16_t)((had + before) * 32u + b);
-            if (before + 1u == (uint32_t)__popcll(same)) s_cnt[b] = had + before + 1u;  // the last lane of the class
-        }
-        __syncthreads();
-    }
-    // new position of every pair, and the pairs' lengths in the new order
-    for (uint32_t base = 0; base < P; base += 64) {
-        const uint32_t p = base + lane;
-        if (p < P) {
-            const uint32_t j = s_jb[p] >> 5, b = s_jb[p] & 31u, jq = j / (uint32_t)E;
-            uint32_t pos = j % (uint32_t)E;
-            for (uint32_t c = 0; c < 32; ++c) {
-                const uint32_t have = s_cnt[c];
-                pos += have < (uint32_t)E * jq ? have : (uint32_t)E * jq;                               // the stretches before this one
-                if (c < b) pos += have > (uint32_t)E * jq ? (have - (uint32_t)E * jq < (uint32_t)E ? have - (uint32_t)E * jq : (uint32_t)E) : 0u;  // ... and the classes before b in it
-            }
-            s_jb[p] = (uint16_t)pos;
-            s_len[pos] = (uint32_t)s_head[p + 1] - (uint32_t)s_head[p];
-        }
-    }
-    __syncthreads();
-    // exclusive prefix sum of the lengths in the new order
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < P; base += 64) {
-        const uint32_t p = base + lane;
-        const uint32_t v = p < P ? s_len[p] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-            if ((int)lane >= o) incl += up;
-        }
-        if (p < P) s_len[p] = carry + incl - v;
-        carry += (uint32_t)__shfl((int)incl, 63, 64);
-    }
-    __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t p = s_pair[i];
-        const uint32_t to = s_len[s_jb[p]] + (i - (uint32_t)s_head[p]);
-        rowq_out[a + to] = s_row[i];
-        perm_out[a + to] = perm[a + i];
     }
 }
 
@@ -794,15 +661,56 @@ static int build_t(::smh_crs *m) {
     SMH_HIP(hipGetLastError());
     std::vector<uint64_t> start((size_t)n_cb + 1);
     SMH_HIP(hipMemcpyAsync(start.data(), d_start, start.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    // row blocks of equal PRODUCT counts (a tile = one slice of a block: ~target products whatever the row lengths), at most `cap`
-    // rows each (their sums share the LDS); greedy over the rows' (row, slice) pair counts, on the host
-    uint32_t *rcount = nullptr;
+    SMH_HIP(hipStreamSynchronize(s));
+    // chunks: ceil(entries of the slice / stride) each (a chunk whose start was moved past the slice's end stays empty)
+    std::vector<uint32_t> cptr((size_t)n_cb + 1);
+    cptr[0] = 0;
+    for (uint32_t b = 0; b < n_cb; ++b) {
+        const uint64_t cnt = start[b + 1] - start[b];
+        if (cnt >= (1ull << 32)) return fail(SMH_ERR_INVALID, "tiled variant: a column slice holds %llu entries", (unsigned long long)cnt);
+        cptr[b + 1] = cptr[b] + (uint32_t)((cnt + STRIDE - 1) / STRIDE);
+    }
+    const uint32_t n_chunks = cptr[n_cb];
+    uint32_t max_slice_chunks = 0;
+    for (uint32_t b = 0; b < n_cb; ++b) max_slice_chunks = std::max(max_slice_chunks, cptr[b + 1] - cptr[b]);
+    const uint64_t slots = (uint64_t)n_chunks * CH;
+    uint32_t *cstart = nullptr, *clen = nullptr, *obase = nullptr, *preal = nullptr, *rcount = nullptr, *prow = nullptr;
+    SMH_TRY(tmp.alloc(&cstart, (size_t)n_chunks));
+    SMH_TRY(tmp.alloc(&clen, (size_t)n_chunks));
+    SMH_TRY(tmp.alloc(&obase, (size_t)n_chunks + 1));
+    SMH_TRY(tmp.alloc(&preal, (size_t)n_chunks));
     SMH_TRY(tmp.alloc(&rcount, m->n_rows));
+    uint32_t *any_cut = nullptr;  // does any chunk boundary cut a (row, slice) pair?
+    SMH_TRY(tmp.alloc(&any_cut, 1));
+    SMH_HIP(hipMemsetAsync(any_cut, 0, sizeof(uint32_t), s));
+    SMH_HIP(hipMalloc(&m->d_t2_val, (slots + CH) * sizeof(T)));
+    SMH_HIP(hipMalloc((void **)&m->d_t2_code, (slots + CH) * sizeof(uint16_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_t3_cptr, ((size_t)n_cb + 1) * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_t3_chunk, ((size_t)n_chunks + 1) * sizeof(T3Chunk)));
+    SMH_HIP(hipMemcpyAsync(m->d_t3_cptr, cptr.data(), cptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     SMH_HIP(hipMemsetAsync(rcount, 0, (m->n_rows ? m->n_rows : 1) * sizeof(uint32_t), s));
-    if (nnz) {
-        hipLaunchKernelGGL(k_t3_pair_rows, dim3(grid), dim3(kBlock), 0, s, key_s, rowq, nnz, rcount);
+    SMH_HIP(hipMemsetAsync(obase, 0, ((size_t)n_chunks + 1) * sizeof(uint32_t), s));
+    const unsigned wgrid = (n_chunks + kBlock / 64 - 1) / (kBlock / 64);
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_t3_chunk_starts, dim3((n_chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, rowq, STRIDE, cstart);
+        SMH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_t3_fill<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, rowq, perm, m->d_col, (const T *)m->d_val,
+                           (T *)m->d_t2_val, m->d_t2_code, clen, obase);
         SMH_HIP(hipGetLastError());
     }
+    uint64_t n_prod = 0;
+    SMH_TRY(device_exclusive_scan_u32(obase, (uint64_t)n_chunks + 1, s, &n_prod));  // obase[c] = products before chunk c; obase[n_chunks] = all
+    if (n_prod >= (1ull << 32) - 4 * CH) return fail(SMH_ERR_INVALID, "tiled variant: %llu products are too many for its 32-bit index", (unsigned long long)n_prod);
+    SMH_TRY(tmp.alloc(&prow, (size_t)n_prod));
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_t3_prow<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, clen, obase, rowq, m->d_t2_code, prow, preal,
+                           rcount, (T3Chunk *)m->d_t3_chunk, any_cut);
+        SMH_HIP(hipGetLastError());
+    }
+    uint32_t h_cut = 0;
+    SMH_HIP(hipMemcpyAsync(&h_cut, any_cut, sizeof h_cut, hipMemcpyDeviceToHost, s));  // (synchronised with the row counts below)
+    // row blocks of equal PRODUCT counts (a tile = one slice of a block: ~target products whatever the row lengths), at most `cap`
+    // rows each (their sums share the LDS); greedy over the rows' product counts, on the host
     std::vector<uint32_t> rb_start;
     uint32_t n_rb = 0, R = 1;
     {
@@ -824,74 +732,15 @@ static int build_t(::smh_crs *m) {
         n_rb = (uint32_t)(rb_start.size() - 1);
         for (uint32_t b = 0; b < n_rb; ++b) R = std::max(R, rb_start[b + 1] - rb_start[b]);
     }
-    // (the row codes are byte offsets into a wavefront's sums and must fit 16 bits)
-    if (((uint64_t)R + 1) * sizeof(T) > 0xFFFFu) return fail(SMH_ERR_INVALID, "tiled variant: row blocks of %u rows do not fit the 16-bit row codes", R);
     const uint64_t table_entries = (uint64_t)(n_rb + 1) * n_cb;
     if (table_entries * 4 > (4ull << 30))
         return fail(SMH_ERR_INVALID, "tiled variant: %u column slices x %u row blocks need a tile table beyond 4 GiB", n_cb, n_rb);
-    SMH_HIP(hipMalloc((void **)&m->d_t2_rbstart, rb_start.size() * sizeof(uint32_t)));
-    SMH_HIP(hipMemcpyAsync(m->d_t2_rbstart, rb_start.data(), rb_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    SMH_HIP(hipMalloc((void **)&m->d_t2_tstart, table_entries * sizeof(uint32_t)));
-    // the pairs of every tile in bank order (k_t3_bank_order); `key` and `idx`, the sort's inputs, take the reordered rows / entries
-    static const bool order_off = getenv("SMH_TILED_ORDER") && atoi(getenv("SMH_TILED_ORDER")) == 0;  // tuning knob: 0 = row order
-    if (nnz && !order_off) {
-        const uint64_t n_tiles = (uint64_t)n_cb * n_rb;
-        if (n_tiles >= (1ull << 31)) return fail(SMH_ERR_INVALID, "tiled variant: %llu tiles", (unsigned long long)n_tiles);
-        hipLaunchKernelGGL(k_t3_tile_entries, dim3(grid), dim3(kBlock), 0, s, rowq, d_start, n_cb, n_rb, m->d_t2_rbstart, m->d_t2_tstart);  // (the tile table's buffer: rewritten below)
-        SMH_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_t3_bank_order<T3<T>::E2>, dim3((unsigned)n_tiles), dim3(64), 0, s, m->d_t2_tstart, n_cb, n_rb, m->d_t2_rbstart, rowq, perm, key, idx);
-        SMH_HIP(hipGetLastError());
-        std::swap(rowq, key);
-        std::swap(perm, idx);
-    }
-    // chunks: ceil(entries of the slice / stride) each (a chunk whose start was moved past the slice's end stays empty)
-    std::vector<uint32_t> cptr((size_t)n_cb + 1);
-    cptr[0] = 0;
-    for (uint32_t b = 0; b < n_cb; ++b) {
-        const uint64_t cnt = start[b + 1] - start[b];
-        if (cnt >= (1ull << 32)) return fail(SMH_ERR_INVALID, "tiled variant: a column slice holds %llu entries", (unsigned long long)cnt);
-        cptr[b + 1] = cptr[b] + (uint32_t)((cnt + STRIDE - 1) / STRIDE);
-    }
-    const uint32_t n_chunks = cptr[n_cb];
-    uint32_t max_slice_chunks = 0;
-    for (uint32_t b = 0; b < n_cb; ++b) max_slice_chunks = std::max(max_slice_chunks, cptr[b + 1] - cptr[b]);
-    const uint64_t slots = (uint64_t)n_chunks * CH;
-    uint32_t *cstart = nullptr, *clen = nullptr, *obase = nullptr, *preal = nullptr, *prow = nullptr;
-    SMH_TRY(tmp.alloc(&cstart, (size_t)n_chunks));
-    SMH_TRY(tmp.alloc(&clen, (size_t)n_chunks));
-    SMH_TRY(tmp.alloc(&obase, (size_t)n_chunks + 1));
-    SMH_TRY(tmp.alloc(&preal, (size_t)n_chunks));
-    uint32_t *any_cut = nullptr;  // does any chunk boundary cut a (row, slice) pair?
-    SMH_TRY(tmp.alloc(&any_cut, 1));
-    SMH_HIP(hipMemsetAsync(any_cut, 0, sizeof(uint32_t), s));
-    SMH_HIP(hipMalloc(&m->d_t2_val, (slots + CH) * sizeof(T)));
-    SMH_HIP(hipMalloc((void **)&m->d_t2_code, (slots + CH) * sizeof(uint16_t)));
-    SMH_HIP(hipMalloc((void **)&m->d_t3_cptr, ((size_t)n_cb + 1) * sizeof(uint32_t)));
-    SMH_HIP(hipMalloc((void **)&m->d_t3_chunk, ((size_t)n_chunks + 1) * sizeof(T3Chunk)));
-    SMH_HIP(hipMemcpyAsync(m->d_t3_cptr, cptr.data(), cptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    SMH_HIP(hipMemsetAsync(obase, 0, ((size_t)n_chunks + 1) * sizeof(uint32_t), s));
-    const unsigned wgrid = (n_chunks + kBlock / 64 - 1) / (kBlock / 64);
-    if (n_chunks) {
-        hipLaunchKernelGGL(k_t3_chunk_starts, dim3((n_chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, rowq, STRIDE, cstart);
-        SMH_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_t3_fill<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, rowq, perm, m->d_col, (const T *)m->d_val,
-                           (T *)m->d_t2_val, m->d_t2_code, clen, obase);
-        SMH_HIP(hipGetLastError());
-    }
-    uint64_t n_prod = 0;
-    SMH_TRY(device_exclusive_scan_u32(obase, (uint64_t)n_chunks + 1, s, &n_prod));  // obase[c] = products before chunk c; obase[n_chunks] = all
-    if (n_prod >= (1ull << 32) - 4 * CH) return fail(SMH_ERR_INVALID, "tiled variant: %llu products are too many for its 32-bit index", (unsigned long long)n_prod);
-    SMH_TRY(tmp.alloc(&prow, (size_t)n_prod));
-    if (n_chunks) {
-        hipLaunchKernelGGL(k_t3_prow<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, clen, obase, rowq, m->d_t2_code, prow, preal,
-                           (T3Chunk *)m->d_t3_chunk, any_cut);
-        SMH_HIP(hipGetLastError());
-    }
-    uint32_t h_cut = 0;
-    SMH_HIP(hipMemcpyAsync(&h_cut, any_cut, sizeof h_cut, hipMemcpyDeviceToHost, s));  // (synchronised before it is read, below)
     // (+ a round of slack: a tile's loads cover whole rounds whatever its length)
     SMH_HIP(hipMalloc(&m->d_t2_prod, (n_prod + 2 * CH) * sizeof(T)));
     SMH_HIP(hipMalloc((void **)&m->d_t2_row, (n_prod + 2 * CH) * sizeof(uint16_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_t2_tstart, table_entries * sizeof(uint32_t)));
+    SMH_HIP(hipMalloc((void **)&m->d_t2_rbstart, rb_start.size() * sizeof(uint32_t)));
+    SMH_HIP(hipMemcpyAsync(m->d_t2_rbstart, rb_start.data(), rb_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     SMH_HIP(hipMemsetAsync(m->d_t2_prod, 0, (n_prod + 2 * CH) * sizeof(T), s));
     SMH_HIP(hipMemsetAsync(m->d_t2_row, 0, (n_prod + 2 * CH) * sizeof(uint16_t), s));  // (slack: the dump slot)
     if (n_chunks) {
@@ -905,6 +754,8 @@ static int build_t(::smh_crs *m) {
     // 128 KiB and more of dynamic LDS need the attribute on every device the kernel runs on: set with each build, on the matrix's device
     for (const void *f : {reinterpret_cast<const void *>(k_t3_expand<T, 2>), reinterpret_cast<const void *>(k_t3_expand<T, 3>), reinterpret_cast<const void *>(k_t3_expand<T, 4>)})
         SMH_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T))));
+    // (the row codes are byte offsets into a wavefront's sums and must fit 16 bits)
+    if (((uint64_t)R + 1) * sizeof(T) > 0xFFFFu) return fail(SMH_ERR_INVALID, "tiled variant: row blocks of %u rows do not fit the 16-bit row codes", R);
     m->t2_n_cb = n_cb;
     m->t2_n_rb = n_rb;
     m->t2_R = R;

@@ -1,8 +1,7 @@
 """numpy restatement of K2t (sparsemat_amd/csrc/spmv_tiled.hip) -- test infrastructure, not product code.
 
 It restates (a) the BUILD: the copy by column slice, its chunks (starts snapped to row boundaries), the continuation bits, the
-product slots, the row blocks cut by (row, slice) pair counts, the BANK ORDER of every tile's pairs, the row codes and the tile
-table -- integer work, compared array by array
+product slots, the row blocks cut by product counts, the row codes and the tile table -- integer work, compared array by array
 with what the library built (smh_crs_tiled_array); and (b) the two passes' SUMMATION ORDER in the value type: the in-lane left
 fold, the Kogge-Stone segmented scan over the 64 lanes (row_shr 1, 2, 4, 8, row_bcast 15, row_bcast 31), the carry into a
 lane's first segment, and pass 2's per-slice adds (equal neighbours merged by the same fold) -- compared bit for bit with the
@@ -18,7 +17,6 @@ CAP = {np.dtype(np.float32): 3328, np.dtype(np.float64): 1664}
 
 
 E1 = 4  # entries per lane in pass 1 (a chunk = 64 E1 slots)
-ORDER_MAX = 1024  # a tile of more entries keeps its row order (kT3OrderMax)
 
 
 def lanes_per(dtype):
@@ -71,34 +69,8 @@ def fold_runs(p, cont):
     return p, tail
 
 
-def bank_order(rows, row_lo, E):
-    """k_t3_bank_order for one tile.  rows: the rows of the tile's entries in (row, storage) order.  Returns `src`: the entry at
-    new position i is old entry src[i].  Pairs = runs of equal rows; class b = (row - row_lo + 1) mod 32; j = rank of the pair in
-    its class; pairs sorted by (j // E, b, j % E); a pair's entries stay together, in their order."""
-    n = len(rows)
-    if n == 0 or n > ORDER_MAX:
-        return np.arange(n)
-    head = np.concatenate([[True], rows[1:] != rows[:-1]])
-    heads = np.flatnonzero(head)
-    pair_of = np.cumsum(head) - 1
-    b = (rows[heads] - row_lo + 1) & 31
-    j = np.zeros(len(heads), dtype=np.int64)
-    for c in range(32):
-        w = np.flatnonzero(b == c)
-        j[w] = np.arange(len(w))
-    order = np.lexsort((j % E, b, j // E))          # new pair position -> old pair
-    lens = np.diff(np.concatenate([heads, [n]]))
-    new_start = np.concatenate([[0], np.cumsum(lens[order])])[:-1]
-    newpos = np.empty(len(heads), dtype=np.int64)
-    newpos[order] = np.arange(len(heads))
-    to = new_start[newpos[pair_of]] + (np.arange(n) - heads[pair_of])
-    src = np.empty(n, dtype=np.int64)
-    src[to] = np.arange(n)
-    return src
-
-
 class TiledModel:
-    def __init__(self, off, col, val, n_rows, n_cols, target=None, cap=None, bank=True):
+    def __init__(self, off, col, val, n_rows, n_cols, target=None, cap=None):
         dt = np.dtype(val.dtype)
         self.dt, self.E = dt, lanes_per(dt)
         E = self.E
@@ -114,41 +86,6 @@ class TiledModel:
         cnt = np.bincount(sl, minlength=self.n_cb)
         start = np.concatenate([[0], np.cumsum(cnt)])
         srow, scol = rows[order], col[order]
-        # row blocks of equal product counts: greedy over the rows' (row, slice) pairs
-        rcount = np.zeros(n_rows, dtype=np.int64)
-        for s in range(self.n_cb):
-            r = srow[start[s]:start[s + 1]]
-            if len(r):
-                rcount += np.bincount(r[np.concatenate([[True], r[1:] != r[:-1]])], minlength=n_rows)
-        target = TARGET[dt] if target is None else target
-        cap = CAP[dt] if cap is None else cap
-        per_block = int(target * self.n_cb)
-        rb = []
-        r = 0
-        while r < n_rows:
-            rb.append(r)
-            have_n, e = 0, r
-            while e < n_rows and e - r < cap and (e == r or have_n + rcount[e] <= per_block):
-                have_n += rcount[e]
-                e += 1
-            r = e
-        if not rb:
-            rb.append(0)
-        rb.append(n_rows)
-        self.rb_start = np.array(rb, dtype=np.uint32)
-        self.n_rb = len(rb) - 1
-        self.R = int(max(1, np.diff(self.rb_start.astype(np.int64)).max()))
-        # every tile's pairs in bank order
-        if bank:
-            rbs = self.rb_start.astype(np.int64)
-            for s in range(self.n_cb):
-                q0, q1 = int(start[s]), int(start[s + 1])
-                cut = q0 + np.searchsorted(srow[q0:q1], rbs, side="left")
-                for k in range(self.n_rb):
-                    a, e = int(cut[k]), int(cut[k + 1])
-                    if e > a:
-                        src = a + bank_order(srow[a:e], int(rbs[k]), E)
-                        order[a:e], srow[a:e], scol[a:e] = order[src], srow[src], scol[src]
         self.order = order
         # chunks
         slice_chunks = [0]
@@ -217,6 +154,26 @@ class TiledModel:
             if c_slice[c + 1] == c_slice[c] and self.c_len[c] and self.c_len[c + 1] and row_s[c + 1][0] == row_s[c][self.c_len[c] - 1]:
                 counts[obase[c]:obase[c + 1]] = True
         self.counts = counts  # slots that take part in pass 2 (real ones + the zero padding of cut pairs)
+        # row blocks of equal product counts
+        rcount = np.bincount(prow[real], minlength=n_rows) if self.n_prod else np.zeros(n_rows, dtype=np.int64)
+        target = TARGET[dt] if target is None else target
+        cap = CAP[dt] if cap is None else cap
+        per_block = int(target * self.n_cb)
+        rb = []
+        r = 0
+        while r < n_rows:
+            rb.append(r)
+            have_n, e = 0, r
+            while e < n_rows and e - r < cap and (e == r or have_n + rcount[e] <= per_block):
+                have_n += rcount[e]
+                e += 1
+            r = e
+        if not rb:
+            rb.append(0)
+        rb.append(n_rows)
+        self.rb_start = np.array(rb, dtype=np.uint32)
+        self.n_rb = len(rb) - 1
+        self.R = int(max(1, np.diff(self.rb_start.astype(np.int64)).max()))
         blk = np.searchsorted(self.rb_start[1:].astype(np.int64), prow, side="right")
         blk = np.minimum(blk, self.n_rb - 1)
         # (the byte offset of the row's sum in pass 2's LDS: slot 0 is the dump slot)
@@ -225,8 +182,8 @@ class TiledModel:
         pb = obase[self.slice_chunks.astype(np.int64)]
         ts = np.zeros((self.n_rb + 1, self.n_cb), dtype=np.uint32)
         for s in range(self.n_cb):
-            # (inside a slice the products are ordered by row BLOCK, not by row)
-            ts[:, s] = pb[s] + np.searchsorted(blk[pb[s]:pb[s + 1]], np.arange(self.n_rb + 1), side="left")
+            seg = prow[pb[s]:pb[s + 1]]
+            ts[:, s] = pb[s] + np.searchsorted(seg, self.rb_start.astype(np.int64), side="left")
         self.tile_start = ts
 
     def products(self, val, x):
