@@ -55,11 +55,11 @@ def build(force=False, verbose=False, extra_flags=(), out=None, objsuffix=""):
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = []
     for s, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            failed.append((s, out.decode(errors="replace")))
-        elif verbose and out:
-            print(out.decode(errors="replace"))
+            failed.append((s, log.decode(errors="replace")))
+        elif verbose and log:
+            print(log.decode(errors="replace"))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join("%s:\n%s" % f for f in failed))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
