@@ -532,7 +532,7 @@ static int ensure_stream_codes(smh_crs *m) {
     uint32_t *d_count = nullptr, h_count = 0;
     SMH_HIP(hipMalloc((void **)&m->d_stream_cwin, n_tiles * 8 * sizeof(uint32_t)));
     SMH_HIP(hipMalloc((void **)&d_count, sizeof(uint32_t)));
-    int rc = launch_stream_windows(m->d_off, m->d_col, m->n_rows, true, m->d_stream_cwin, d_count, m->stream);
+    int rc = launch_stream_windows(m->d_off, m->d_col, m->n_rows, m->d_stream_cwin, d_count, m->stream);
     hipError_t e = hipSuccess;
     if (rc == SMH_OK) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, m->stream);
     if (rc == SMH_OK && e == hipSuccess) e = hipStreamSynchronize(m->stream);

@@ -43,7 +43,6 @@ constexpr int kRingEntriesWide = 32768;  // ... f32 only, for rows that need it:
 constexpr int kStreamRows = kBlock;    // K1s: rows per tile (one thread folds one row)
 constexpr int kStreamCap = 4096;       // K1s: entries of a tile staged in LDS
 constexpr int kStreamCapSmall = 2045;  // K1s: ... when no tile holds more (two 16-byte chunks per thread from an aligned start)
-constexpr int kStreamXWin = 3072;      // K1s-w: x entries of a tile's column intervals staged in LDS
 constexpr int kStreamCodeWidth = 16384;  // K1s 16-bit column codes: columns per interval (14 bits) x 4 intervals
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
@@ -72,7 +71,7 @@ int launch_spmv_stream(int dtype, const uint32_t *off, const uint32_t *col, cons
 int launch_stream_xs_stats(const uint32_t *win, size_t n_tiles, uint32_t *d_out2, hipStream_t s);
 int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32_t *tbase, hipStream_t s);
 size_t stream_tiles(size_t n_rows, int rows_per_thread);
-int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, bool for_codes, uint32_t *win,
+int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win,
                           uint32_t *d_count, hipStream_t s);
 int launch_stream_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint16_t *code,
                         hipStream_t s);

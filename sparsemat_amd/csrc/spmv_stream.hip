@@ -17,11 +17,12 @@
 // Product rounded, then added in storage order: this is exactly the reference's `sum += rhs.get(j) * val`
 // -- K1s is BIT-EXACT against the reference loop (like the SEQ checker), not merely within tolerance.
 //
-// x WINDOWS (K1s-w).  The gathers are what keeps the address path busy (7 stencil arms interleaved over the
-// lanes: ~14 cache lines per gather instruction).  An inspector (create time, one wave per tile) describes the
-// columns a tile references as up to 4 disjoint intervals (a stencil tile: the 3 planes it touches) of at
-// most kStreamXWin entries in total; the kernel then copies those intervals into LDS with coalesced loads
-// and gathers from LDS.  A tile without such a description (columns all over x) gathers from L2 as before.
+// x STAGED IN LDS (K1s XS; its successor K1s XD lives in spmv_stream_xd.hip).  The gathers are what keeps the address path busy (7
+// stencil arms interleaved over the lanes: ~14 cache lines per gather instruction).  An inspector (plan time, one wave per tile)
+// describes the columns a tile references as up to 4 disjoint intervals (a stencil tile: the planes it touches; a span beyond 1024
+// columns is cut at its widest gaps); the 16-bit column codes are relative to them, and when the intervals of every tile fit a
+// 2048- or 4096-entry stage the kernel copies them to LDS with 16-byte loads issued BEFORE the tile's own chunk loads and gathers
+// from LDS.  (Round 1's K1s-w staged x with 4-byte loads in a phase of its own and lost by 0.9 ms; it left the library in round 3.)
 //
 // ANY ROW LENGTH.  A tile with more entries than the LDS product stage holds (4096) is taken in several passes
 // over the stage; a row that straddles passes carries its accumulator, so the adds stay in storage order:
@@ -46,7 +47,7 @@ __device__ __forceinline__ double st_add(double a, double b) { return __dadd_rn(
 // win[8*t + 2k], win[8*t + 2k + 1] = [lo, hi) of interval k (sorted, disjoint; hi == lo: unused).  All zero:
 // the tile has no window (gathers go to L2).  Limits: a tile qualifies when it holds at most max_entries entries,
 // every interval is at most max_width columns wide and the intervals hold at most max_total columns together
-// (K1s-w: what fits the LDS stage; 16-bit column codes: 16384 per interval, nothing else; there a tile WITHOUT
+// (the 16-bit column codes: 16384 per interval, nothing else; K1r's banded ring: a quarter of the ring per interval; a tile WITHOUT
 // entries counts as described).
 __global__ void __launch_bounds__(kBlock)
 k_stream_windows(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, uint64_t n_rows, uint64_t n_tiles,
@@ -635,21 +636,17 @@ int launch_stream_len8(const uint32_t *off, size_t n_rows, uint8_t *len8, uint32
     return SMH_OK;
 }
 
-// for_codes: intervals for the 16-bit column codes (any tile size, <= 16384 columns per interval; tiles without
-// entries count as described) instead of the K1s-w LDS windows (single-pass tiles, <= kStreamXWin columns in total)
-int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, bool for_codes, uint32_t *win,
-                          uint32_t *d_count, hipStream_t s) {
+// the intervals the 16-bit column codes are relative to: 256-row tiles of any size, <= 16384 columns per interval, tiles without
+// entries count as described; a span beyond 1024 columns is split where it has gaps (what K1s XS / XD stage of x is the
+// intervals' total)
+int launch_stream_windows(const uint32_t *off, const uint32_t *col, size_t n_rows, uint32_t *win, uint32_t *d_count, hipStream_t s) {
     const uint64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
     SMH_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
     if (n_tiles == 0) return SMH_OK;
     uint64_t blocks = (n_tiles * kWave + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;
-    const uint64_t max_entries = for_codes ? ~uint64_t(0) : (uint64_t)kStreamCap;
-    const uint64_t max_width = for_codes ? (uint64_t)kStreamCodeWidth : (uint64_t)kStreamXWin;
-    const uint64_t max_total = for_codes ? ~uint64_t(0) : (uint64_t)kStreamXWin;
-    // (codes: a span beyond 1024 columns is split where it has gaps -- what K1s XS / XD stage of x is the intervals' total)
     hipLaunchKernelGGL(k_stream_windows, dim3((unsigned)blocks), dim3(kBlock), 0, s, off, col, (uint64_t)n_rows, n_tiles,
-                       (uint64_t)kStreamRows, max_entries, max_width, max_total, for_codes ? (uint64_t)1024 : max_width, for_codes, win, d_count);
+                       (uint64_t)kStreamRows, ~uint64_t(0), (uint64_t)kStreamCodeWidth, ~uint64_t(0), (uint64_t)1024, true, win, d_count);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
