@@ -51,6 +51,8 @@ extern "C" {
                           ops: *const u8, out: *mut *mut smh_crs) -> c_int;
     pub fn smh_crs_transpose(a: *const smh_crs, out: *mut *mut smh_crs) -> c_int;
     pub fn smh_crs_set_stream_xs(m: *mut smh_crs, mode: c_int) -> c_int;  // K1s with x staged in LDS: -1 auto, 0 never, 1 whenever the tiles allow
+    pub fn smh_crs_set_stream_direct(m: *mut smh_crs, mode: c_int) -> c_int;  // K1s XD (stage offsets instead of column codes): -1 auto, 0 never, 1 whenever x is staged
+    pub fn smh_crs_stream_direct(m: *mut smh_crs, direct_out: *mut c_int) -> c_int;
     pub fn smh_crs_stream_layout(m: *mut smh_crs, coded_out: *mut c_int, byte_lengths_out: *mut c_int, small_tiles_out: *mut c_int, xs_chunks_out: *mut c_int) -> c_int;
     pub fn smh_last_transpose_route() -> c_int;  // 0 general (device-wide sort), 1 two bucketed passes: diagnostics only
     pub fn smh_crs_orphans(m: *const smh_crs) -> usize;

@@ -173,6 +173,11 @@ def test_stream_16bit_column_codes_bit_exact(gpu, dtype):
     off, col, val = m.raw_parts()
     x = oracle.gen_x(synth.SEED_X, 11 * 7 * 5, np.float32)
     assert np.array_equal(bits(_with_codes("1", lambda: m.mvp(x, variant="stream"))), bits(oracle.spmv(off, col, val, x)))
+    # ... and through K1s XD: its buffer descriptors end with the tile's entries, so nothing past the borrowed arrays' end is read
+    m.set_stream_xs(1)
+    m.set_stream_direct(1)
+    assert m.stream_direct()
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x)))
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
