@@ -164,7 +164,7 @@ template <typename T, int AHEAD>
 __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
                                                                  const uint16_t *__restrict__ code, const uint32_t *__restrict__ cptr,
                                                                  const T3Chunk *__restrict__ chunk, T *__restrict__ prod, uint32_t parts,
-                                                                 uint32_t n_items, uint32_t xcd_map) {
+                                                                 uint32_t n_items, uint32_t per_xcd) {
     using V = typename T3<T>::V1;
     using V2 = typename T3<T>::V2;
     constexpr int E = T3<T>::E1, E2 = T3<T>::E2;
@@ -174,15 +174,46 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
     T *xs = (T *)t3_smem;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     T *stage = xs + kT3Slice + wave * CH;
-    // workgroups b, b + 8, ... share an XCD (round-robin dispatch): an XCD gets a contiguous run of (slice, part) pairs, so the
-    // parts of a slice stage its x from one L2 instead of fetching it into eight (a speed hint only)
-    uint32_t g = blockIdx.x;
-    if (xcd_map) g = (blockIdx.x & 7u) * ((gridDim.x + 7u) / 8u) + (blockIdx.x >> 3);
-    if (g >= n_items) return;  // (the remapped grid is rounded up to a multiple of 8; whole workgroup, before the barrier)
-    const uint32_t cb = g / parts, part = g % parts;
-    const uint64_t col0 = (uint64_t)cb * kT3Slice;
-    for (uint32_t i = threadIdx.x; i < kT3Slice; i += kT3ExpandThreads) xs[i] = col0 + i < x_len ? x[col0 + i] : T(0);
+    // PERSISTENT workgroups (the grid is what the chip holds at once): workgroups b, b + 8, ... share an XCD (round-robin dispatch);
+    // an XCD gets a contiguous run of `per_xcd` (slice, part) items -- the parts of a slice then stage its x from one L2 instead of
+    // fetching it into eight -- and its workgroups deal them out among themselves.  While an item's chunks are folded the NEXT item's
+    // slice of x is already on its way into registers (16 values per thread), so a workgroup pays the latency of staging x once,
+    // not once per item: without the staging pass 1 ran 5-13 % faster, f64 -- one workgroup per CU, nobody to overlap with --
+    // the most.  (per_xcd == 0, the knob's other setting: the items are dealt round-robin over all workgroups.)
+    uint32_t g, g_step, g_end;
+    if (per_xcd) {
+        const uint32_t xcd = blockIdx.x & 7u;
+        g = xcd * per_xcd + (blockIdx.x >> 3);
+        g_step = gridDim.x >> 3;
+        g_end = (xcd + 1u) * per_xcd < n_items ? (xcd + 1u) * per_xcd : n_items;
+    } else {
+        g = blockIdx.x;
+        g_step = gridDim.x;
+        g_end = n_items;
+    }
+    if (g >= g_end) return;  // (whole workgroup, before any barrier)
+    constexpr int NP = (int)(kT3Slice / kT3ExpandThreads);  // values of x per thread and slice
+    T pre[NP];
+    // (buffer loads whose descriptor ends with x -- or holds nothing when there is no next item --: no branch around a load, see below)
+    auto fetch = [&](uint32_t item, bool any) {  // the slice of `item` into registers (columns past x_len: zero)
+        const uint64_t c0 = (uint64_t)(item / parts) * kT3Slice;
+        const uint64_t left = any && c0 < x_len ? x_len - c0 : 0;
+        const uint32_t have = (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < kT3Slice ? (uint32_t)left : kT3Slice));
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (have ? c0 : 0)), 0, (int)(have * sizeof(T)), kT3Rsrc);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const uint32_t at = (threadIdx.x + (uint32_t)u * kT3ExpandThreads) * (uint32_t)sizeof(T);
+            if constexpr (sizeof(T) == 4) pre[u] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)at, 0, 0));
+            else pre[u] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rx, (int)at, 0, 0));
+        }
+    };
+    fetch(g, true);
+  for (;;) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) xs[threadIdx.x + (uint32_t)u * kT3ExpandThreads] = pre[u];
     __syncthreads();
+    const bool more = g + g_step < g_end;  // (workgroup-uniform)
+    const uint32_t cb = g / parts, part = g % parts;
     const uint32_t c_lo = cptr[cb], c_hi = cptr[cb + 1];
     const uint32_t per = (c_hi - c_lo + parts - 1) / parts;
     const uint32_t k0 = c_lo + part * per, k1 = k0 + per < c_hi ? k0 + per : c_hi;
@@ -201,6 +232,11 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
         my_ob = d.obase;
         my_ln = d.len;
     }
+    // the next item's slice: requested AFTER the descriptors (loads return in order: the chunk loop must not wait for the slice to
+    // get its first descriptor) and before this item's chunks, whose latency it shares
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(g + g_step, more);
+    __builtin_amdgcn_sched_barrier(0);
     // Loads and stores go through BUFFER instructions whose descriptor covers exactly the chunk's pieces: a lane past them reads
     // zeros / stores nothing, without a branch -- a branch around a load or store makes the compiler drain every load in flight
     // before the next use (it cannot count them any more), which is what kept the first form of this loop at one chunk in flight.
@@ -270,6 +306,10 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
             issue(S[u], i + u + AHEAD);
         }
     }
+    if (!more) break;
+    g += g_step;
+    __syncthreads();  // every wavefront is done with this slice before the next one overwrites it
+  }
 }
 
 // ---- pass 2 -----------------------------------------------------------------------------------------------------------
@@ -834,12 +874,25 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
         // (a wavefront keeps the descriptors of its chunks in one register: at most 64 chunks each, 1024 per workgroup)
         const uint32_t need = (m->t3_max_slice_chunks + 1023u) / 1024u;
         if (parts < need) parts = need;
-        // (the remapped grid is rounded up to a multiple of 8 so that every XCD's run has the same length)
-        const uint32_t g1 = m->t2_n_cb * parts, g1r = (xcd_map & 1u) ? (g1 + 7u) & ~7u : g1;
+        const uint32_t g1 = m->t2_n_cb * parts;  // (slice, part) items
         static const int ahead = getenv("SMH_TILED_AHEAD") ? atoi(getenv("SMH_TILED_AHEAD")) : kT3Ahead;  // tuning knob: chunks in flight per wavefront
         auto *exp = ahead == 2 ? k_t3_expand<T, 2> : ahead == 4 ? k_t3_expand<T, 4> : k_t3_expand<T, 3>;
-        hipLaunchKernelGGL(exp, dim3(g1r), dim3(kT3ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val, m->d_t2_code,
-                           m->d_t3_cptr, (const T3Chunk *)m->d_t3_chunk, (T *)m->d_t2_prod, parts, g1, xcd_map & 1u);
+        // persistent workgroups: as many as the device holds at once (a multiple of 8: every XCD the same number), never more than items
+        static int held_cache[64][2] = {};  // per device and value type; (racing threads compute the same value)
+        int &held = held_cache[m->device & 63][sizeof(T) == 8];
+        if (held == 0) {
+            int per_cu = 0;
+            SMH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, exp, kT3ExpandThreads, lds1));
+            hipDeviceProp_t prop;
+            const int cus = hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            held = (per_cu < 1 ? 1 : per_cu) * cus;
+        }
+        uint32_t wgs = (uint32_t)held & ~7u;
+        if (wgs < 8) wgs = 8;
+        const uint32_t per_xcd = (xcd_map & 1u) ? (g1 + 7u) / 8u : 0u;
+        if ((xcd_map & 1u) ? wgs / 8u > per_xcd : wgs > g1) wgs = (xcd_map & 1u) ? (per_xcd ? per_xcd * 8u : 8u) : (g1 ? g1 : 1u);
+        hipLaunchKernelGGL(exp, dim3(wgs), dim3(kT3ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val, m->d_t2_code,
+                           m->d_t3_cptr, (const T3Chunk *)m->d_t3_chunk, (T *)m->d_t2_prod, parts, g1, per_xcd);
         SMH_HIP(hipGetLastError());
     }
     // pass 2: one wavefront = one workgroup per row block
