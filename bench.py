@@ -470,7 +470,7 @@ def main():
         return
 
     # cold: the same launch after 512 MiB of stores flushed L2 and the Infinity Cache (N = 1 only)
-    cold = None
+    cold = cold_reads = None
     if n_gpus == 1:
         flush = synth.DeviceBuffer(FLUSH_BYTES)
         cev = Events(lib, check, 20)
@@ -481,7 +481,19 @@ def main():
             cev.stop(i, stream)
         sync()
         cold = stats(cev.times_ms())
-        del flush
+        # ... and after 512 MiB of READS (a dot product of the flush buffer with itself): the caches hold nothing of the product's
+        # either, but no dirty lines -- the stores above leave ~290 MB of them, written back while the timed launch runs
+        scratch, res = synth.DeviceBuffer(int(lib.smh_blas_dot_scratch_bytes())), synth.DeviceBuffer(8)
+        rev = Events(lib, check, 21)
+        for i in range(21):
+            check(lib.smh_blas_dot_dev(0, C.c_void_p(flush.ptr), C.c_void_p(flush.ptr), FLUSH_BYTES // 4, C.c_void_p(res.ptr),
+                                       C.c_void_p(scratch.ptr), C.c_void_p(stream)))
+            rev.start(i, stream)
+            spmv()
+            rev.stop(i, stream)
+        sync()
+        cold_reads = stats(rev.times_ms()[1:])  # (the first one still meets the memsets' dirty lines)
+        del flush, scratch, res
 
     # rides along (N = 1, plain path): the other column pattern on the same box in the same process -- the rounds before this
     # one put the headline on the stratified subset of SURVEY 8d's window matrices; both numbers stay visible
@@ -559,6 +571,12 @@ def main():
                 "kernel_ms_median": cold["median"], "kernel_ms_min": cold["min"], "kernel_ms_max": cold["max"],
                 "launches": cold["launches"], "frac": bytes_gpu / (cold["median"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "frac_traffic": (traffic / (cold["median"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            },
+            "cold_after_reads": None if cold_reads is None else {
+                "flush": "%d MiB of READS before every launch (nothing of the product in L2 / Infinity Cache, no dirty lines to write back)" % (FLUSH_BYTES >> 20),
+                "kernel_ms_median": cold_reads["median"], "kernel_ms_min": cold_reads["min"], "kernel_ms_max": cold_reads["max"],
+                "launches": cold_reads["launches"], "frac": bytes_gpu / (cold_reads["median"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_traffic": (traffic / (cold_reads["median"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
             },
             "layout": "f32 values + 16-bit ring-slot columns for LDS-ring phases (u32 columns kept for the rest)",
         },

@@ -36,6 +36,7 @@ def test_single_gpu_line(gpu):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches"] == 7 and r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"] and r["traffic"] is None
     assert r["cold"]["launches"] == 20
+    assert r["cold_after_reads"]["launches"] == 20 and r["cold_after_reads"]["kernel_ms_median"] > 0
     assert abs(d["value"] - d["algorithmic_bytes_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.02
     c = d["cpu_baseline"]
