@@ -869,12 +869,10 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
         // (round 2's measurement, profiles/r02_tiled_pass1.log) = 16 chunks per wavefront
         const uint64_t per_slice = (uint64_t)m->t3_n_chunks * CH / (m->t2_n_cb ? m->t2_n_cb : 1);
         uint32_t parts = (uint32_t)((per_slice + 32768) / 65536);
-        if (const char *e = getenv("SMH_TILED_PARTS")) { const int v = atoi(e); if (v >= 1) parts = (uint32_t)v; }  // tuning knob
         parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
         // (a wavefront keeps the descriptors of its chunks in one register: at most 64 chunks each, 1024 per workgroup)
         const uint32_t need = (m->t3_max_slice_chunks + 1023u) / 1024u;
         if (parts < need) parts = need;
-        const uint32_t g1 = m->t2_n_cb * parts;  // (slice, part) items
         static const int ahead = getenv("SMH_TILED_AHEAD") ? atoi(getenv("SMH_TILED_AHEAD")) : kT3Ahead;  // tuning knob: chunks in flight per wavefront
         auto *exp = ahead == 2 ? k_t3_expand<T, 2> : ahead == 4 ? k_t3_expand<T, 4> : k_t3_expand<T, 3>;
         // persistent workgroups: as many as the device holds at once (a multiple of 8: every XCD the same number), never more than items
@@ -889,6 +887,24 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
         }
         uint32_t wgs = (uint32_t)held & ~7u;
         if (wgs < 8) wgs = 8;
+        // the items are dealt out statically, so the pass lasts as long as the workgroup with the most of them: among the part counts
+        // near the one above take the one whose items divide most evenly (611 slices x 8 parts over 512 workgroups: 10 against 9.5 on
+        // average, 5 % lost; x 10 parts: 12 against 11.9 -- measured 572 against 586-601 us on f32, 1015-1044 against 1051 on f64)
+        auto longest = [&](uint32_t c) {  // items of the busiest workgroup
+            const uint64_t items = (uint64_t)m->t2_n_cb * c;
+            return (xcd_map & 1u) ? ((items + 7) / 8 + wgs / 8 - 1) / (wgs / 8) : (items + wgs - 1) / wgs;
+        };
+        {
+            const uint32_t lo = std::max(need, std::max(1u, parts * 5 / 8)), hi = std::min(64u, parts + parts / 2);
+            uint32_t best = parts;
+            for (uint32_t c = lo; c <= hi; ++c)  // cost = longest(c) / c, compared as cross products; ties: the nearer to the target
+                if (longest(c) * best < longest(best) * c ||
+                    (longest(c) * best == longest(best) * c && (c > parts ? c - parts : parts - c) < (best > parts ? best - parts : parts - best)))
+                    best = c;
+            parts = best;
+        }
+        if (const char *e = getenv("SMH_TILED_PARTS")) { const int v = atoi(e); if (v >= (int)need && v <= 64) parts = (uint32_t)v; }  // tuning knob
+        const uint32_t g1 = m->t2_n_cb * parts;  // (slice, part) items
         const uint32_t per_xcd = (xcd_map & 1u) ? (g1 + 7u) / 8u : 0u;
         if ((xcd_map & 1u) ? wgs / 8u > per_xcd : wgs > g1) wgs = (xcd_map & 1u) ? (per_xcd ? per_xcd * 8u : 8u) : (g1 ? g1 : 1u);
         hipLaunchKernelGGL(exp, dim3(wgs), dim3(kT3ExpandThreads), lds1, s, (const T *)x, (uint64_t)x_len, (const T *)m->d_t2_val, m->d_t2_code,
