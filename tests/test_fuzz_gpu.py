@@ -248,3 +248,68 @@ def test_fuzz_transpose_routes_agree(gpu):
             assert (t.n_rows(), t.n_cols()) == (e[0], e[1]) and np.array_equal(t_off[:e[0] + 1], e[2]) and np.array_equal(t_col, e[3]), what
             assert t_val.tobytes() == e[4].tobytes(), what
     assert taken["bucketed"] >= 40 and taken["general"] >= 10, taken
+
+
+def _short_row_matrix(rng, n_rows, dtype):
+    """Rows of 0..9 entries (a few longer), columns in up to four clusters around the diagonal: the shapes K1s XS / XD stage x for."""
+    n_cols = n_rows + int(rng.integers(0, 50))
+    lens = rng.integers(0, int(rng.integers(2, 10)), n_rows)
+    if rng.random() < 0.5:
+        lens[rng.integers(0, n_rows, max(1, n_rows // 300))] = rng.integers(9, 60)   # rows beyond the eight masked adds
+    if rng.random() < 0.3:
+        lens[int(rng.integers(0, n_rows)):][:int(rng.integers(1, 700))] = 0               # a run of empty rows (whole tiles of them)
+    off = np.zeros(n_rows + 1, dtype=np.uint32)
+    np.cumsum(lens, out=off[1:])
+    nnz = int(off[-1])
+    rows = np.repeat(np.arange(n_rows), lens)
+    arms = np.array([0] + [int(v) for v in rng.integers(-3000, 3000, int(rng.integers(0, 4)))])
+    col = np.clip(rows + arms[rng.integers(0, len(arms), nnz)] + rng.integers(-40, 41, nnz), 0, n_cols - 1).astype(np.uint32)
+    return n_cols, off, col, rng.uniform(-1, 1, nnz).astype(dtype), rng.uniform(-1, 1, n_cols).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_fuzz_stream_with_x_staged(gpu, dtype):
+    """K1s with x staged in LDS, both bodies (column codes / stage offsets), forced on random short-row matrices around the tile
+    boundaries: bit-exact against the oracle whatever the layout decides (a matrix whose tiles do not fit a stage keeps the gathers)."""
+    rng = np.random.default_rng(777)
+    bits = np.uint32 if dtype == np.float32 else np.uint64
+    trials = int(__import__("os").environ.get("SMH_FUZZ_TRIALS", "40"))
+    staged = 0
+    for trial in range(trials):
+        n_rows = int(rng.choice([255, 256, 257, 511, 513, 1000, 4099, 20000, 70001]))
+        n_cols, off, col, val, x = _short_row_matrix(rng, n_rows, dtype)
+        what = "trial %d: %d x %d, nnz %d" % (trial, n_rows, n_cols, len(val))
+        y_ref = oracle.spmv(off, col, val, x)
+        m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+        lhs = rng.uniform(-1, 1, n_rows).astype(dtype)
+        ip_plain = m.inner_prod(lhs, x, variant="stream")
+        m.set_stream_xs(1)
+        for direct in (0, 1, -1):
+            m.set_stream_direct(direct)
+            y = m.mvp(x, variant="stream")
+            assert np.array_equal(y.view(bits), y_ref.view(bits)), (what, direct, m.stream_layout(), m.stream_direct())
+            assert m.inner_prod(lhs, x, variant="stream") == ip_plain, (what, direct)
+        staged += m.stream_layout()["xs_chunks"] != 0
+    assert staged >= trials // 2   # most of these matrices are what the staged bodies are for
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_fuzz_tiled(gpu, dtype):
+    """K2t on random shapes over 1..6 column slices (row lengths from empty to thousands, banded or scattered columns, duplicates):
+    within the parity bound, and the same bits on a second launch."""
+    rng = np.random.default_rng(4242)
+    bits = np.uint32 if dtype == np.float32 else np.uint64
+    trials = int(__import__("os").environ.get("SMH_FUZZ_TRIALS", "24"))
+    for trial in range(trials):
+        n_rows = int(rng.choice([1, 63, 257, 1000, 4100, 9001, 30000]))
+        n_cols, off, col, val, x = _matrix(rng, n_rows, dtype)
+        # stretch the columns over several slices (the generator stays below 3 n_rows + 5 columns)
+        stretch = int(rng.integers(1, 1 + max(1, (6 * 16384) // max(n_cols, 1))))
+        n_cols2 = n_cols * stretch
+        col2 = (col.astype(np.int64) * stretch + rng.integers(0, stretch, len(col))).astype(np.uint32)
+        x2 = rng.uniform(-1, 1, n_cols2).astype(dtype)
+        what = "trial %d: %d x %d, nnz %d" % (trial, n_rows, n_cols2, len(val))
+        m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols2, off, col2, val)
+        y = m.mvp(x2, variant="tiled")
+        assert_spmv_close(y, off, col2, val, x2, what + " tiled")
+        assert np.array_equal(y.view(bits), m.mvp(x2, variant="tiled").view(bits)), what
