@@ -323,30 +323,36 @@ struct T3Tiles {
 // tstart[rb * n_cb + cb] = index (into prod / rowc) of the first product of tile (cb, rb); row n_rb of the table holds the ends of
 // the last row block's tiles.  rowc: (the product's row relative to its block + 1) * sizeof(T) -- the byte offset of the row's sum
 // in the wavefront's LDS -- or 0, the dump slot, for padding (so a lane past the tile, which reads zeros, lands there too).
-// One wavefront per workgroup: LDS = (R + 1) sums.  DUPS: the copy has (row, slice) pairs cut by a chunk boundary, i.e. a tile
-// may hold equal neighbours (checked per round; merged first); without them the rows of a round are distinct by construction.
+// One wavefront per row block, its (R + 1) sums in LDS at `stride` bytes per wavefront; the blockDim / 64 wavefronts of a workgroup
+// own ADJACENT row blocks and meet at a barrier before every batch of tiles, so that the workgroup's loads of a slice -- neighbours
+// in memory -- are issued together (launch_t says what that is worth).  Nothing else is shared: the sums, the adds and their order are
+// each wavefront's own.  DUPS: the copy has (row, slice) pairs cut by a chunk boundary, i.e. a tile may hold equal neighbours
+// (checked per round; merged first); without them the rows of a round are distinct by construction.
 template <typename T, bool DUPS, int NB>
-__global__ __launch_bounds__(64) void k_t3_reduce(const T *__restrict__ prod, const uint16_t *__restrict__ rowc,
+__global__ __launch_bounds__(1024) void k_t3_reduce(const T *__restrict__ prod, const uint16_t *__restrict__ rowc,
                                                    const uint32_t *__restrict__ tstart, uint32_t n_cb, uint32_t n_rb,
-                                                   const uint32_t *__restrict__ rb_start, T *__restrict__ y, uint32_t xcd_map) {
+                                                   const uint32_t *__restrict__ rb_start, T *__restrict__ y, uint32_t xcd_map, uint32_t stride) {
     using V = typename T3<T>::V2;
     using C = typename T3<T>::C2;
     constexpr int E = T3<T>::E2;
     constexpr uint32_t RND = 64u * E;
     extern __shared__ __attribute__((aligned(16))) char t3_smem[];
-    const uint32_t lane = threadIdx.x;
-    uint32_t rb = blockIdx.x;  // neighbouring row blocks' tiles share cache lines: neighbours on one XCD (one L2)
-    if (xcd_map) rb = (blockIdx.x & 7u) * ((gridDim.x + 7u) / 8u) + (blockIdx.x >> 3);
-    if (rb >= n_rb) return;
-    T *acc = (T *)t3_smem;  // [0]: dump; [1 + i]: row r0 + i
-    const uint32_t r0 = rb_start[rb], rows = rb_start[rb + 1] - r0;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t gb = blockIdx.x;  // neighbouring row blocks' tiles share cache lines: neighbours on one XCD (one L2)
+    if (xcd_map) gb = (blockIdx.x & 7u) * ((gridDim.x + 7u) / 8u) + (blockIdx.x >> 3);
+    const uint32_t rbq = gb * (blockDim.x >> 6) + wv;
+    const bool live = rbq < n_rb;  // (a wavefront without a row block still keeps every barrier: it walks empty tiles)
+    const uint32_t rb = live ? rbq : 0u;
+    char *accb = t3_smem + (size_t)wv * stride;
+    T *acc = (T *)accb;  // [0]: dump; [1 + i]: row r0 + i
+    const uint32_t r0 = rb_start[rb], rows = live ? rb_start[rb + 1] - r0 : 0u;
     for (uint32_t i = lane; i <= rows; i += 64) acc[i] = T(0);
     const uint32_t *ts0 = tstart + (size_t)rb * n_cb, *ts1 = ts0 + n_cb;
     auto table = [&](uint32_t t, uint32_t &base, uint32_t &len) {  // lane l: tile t + l
         const uint32_t cbl = t + lane;
         base = 0;
         len = 0;
-        if (cbl < n_cb) {
+        if (cbl < n_cb && live) {
             base = ts0[cbl];
             len = ts1[cbl] - base;
         }
@@ -417,9 +423,9 @@ __global__ __launch_bounds__(64) void k_t3_reduce(const T *__restrict__ prod, co
         // ~150 cycles per wavefront instruction; ds_add_f64 no faster than the three instructions it replaces.)
         T s[E];
 #pragma unroll
-        for (int k = 0; k < E; ++k) s[k] = *(const T *)(t3_smem + r[k]);
+        for (int k = 0; k < E; ++k) s[k] = *(const T *)(accb + r[k]);
 #pragma unroll
-        for (int k = 0; k < E; ++k) *(T *)(t3_smem + r[k]) = s[k] + p[k];  // (unconditional: a branch per write cost 20 %)
+        for (int k = 0; k < E; ++k) *(T *)(accb + r[k]) = s[k] + p[k];  // (unconditional: a branch per write cost 20 %)
     };
     auto fold = [&](T3Tiles<T, NB> &B) {
 #pragma unroll
@@ -442,6 +448,7 @@ __global__ __launch_bounds__(64) void k_t3_reduce(const T *__restrict__ prod, co
     issue(A, 0);
     __builtin_amdgcn_sched_barrier(0);
     for (uint32_t j0 = 0; j0 < n_cb; j0 += 2 * NB) {
+        __syncthreads();  // lock step with the workgroup's other row blocks (the trip count is the same for all: n_cb)
         issue(B, j0 + NB);
         fold(A);
         issue(A, j0 + 2 * NB);
@@ -794,6 +801,11 @@ static int build_t(::smh_crs *m) {
     // 128 KiB and more of dynamic LDS need the attribute on every device the kernel runs on: set with each build, on the matrix's device
     for (const void *f : {reinterpret_cast<const void *>(k_t3_expand<T, 2>), reinterpret_cast<const void *>(k_t3_expand<T, 3>), reinterpret_cast<const void *>(k_t3_expand<T, 4>)})
         SMH_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T))));
+    // (pass 2: several wavefronts' sums per workgroup)
+    for (const void *f : {reinterpret_cast<const void *>(k_t3_reduce<T, false, 2>), reinterpret_cast<const void *>(k_t3_reduce<T, false, 4>),
+                          reinterpret_cast<const void *>(k_t3_reduce<T, false, 8>), reinterpret_cast<const void *>(k_t3_reduce<T, true, 2>),
+                          reinterpret_cast<const void *>(k_t3_reduce<T, true, 4>), reinterpret_cast<const void *>(k_t3_reduce<T, true, 8>)})
+        SMH_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
     // (the row codes are byte offsets into a wavefront's sums and must fit 16 bits)
     if (((uint64_t)R + 1) * sizeof(T) > 0xFFFFu) return fail(SMH_ERR_INVALID, "tiled variant: row blocks of %u rows do not fit the 16-bit row codes", R);
     m->t2_n_cb = n_cb;
@@ -912,13 +924,36 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
         SMH_HIP(hipGetLastError());
     }
     // pass 2: one wavefront = one workgroup per row block
-    const uint32_t g2 = m->t2_n_rb, g2r = (xcd_map & 2u) ? (g2 + 7u) & ~7u : g2;
+    // pass 2: one wavefront per row block, and the wavefronts of ADJACENT row blocks share a workgroup and walk the slices in lock step
+    // (a barrier per batch of tiles): their tiles are neighbours in memory, so the workgroup reads one piece of W x ~1 KiB per slice
+    // instead of W pieces at W different times -- the pass is bound by exactly those reads (profiles/r03_k2t_pass2_bound_experiments.log;
+    // W = 1 / 2 / 4 / 6 / 12: 472 / 429 / 406 / 395 / 368 us on C2-uniform, 536 / 502 / 477 / 471 / 451 on C3, r03_k2t_pass2_lockstep.log).
+    // W = as many as a CU's LDS holds sums for -- or a divisor of that number (no LDS left unused) when there are too few row blocks
+    // to give every CU a workgroup
+    static const int waves2_env = getenv("SMH_TILED_WAVES") ? atoi(getenv("SMH_TILED_WAVES")) : 0;  // tuning knob: 0 = automatic
+    const uint32_t stride2 = (uint32_t)((lds2 + 15) & ~(size_t)15);
+    static int cus_cache[64] = {};  // per device
+    int &cus = cus_cache[m->device & 63];
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        cus = hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    uint32_t fit = (uint32_t)(((size_t)160 << 10) / stride2);
+    fit = fit < 1 ? 1 : (fit > 16 ? 16 : fit);
+    uint32_t waves2 = fit;
+    while (waves2 > 1 && ((uint64_t)m->t2_n_rb + waves2 - 1) / waves2 < (uint64_t)cus * 9 / 10) {  // (the next smaller divisor of `fit`)
+        uint32_t d = waves2 - 1;
+        while (d > 1 && fit % d) --d;
+        waves2 = d;
+    }
+    if (waves2_env >= 1 && (uint32_t)waves2_env <= fit) waves2 = (uint32_t)waves2_env;
+    const uint32_t g2 = (m->t2_n_rb + waves2 - 1u) / waves2, g2r = (xcd_map & 2u) ? (g2 + 7u) & ~7u : g2;
     static const int batch = getenv("SMH_TILED_BATCH") ? atoi(getenv("SMH_TILED_BATCH")) : kT3Batch;  // tuning knob: 2, 4 or 8 tiles per batch
     auto *red = batch == 8 ? (m->t3_dups ? k_t3_reduce<T, true, 8> : k_t3_reduce<T, false, 8>)
                 : batch == 2 ? (m->t3_dups ? k_t3_reduce<T, true, 2> : k_t3_reduce<T, false, 2>)
                              : (m->t3_dups ? k_t3_reduce<T, true, 4> : k_t3_reduce<T, false, 4>);
-    hipLaunchKernelGGL(red, dim3(g2r), dim3(64), lds2, s, (const T *)m->d_t2_prod, m->d_t2_row, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb, m->d_t2_rbstart,
-                       (T *)y, xcd_map >> 1 & 1u);
+    hipLaunchKernelGGL(red, dim3(g2r), dim3(64 * waves2), (size_t)waves2 * stride2, s, (const T *)m->d_t2_prod, m->d_t2_row, m->d_t2_tstart, m->t2_n_cb, m->t2_n_rb, m->d_t2_rbstart,
+                       (T *)y, xcd_map >> 1 & 1u, stride2);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
