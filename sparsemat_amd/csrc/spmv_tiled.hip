@@ -928,8 +928,7 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
     // (a barrier per batch of tiles): their tiles are neighbours in memory, so the workgroup reads one piece of W x ~1 KiB per slice
     // instead of W pieces at W different times -- the pass is bound by exactly those reads (profiles/r03_k2t_pass2_bound_experiments.log;
     // W = 1 / 2 / 4 / 6 / 12: 472 / 429 / 406 / 395 / 368 us on C2-uniform, 536 / 502 / 477 / 471 / 451 on C3, r03_k2t_pass2_lockstep.log).
-    // W = as many as a CU's LDS holds sums for -- or a divisor of that number (no LDS left unused) when there are too few row blocks
-    // to give every CU a workgroup
+    // W = the largest count (<= 16: 1024 threads) that packs the CU's LDS and still leaves a workgroup for every CU
     static const int waves2_env = getenv("SMH_TILED_WAVES") ? atoi(getenv("SMH_TILED_WAVES")) : 0;  // tuning knob: 0 = automatic
     const uint32_t stride2 = (uint32_t)((lds2 + 15) & ~(size_t)15);
     static int cus_cache[64] = {};  // per device
@@ -938,15 +937,14 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
         hipDeviceProp_t prop;
         cus = hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    uint32_t fit = (uint32_t)(((size_t)160 << 10) / stride2);
-    fit = fit < 1 ? 1 : (fit > 16 ? 16 : fit);
-    uint32_t waves2 = fit;
-    while (waves2 > 1 && ((uint64_t)m->t2_n_rb + waves2 - 1) / waves2 < (uint64_t)cus * 9 / 10) {  // (the next smaller divisor of `fit`)
-        uint32_t d = waves2 - 1;
-        while (d > 1 && fit % d) --d;
-        waves2 = d;
+    const uint32_t fit = std::max<uint32_t>(1u, (uint32_t)(((size_t)160 << 10) / stride2));  // wavefronts a CU's LDS holds sums for
+    uint32_t waves2 = 1;
+    for (uint32_t w = std::min(fit, 16u); w > 1; --w) {
+        const bool packs = (uint64_t)(fit / w) * w * 10 >= (uint64_t)fit * 9;                      // workgroups of w leave at most a tenth of that unused
+        const bool spreads = ((uint64_t)m->t2_n_rb + w - 1) / w >= (uint64_t)cus * 9 / 10;          // ... and there is a workgroup for (nearly) every CU
+        if (packs && spreads) { waves2 = w; break; }
     }
-    if (waves2_env >= 1 && (uint32_t)waves2_env <= fit) waves2 = (uint32_t)waves2_env;
+    if (waves2_env >= 1 && (uint32_t)waves2_env <= std::min(fit, 16u)) waves2 = (uint32_t)waves2_env;
     const uint32_t g2 = (m->t2_n_rb + waves2 - 1u) / waves2, g2r = (xcd_map & 2u) ? (g2 + 7u) & ~7u : g2;
     static const int batch = getenv("SMH_TILED_BATCH") ? atoi(getenv("SMH_TILED_BATCH")) : kT3Batch;  // tuning knob: 2, 4 or 8 tiles per batch
     auto *red = batch == 8 ? (m->t3_dups ? k_t3_reduce<T, true, 8> : k_t3_reduce<T, false, 8>)
