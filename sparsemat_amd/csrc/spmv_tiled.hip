@@ -21,7 +21,10 @@
 //                     wavefront per row block walks its tiles slice by slice, 16 bytes of products per lane (4 f32 / 2 f64), and adds them
 //                     into wave-private sums in LDS; the rows of a tile are distinct (checked per tile with one ballot; else a
 //                     segmented scan merges equal neighbours first), so the adds of a tile are independent: no atomics, no
-//                     barriers, a fixed order -- bitwise reproducible.  The loads of the next tiles are in flight meanwhile.
+//                     barriers between them, a fixed order -- bitwise reproducible.  The loads of the next tiles are in flight meanwhile.
+//                     The wavefronts of up to 12 ADJACENT row blocks share a workgroup and meet at a barrier before every batch of
+//                     tiles: their tiles are neighbours in memory, and reading them at one time is worth 22 % of the pass.
+//   pass 1 runs on persistent workgroups (the next item's slice of x travels into registers while the current one is in use).
 // Round 2's form (one product per entry, one entry per lane in pass 2: 16 / 28 B per entry, 42 VALU per 48-entry tile) is in
 // the history of this file; what changed and what it bought: DESIGN.md section 4, "K2t".
 //
@@ -923,7 +926,6 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
                            m->d_t3_cptr, (const T3Chunk *)m->d_t3_chunk, (T *)m->d_t2_prod, parts, g1, per_xcd);
         SMH_HIP(hipGetLastError());
     }
-    // pass 2: one wavefront = one workgroup per row block
     // pass 2: one wavefront per row block, and the wavefronts of ADJACENT row blocks share a workgroup and walk the slices in lock step
     // (a barrier per batch of tiles): their tiles are neighbours in memory, so the workgroup reads one piece of W x ~1 KiB per slice
     // instead of W pieces at W different times -- the pass is bound by exactly those reads (profiles/r03_k2t_pass2_bound_experiments.log;
