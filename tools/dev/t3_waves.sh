@@ -1,7 +1,6 @@
 #!/bin/bash
 # K2t pass 2: wavefronts (= adjacent row blocks walking the slices in lock step) per workgroup, kernel trace, one box
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export SPARSEMAT_HIP_LIB=$GRAFT_REPO_ROOT/sparsemat_amd/libsparsemat_hip_ab.so
 for w in 1 2 4 6 12 3 4; do
   echo "== SMH_TILED_WAVES=$w"
   rm -rf gpurun_out/t3_trace
