@@ -95,7 +95,7 @@ def main():
             with open(f, newline="") as fh:
                 for row in csv.DictReader(fh):
                     if row.get("Counter_Name") == counter:
-                        name = row["Kernel_Name"].split("(")[0].replace("void smh::", "")
+                        name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void smh::", "")
                         per[name][counter].append(float(row["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
     cal = [k for k in per if "k_ew" in k]
