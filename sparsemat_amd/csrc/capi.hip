@@ -282,10 +282,11 @@ static int ensure_ring_plan(smh_crs *m, bool with_bands = true) {
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    // Two 512-thread blocks (64 KiB of LDS each) are resident per CU; the row range is cut into 4x as many
-    // blocks so that the hardware dispatcher evens out the tail (measured on C2, same box, steady state:
-    // 2/CU 0.4245 ms, 8/CU 0.404 ms, 24/CU 0.402 ms; x is then read ~2.7x instead of ~1.4x, from L2).
-    unsigned per_cu = 8;
+    // Two 512-thread blocks (64 KiB of LDS each) are resident per CU; the row range is cut into 3x as many
+    // blocks so that the hardware dispatcher evens out the tail (round 1, on C2: 2/CU 0.4245 ms, 8/CU 0.404 ms, 24/CU 0.402 ms;
+    // round 3, the final kernel: 4 / 6 / 8 / 12 / 16 per CU 0.360 / 0.357 / 0.361 / 0.364 / 0.371 ms, and 0.350-0.353 against
+    // 0.356-0.359 ms for 6 against 8 on banded and window matrices, f64 level -- profiles/r03_k1r_blocks_per_cu.log)
+    unsigned per_cu = 6;
     if (const char *e = getenv("SMH_RING_BLOCKS_PER_CU")) {  // tuning knob
         const int v = atoi(e);
         if (v >= 1 && v <= 64) per_cu = (unsigned)v;
