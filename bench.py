@@ -255,9 +255,340 @@ def exchange_check(lib, check, synth, np, par, x, y, n, comm, pattern):
     return out
 
 
+def time_launches(lib, check, fn, stream, sync, reps, warm):
+    """`reps` launches of fn, each bracketed by HIP events recorded on the launch stream, after `warm` untimed ones."""
+    for _ in range(warm):
+        fn()
+    sync()
+    ev = Events(lib, check, reps)
+    for i in range(reps):
+        ev.start(i, stream)
+        fn()
+        ev.stop(i, stream)
+    sync()
+    return stats(ev.times_ms())
+
+
+def inspector_cost(mat, variant, xptr, x_len, yptr, stream, lib, check, sync, chosen_ms):
+    """What the chosen kernel's set-up costs against north_star's two plain row-major variants, which need none worth the name
+    (K1 = a (sub-)wavefront per row, no plan, no derived arrays; K2 = merge path, a table of 2 u32 per 2048 items): the reference has
+    no set-up at all (sparsemat_crs.rs:102-110 is a slice zip), so `break_even_products` = prepare_ms / (best plain kernel - chosen
+    kernel) is the number of products after which the inspectors have paid for themselves."""
+    prepare_ms, derived = mat.prepare_stats(variant)
+    mat.set_ring(0)
+    k1 = time_launches(lib, check, lambda: mat.mvp_dev(xptr, x_len, yptr, "vector", stream=stream), stream, sync, 5, 2)["median"]
+    mat.set_ring(-1)
+    k2 = time_launches(lib, check, lambda: mat.mvp_dev(xptr, x_len, yptr, "merge", stream=stream), stream, sync, 5, 2)["median"]
+    plain = min(k1, k2)
+    gain = plain - chosen_ms
+    return {"prepare_ms": prepare_ms, "derived_bytes": derived,
+            "plain_row_major_ms": {"vector_k1_no_ring": k1, "merge_k2": k2},
+            "break_even_products": (prepare_ms / gain) if gain > 0 else None,
+            "note": "prepare_ms = create-time inspection + smh_crs_prepare (host wall, device-synchronised); derived_bytes = device "
+                    "memory the plan holds beside the CRS arrays; the reference has no set-up step (sparsemat_crs.rs:102-110)"}
+
+
+def parity_rows(np, oracle, y_gpu, blocks, x_host, tol, exact):
+    """Sampled row blocks against the oracle (which generated them itself): bit-exact, or SURVEY 8d's componentwise bound
+    |dy_i| <= tol * sum_j |a_ij x_j|.  blocks: [(row_begin, off, col, val)] with offsets rebased to the block."""
+    worst, rows, same = 0.0, 0, True
+    for rb, off, col, val in blocks:
+        nr = len(off) - 1
+        y_ref = oracle.spmv(off, col, val, x_host)
+        got = y_gpu[rb:rb + nr]
+        rows += nr
+        if exact:
+            same = same and got.tobytes() == y_ref.tobytes()
+        scale = oracle.spmv_abs(off, col, val, x_host)
+        err = np.abs(got.astype(np.float64) - y_ref.astype(np.float64)) / np.maximum(scale, 1e-300)
+        worst = max(worst, float(err.max()))
+    out = {"rows_checked": rows, "blocks": [(int(b[0]), int(len(b[1]) - 1)) for b in blocks], "max_rel_err_vs_sum_abs": worst, "tol": tol,
+           "ok": bool(worst <= tol and (same or not exact))}
+    if exact:
+        out["bit_exact"] = bool(same)
+    return out
+
+
+def med_of(fn, reps):
+    ts, out = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], out
+
+
+def extra_configs(args, lib, check, sm, synth, np, stream, sync):
+    """BASELINE configs[2] (C3) and configs[3] (C4: SpMV and CG per iteration) measured in the same process as the headline, each
+    with HIP-event kernel times, `roofline.frac` by SURVEY 8d's algorithmic bytes, a parity gate on sampled row blocks against the
+    oracle and a one-core CPU baseline on a stated sample.  PMC traffic for these kernels is collected separately
+    (profiles/r04_pmc_*; tools/pmc_kernels.py) -- `traffic` stays null here."""
+    import oracle
+    out = {}
+    # ---- C3: f64, power-law row lengths 1..2048 (alpha 1.52), uniform columns, AUTO ----------------------------------------
+    t0 = time.perf_counter()
+    n3 = args.c3_rows
+    m3 = synth.crs_powerlaw(synth.SEED_MATRIX, n3, n3, np.float64)
+    nnz3 = m3.n_non_zero_entries()
+    xb3, xp3 = synth.gen_x(synth.SEED_X, n3, np.float64)
+    yb3 = synth.DeviceBuffer(n3 * 8)
+    variant3, lanes3 = m3.resolved_variant()
+    prep3 = m3.prepare_stats("auto")  # (build before the clock; reported below)
+    k3 = time_launches(lib, check, lambda: m3.mvp_dev(xp3, n3, yb3.ptr, "auto", stream=stream), stream, sync, 20, 3)
+    b3 = nnz3 * 12 + (n3 + 1) * 4 + n3 * 8 + n3 * 8
+    y3 = yb3.download(np.float64, n3)
+    x3 = xb3.download(np.float64, n3)
+    s_rows = min(n3, 1_000_000)
+    starts = sorted({0, max(0, n3 // 2 - s_rows // 2), max(0, n3 - 50_000)})
+    blocks = []
+    for rb in starts:
+        re = min(n3, rb + (s_rows if rb == starts[len(starts) // 2] else 50_000))
+        blocks.append((rb,) + tuple(oracle.gen_powerlaw(synth.SEED_MATRIX, n3, n3, np.float64, row_begin=rb, row_end=re)))
+    par3 = parity_rows(np, oracle, y3, blocks, x3, 1e-12, False)
+    big = max(blocks, key=lambda b: len(b[1]))
+    med, _ = med_of(lambda: oracle.spmv(big[1], big[2], big[3], x3), 5)
+    share = len(big[3]) / nnz3
+    cost3 = inspector_cost(m3, "auto", xp3, n3, yb3.ptr, stream, lib, check, sync, k3["mean"])
+    out["C3"] = {
+        "workload": "f64 CSR SpMV, %d rows, power-law row lengths 1..2048 (alpha 1.52, %d entries), uniform columns, 1xMI355X (BASELINE configs[2])" % (n3, nnz3),
+        "dtype": "f64", "kernel": "%s (AUTO)%s" % (variant3, " = k_t3_expand + k_t3_reduce (two passes)" if variant3 == "tiled" else ""),
+        "kernel_ms": k3["mean"], "kernel_ms_median": k3["median"], "kernel_ms_min": k3["min"], "kernel_ms_max": k3["max"], "launches": k3["launches"],
+        "timing": "HIP events on the launch stream around every product (both passes)",
+        "algorithmic_bytes": b3,
+        "roofline": {"bound": "hbm", "achieved": b3 / (k3["mean"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": b3 / (k3["mean"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "traffic_note": "PMC bytes per product for this kernel pair: profiles/r04_pmc_k2t_powerlaw.txt (separate rocprofv3 --pmc passes)"},
+        "gflops": 2.0 * nnz3 / (k3["mean"] * 1e-3) / 1e9,
+        "parity": par3,
+        "cpu_baseline": {"value": b3 * share / med / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": "rows [%d, %d) of the same matrix (%d entries = %.1f %% of the workload, all of x), median of 5 passes, %.3f s per pass; "
+                                   "bytes = the workload's algorithmic bytes x that share" % (big[0], big[0] + len(big[1]) - 1, len(big[3]), 100 * share, med),
+                         "ms_per_step_extrapolated": med / share * 1e3},
+        "inspector": cost3, "set_up_s": time.perf_counter() - t0,
+    }
+    del m3, xb3, yb3, y3, x3, blocks, big
+    # ---- C4: 7-point Laplacian on a g^3 grid, f32: the SpMV and the CG iteration ---------------------------------------------
+    t0 = time.perf_counter()
+    g = args.c4_grid
+    n4 = g * g * g
+    m4 = synth.crs_laplace3d(g, g, g, np.float32)
+    nnz4 = m4.n_non_zero_entries()
+    xb4, xp4 = synth.gen_x(synth.SEED_X, n4, np.float32)
+    yb4 = synth.DeviceBuffer(n4 * 4)
+    variant4, _ = m4.resolved_variant()
+    m4.prepare_stats("auto")
+    k4 = time_launches(lib, check, lambda: m4.mvp_dev(xp4, n4, yb4.ptr, "auto", stream=stream), stream, sync, 20, 3)
+    b4 = nnz4 * 8 + (n4 + 1) * 4 + 2 * n4 * 4
+    y4 = yb4.download(np.float32, n4)
+    x4 = xb4.download(np.float32, n4)
+    s_rows = min(n4, 8_000_000)
+    starts = sorted({0, max(0, n4 // 2 - s_rows // 2), max(0, n4 - 70_000)})
+    blocks = []
+    for rb in starts:
+        re = min(n4, rb + (s_rows if rb == starts[len(starts) // 2] else 70_000))
+        blocks.append((rb,) + tuple(oracle.laplace3d_rows(g, g, g, rb, re, np.float32)))
+    par4 = parity_rows(np, oracle, y4, blocks, x4, 1e-5, variant4 == "stream")
+    big = max(blocks, key=lambda b: len(b[1]))
+    med, _ = med_of(lambda: oracle.spmv(big[1], big[2], big[3], x4), 5)
+    share = len(big[3]) / nnz4
+    cost4 = inspector_cost(m4, "auto", xp4, n4, yb4.ptr, stream, lib, check, sync, k4["mean"])
+    direct = m4.stream_direct() if variant4 == "stream" else False
+    out["C4_spmv"] = {
+        "workload": "f32 CSR SpMV, 7-point Laplacian %d^3 (%d rows, %d entries), natural ordering, 1xMI355X (BASELINE configs[3], the product)" % (g, n4, nnz4),
+        "dtype": "f32", "kernel": "%s (AUTO)%s" % (variant4, " = k_spmv_stream_xd (x staged in LDS, 16-bit stage offsets, byte row lengths)" if direct else ""),
+        "kernel_ms": k4["mean"], "kernel_ms_median": k4["median"], "kernel_ms_min": k4["min"], "kernel_ms_max": k4["max"], "launches": k4["launches"],
+        "timing": "HIP events on the launch stream around every product",
+        "algorithmic_bytes": b4,
+        "roofline": {"bound": "hbm", "achieved": b4 / (k4["mean"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": b4 / (k4["mean"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "traffic_note": "PMC bytes per product: profiles/r04_pmc_k1s_xd_lap512.txt (separate rocprofv3 --pmc passes)"},
+        "gflops": 2.0 * nnz4 / (k4["mean"] * 1e-3) / 1e9,
+        "parity": par4,
+        "cpu_baseline": {"value": b4 * share / med / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": "rows [%d, %d) of the same matrix (%d entries = %.1f %% of the workload), median of 5 passes, %.3f s per pass; bytes = the "
+                                   "workload's algorithmic bytes x that share" % (big[0], big[0] + len(big[1]) - 1, len(big[3]), 100 * share, med),
+                         "ms_per_step_extrapolated": med / share * 1e3},
+        "inspector": cost4, "set_up_s": time.perf_counter() - t0,
+    }
+    del y4, x4, blocks, big, xb4, yb4
+    # CG (linearsolver.rs:27-61): b = A.1, x0 = 0, a fixed number of iterations (f32 never reaches 1e-12 at this size, SURVEY 7)
+    t0 = time.perf_counter()
+    iters = args.cg_iters
+    ones = sm.DenseVec.from_vec(np.ones(n4, np.float32))
+    bvec = sm.DenseVec.zeros(n4, np.float32)
+    m4.mvp_dev(ones.data_ptr(), n4, bvec.data_ptr(), "auto")
+    check(lib.smh_device_synchronize())
+    cg = sm.ConjugateGradient(0.0, iters, check_every=iters)
+    xs = sm.DenseVec.zeros(n4, np.float32)
+    cg.solve(m4, bvec, xs)  # warm: plans, graph instantiation
+    per_it = []
+    for _ in range(3):
+        xs = sm.DenseVec.zeros(n4, np.float32)
+        check(lib.smh_device_synchronize())
+        t1 = time.perf_counter()
+        cg.solve(m4, bvec, xs)
+        check(lib.smh_device_synchronize())
+        per_it.append((time.perf_counter() - t1) / cg.iterations * 1e3)
+    per_it.sort()
+    it_ms = per_it[len(per_it) // 2]
+    b_cg = b4 + 9 * n4 * 4
+    # what the solver reports against what its x really leaves: r = b - A x recomputed with the library's own kernels
+    ax = sm.DenseVec.zeros(n4, np.float32)
+    m4.mvp_dev(xs.data_ptr(), n4, ax.data_ptr(), "auto")
+    check(lib.smh_device_synchronize())
+    res = bvec.clone()
+    res.sub(ax)
+    true_r = float(res.norm())
+    err1 = float(np.abs(xs.to_numpy() - 1.0).max())
+    del ax, res, ones
+    # the solver against the oracle where the oracle finishes in seconds: same code path (graph, fused dot, device scalars), a
+    # 64^3 grid, the reference's stop rule.  tol 0.1: well above what f32 attains on this matrix -- from ~0.03 down the reference's
+    # own SEQUENTIAL f32 dots (vector.rs:50-58) stall its convergence (102 / 128 / 156 iterations for 0.03 / 0.01 / 0.001) while
+    # the device's tree sums keep going (120 for 0.001), so the iteration counts only agree above that
+    gs, tol = min(g, 64), 1e-1
+    ns = gs ** 3
+    so, sc, sv = oracle.laplace3d(gs, gs, gs, np.float32)
+    sb = oracle.spmv(so, sc, sv, np.ones(ns, np.float32))
+    x_ref, it_ref, _ = oracle.cg(ns, ns, so, sc, sv, sb, np.zeros(ns, np.float32), tol=tol, iter_max=2000)
+    small = sm.SparseMatCRS.from_raw_parts(ns, ns, so, sc, sv)
+    xsm = np.zeros(ns, np.float32)
+    cgs = sm.ConjugateGradient(tol, 2000)
+    cgs.solve(small, sb, xsm)
+    d_small = float(np.abs(xsm.astype(np.float64) - x_ref).max())
+    # one core on a grid the oracle finishes in seconds: 10 iterations of the reference's recurrence
+    gc = min(g, 160)
+    nc = gc ** 3
+    co, cc, cv = oracle.laplace3d(gc, gc, gc, np.float32)
+    cb = oracle.spmv(co, cc, cv, np.ones(nc, np.float32))
+    c_iters = 10
+    t1 = time.perf_counter()
+    oracle.cg(nc, nc, co, cc, cv, cb, np.zeros(nc, np.float32), tol=0.0, iter_max=c_iters)
+    c_it = (time.perf_counter() - t1) / c_iters
+    bc = len(cv) * 8 + (nc + 1) * 4 + 2 * nc * 4 + 9 * nc * 4
+    out["C4_cg"] = {
+        "workload": "ConjugateGradient::solve, 7-point Laplacian %d^3 f32, b = A.1, x0 = 0, device-resident, %d iterations per solve (BASELINE configs[3])" % (g, iters),
+        "dtype": "f32", "kernel": "hipGraph per iteration: %s SpMV with the p.Ap fold in its epilogue + k_cg_update_xr (x, r, r.r) + k_cg_update_p" % variant4,
+        "ms_per_iteration": it_ms, "ms_per_iteration_min": per_it[0], "ms_per_iteration_max": per_it[-1], "solves": len(per_it), "iterations_per_solve": cg.iterations,
+        "timing": "host wall clock around smh_cg_solve_vec (device-synchronised on both sides) / iterations, median of 3 solves; per-kernel times: profiles/r04_cg_kernel_stats.csv",
+        "algorithmic_bytes": b_cg, "algorithmic_bytes_reference_op_sequence": b4 + 12 * n4 * 4,
+        "roofline": {"bound": "hbm", "achieved": b_cg / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": b_cg / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "traffic_note": "minimum-traffic schedule of SURVEY 8d: B_spmv + 9 n sizeof(T)"},
+        "parity": {"oracle_case": "%d^3 f32, tol %g, reference stop rule: iterations device %d / oracle %d, max |x - x_oracle| %.3g" % (gs, tol, cgs.iterations, it_ref, d_small),
+                   "ok": bool(abs(cgs.iterations - it_ref) <= 1 and d_small <= 10 * tol),
+                   "full_size": {"iterations": cg.iterations, "r_norm_reported": float(np.sqrt(cg.r_norm_squared)), "r_norm_recomputed": true_r,
+                                 "max_abs_err_vs_ones": err1}},
+        "cpu_baseline": {"value": bc / c_it / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": "the oracle's CG (linearsolver.rs:27-61 restated) on the same stencil at %d^3 (%d rows), %d iterations, %.3f s per iteration; "
+                                   "bytes = B_spmv + 9 n sizeof(T) of that grid" % (gc, nc, c_iters, c_it),
+                         "ms_per_iteration_extrapolated": c_it * 1e3 * n4 / nc},
+        "set_up_s": time.perf_counter() - t0,
+    }
+    return out
+
+
+
 def stats(ts):
     s = sorted(ts)
     return {"mean": sum(s) / len(s), "median": s[len(s) // 2], "min": s[0], "max": s[-1], "launches": len(s)}
+
+
+def spawn_ranks(n):
+    """N children of this process, one per GPU, each running this script with the launcher's environment; rank 0's JSON line is
+    passed through on stdout; the exit status is the worst child's.  The children are killed by PID if the job overruns."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                SMH_BENCH_LAUNCH="bench.py --gpus %d (spawned ranks)" % n)
+    procs = []
+    log = None
+    if "--rccl-probe" in sys.argv:
+        log = "/tmp/smh_rccl_probe_%d.log" % os.getpid()
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        if log and r == 0:  # RCCL's own account of the job, from rank 0 (read back by rccl_report)
+            env.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=log, SMH_BENCH_RCCL_LOG_PATH=log)
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    limit = float(os.environ.get("SMH_BENCH_SPAWN_TIMEOUT_S", "1500"))
+    deadline = time.time() + limit
+    out0, worst = b"", 0
+    try:
+        out0 = procs[0].communicate(timeout=max(1.0, deadline - time.time()))[0] or b""
+        for pr in procs[1:]:
+            pr.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: spawned ranks did not finish within %g s -- killing them\n" % limit)
+        worst = WATCHDOG_EXIT
+    for pr in procs:
+        if pr.poll() is None:
+            pr.kill()
+            pr.wait()
+        if pr.returncode:
+            worst = max(worst, abs(pr.returncode))
+    sys.stdout.buffer.write(out0)
+    sys.stdout.flush()
+    if log:
+        try:
+            os.remove(log)
+        except OSError:
+            pass
+    return worst
+
+
+def run_rccl_probe(n_gpus, rows, pattern_name):
+    """Rank 0 of an N > 1 job, after the measurements: the same job once more in small (2 steps, all-gather exchange) as fresh
+    processes with RCCL's log switched on -- the headline never runs with logging -- and what that log says.  Bounded; a probe
+    that fails or overruns costs nothing but its own field."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                            "TORCHELASTIC_RUN_ID", "SMH_BENCH_LAUNCH")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_gpus), "--rows", str(rows), "--steps", "2", "--warmup", "1",
+           "--exchange", "allgather", "--pattern", pattern_name, "--rccl-probe"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(env, SMH_BENCH_SPAWN_TIMEOUT_S="150"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=200)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "probe exit status %d, %d line(s)" % (r.returncode, len(lines))}
+        return json.loads(lines[-1]).get("rccl_probe")
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def rccl_report(comm, sm):
+    """What RCCL itself says about this job (N > 1 lines carry it, so the first record from a node answers 'did RCCL see N ranks,
+    which RCCL, ring or direct' by itself): communicator size and device from the library, the version, and -- when the run was
+    started with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,TUNING NCCL_DEBUG_FILE=... (the spawn path and the launcher path both set
+    it for rank 0 unless SMH_BENCH_RCCL_LOG=0) -- the lines of RCCL's own log that name the channels, rings / trees and the
+    algorithm / protocol it chose per collective."""
+    out = {}
+    try:
+        out["version"] = sm.Comm.rccl_version()
+        if comm is not None:
+            seen, dev = comm.ranks_seen()
+            out["ranks_seen"], out["device"] = seen, dev
+    except Exception as e:
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    path = os.environ.get("SMH_BENCH_RCCL_LOG_PATH")
+    if path and os.path.exists(path):
+        keep, algo = [], []
+        try:
+            with open(path, errors="replace") as f:
+                for line in f:
+                    t = line.strip()
+                    if "Algo" in t and "proto" in t:
+                        if len(algo) < 12 and t not in algo:
+                            algo.append(t[-200:])
+                    elif any(k in t for k in ("Channel 00", "Ring 00", "Trees", "Connected all", "channels", "comm 0x", "NCCL version", "RCCL version", "P2P", "xGMI", "XGMI")):
+                        if len(keep) < 24:
+                            keep.append(t[-200:])
+            out["log_algo_proto"] = algo
+            out["log_excerpt"] = keep
+        except OSError as e:
+            out["log_error"] = str(e)
+    return out
+
 
 
 def rendezvous_id(rank, make_id):
@@ -310,7 +641,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # rocprofv3 --pmc child pass
+    ap.add_argument("--one-process", action="store_true",
+                    help="bare --gpus N > 1: ONE process owns all N blocks (ncclCommInitAll / peer reads) instead of the default, N child "
+                         "processes of this one, one per GPU (ncclCommInitRank) -- every block's work is then issued by one host thread")
+    ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
+                    help="N = 1: append BASELINE configs[2] (C3) and configs[3] (C4 SpMV, C4 CG) to the line as `configs` "
+                         "(auto: when --rows is the BASELINE size)")
+    ap.add_argument("--rccl-probe", action="store_true", help=argparse.SUPPRESS)  # short N > 1 run with RCCL's own log switched on (see rccl_report)
+    ap.add_argument("--c3-rows", type=int, default=10_000_000, help=argparse.SUPPRESS)
+    ap.add_argument("--c4-grid", type=int, default=512, help=argparse.SUPPRESS)
+    ap.add_argument("--cg-iters", type=int, default=100, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torch.distributed.run (or our own spawn): one process per GPU
+    if not launched and args.gpus > 1 and not args.one_process and not args.child:
+        # bare `bench.py --gpus N`: N fresh children, one per GPU, started BEFORE this process makes any GPU call (it never
+        # does); they meet exactly as under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE, id file keyed by this pid)
+        sys.exit(spawn_ranks(args.gpus))
 
     # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to stdout when its first communicator is
     # created (and libraries may chatter), so fd 1 is pointed at stderr for the run and the JSON goes to the saved fd
@@ -318,7 +665,6 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torch.distributed.run: one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -422,6 +768,7 @@ def main():
             par.synchronize()
 
     nnz = mat.n_non_zero_entries()
+    head_prepare = mat.prepare_stats(args.variant) if par is None else None  # (the plan is built here, before any clock starts)
     variant, lanes = mat.resolved_variant()
     _, ring_frac, ring_active, _, _ = mat.ring_plan()
     bytes_gpu = algorithmic_bytes(rows, nnz, min(n, rows + band))
@@ -461,6 +808,21 @@ def main():
         barrier()
         kernel = stats(kev.times_ms())
 
+    if args.rccl_probe:
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"rccl_probe": dict(rccl_report(comm, sm), exchange=exchange_mode, backend=backend, n_gpus=n_gpus,
+                                                              ms_per_step=elapsed / args.steps * 1e3)}) + "\n").encode())
+        if comm is not None:
+            comm.barrier()
+            if rank == 0 and rdzv_path:
+                try:
+                    os.remove(rdzv_path)
+                except OSError:
+                    pass
+        par.close()
+        if comm is not None:
+            comm.close()
+        return
     if args.child:
         # the calibration kernel of the PMC pass: x += y on CALIB_N f32 (known traffic, 16 B per lane)
         a, b = sm.DenseVec.zeros(CALIB_N, np.float32), sm.DenseVec.zeros(CALIB_N, np.float32)
@@ -542,7 +904,7 @@ def main():
             "workload": workload, "pattern": args.pattern, "rows_per_gpu": rows, "nnz_per_gpu": nnz, "index": "u32",
             "kernel": "%s lanes=%d ring=%s (ring rows %.3f)" % (variant, lanes, ring_active, ring_frac),
             "parallelism": parallelism, "exchange": exchange_mode, "exchange_backend": backend,
-            "launch": "torch.distributed.run, one process per GPU" if launched else ("one process" if n_gpus > 1 else "single process"),
+            "launch": (os.environ.get("SMH_BENCH_LAUNCH") or "torch.distributed.run, one process per GPU") if launched else ("one process" if n_gpus > 1 else "single process"),
         },
         "gflops": 2.0 * nnz * n_gpus / (elapsed / args.steps) / 1e9,
         # per step: the local SpMV kernel (HIP events, block 0 of rank 0) and what the rest of the step costs (the exchange
@@ -583,6 +945,16 @@ def main():
     }
     if other is not None:
         result["other_pattern"] = other
+    if par is not None:
+        # what RCCL itself reports: ncclCommCount of this rank's communicator (one process per GPU); the one-process mode's
+        # communicators (ncclCommInitAll) live inside the library's blocks and are not asked
+        result["rccl"] = rccl_report(comm, sm) if backend == "rccl" else {"note": "exchange backend '%s': no RCCL call in this run" % backend}
+        result["ranks_seen"] = result["rccl"].get("ranks_seen") if comm is not None else None
+    if head_prepare is not None and not args.child:
+        result["inspector"] = inspector_cost(mat, args.variant, xptr, n, yptr, stream, lib, check, sync, kernel_ms)
+        if not args.no_cpu_baseline:  # (the plain kernels wrote y: the headline matrix's product again for the parity gate)
+            spmv()
+            sync()
     if step_events is not None:
         result["step_ms_block0_events"] = step_events["mean"]
     # The optional legs of an N > 1 run come AFTER the headline is complete, under a watchdog: should one of them hang (it is
@@ -674,6 +1046,16 @@ def main():
             result["cpu_baseline"], result["cpu_baseline_all_cores"] = one, allc
         else:
             result["cpu_baseline"] = None
+        want_configs = args.configs == "on" or (args.configs == "auto" and rows == ROWS_PER_GPU)
+        if n_gpus == 1 and par is None and want_configs:
+            # the other single-GPU BASELINE configs, after the headline is complete; the headline's buffers go first
+            del mat, blocks, xbuf, ybuf
+            try:
+                result["configs"] = extra_configs(args, lib, check, sm, synth, np, stream, sync)
+            except Exception as e:
+                result["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if n_gpus > 1 and backend == "rccl" and os.environ.get("SMH_BENCH_RCCL_PROBE", "0" if share else "1") == "1":
+            result.setdefault("rccl", {})["probe"] = run_rccl_probe(n_gpus, rows, args.pattern)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if comm is not None:

@@ -33,7 +33,14 @@
 extern "C" {
 #endif
 
-#define SMH_ABI_VERSION 2
+/* ABI history.  3 (round 4): smh_crs_tiled_layout is back to its version-2 form of SIX out pointers (round 3 had appended a
+ * seventh without a version bump: a caller built against the older header would have had the library write through a garbage
+ * pointer) and the product count has its own entry point, smh_crs_tiled_products; REMOVED since version 2:
+ * smh_crs_set_stream_windows and smh_crs_stream_windows (K1s's column windows are chosen by the inspector alone; the K1s-w kernel
+ * they steered left the library); ADDED: smh_crs_tiled_products, smh_crs_prepare_stats,
+ * smh_comm_ranks_seen, smh_rccl_version.  A caller checks smh_abi_version() ==
+ * SMH_ABI_VERSION once at load time (rust/src/lib.rs does). */
+#define SMH_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------ */
 enum {
@@ -273,7 +280,9 @@ int smh_crs_colfused(smh_crs *m, int *fits_out, uint32_t *shift_out, size_t *n_b
  * equal in value.  Memory: the copy (sizeof(T) + 2 bytes per slot), the products of the last launch (sizeof(T) + 2 bytes per
  * product slot) and a table of (n_row_blocks + 1) x n_slices u32 (beyond 4 GiB: SMH_ERR_INVALID).  Any out pointer may be NULL. */
 int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_columns_out, uint32_t *rows_per_block_out,
-                         uint32_t *n_row_blocks_out, size_t *copy_entries_out, size_t *n_products_out);
+                         uint32_t *n_row_blocks_out, size_t *copy_entries_out);
+/* ... and the number of product slots pass 1 writes / pass 2 reads (its own entry point: see the ABI history above). */
+int smh_crs_tiled_products(smh_crs *m, size_t *n_products_out);
 
 /* The arrays of that plan, for inspection (tests restate the build and the passes' summation order from them): `which` =
  * 0 first chunk of each slice (u32, n_slices + 1) | 1 per chunk {first product slot, entries} (2 x u32) | 2 the copy's 16-bit
@@ -299,6 +308,13 @@ int smh_crs_spmv(smh_crs *m, const void *x_host, size_t x_len, void *y_host, int
  * table, K2c blocked copy: device allocations and a synchronisation): call it before capturing
  * smh_crs_spmv_dev into a hipGraph of your own.  Never needed for correctness otherwise.      */
 int smh_crs_prepare(smh_crs *m, int variant);
+/* What the inspectors cost -- the reference has no set-up step at all (iter_row, sparsemat_crs.rs:102-110, is a slice zip), so an
+ * honest comparison carries it.  Runs smh_crs_prepare(m, variant) (a no-op when already built) and reports, accumulated over the
+ * handle's life: *prepare_ms_out = host wall time of the create-time inspection (statistics passes, K1r inspector) plus every
+ * build smh_crs_prepare performed, device-synchronised; *derived_bytes_out = the device memory those builds left allocated
+ * beside the CRS arrays (16-bit column arrays, code / phase tables, K2t's copy, product buffer and tile table ...; blocks below
+ * 1 MiB are not counted).  A plan built lazily by a first product that was NOT preceded by smh_crs_prepare is not in the figures. */
+int smh_crs_prepare_stats(smh_crs *m, int variant, double *prepare_ms_out, size_t *derived_bytes_out);
 int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant,
                      void *stream);
 /* SparseMatrix::inner_prod (sparsematrix.rs:161-171): lhs^T A rhs = sum over all entries of
@@ -417,6 +433,11 @@ int smh_comm_create(const void *id, int n_ranks, int rank, smh_comm **out);
 int smh_comm_destroy(smh_comm *c);
 int smh_comm_size(const smh_comm *c);
 int smh_comm_rank(const smh_comm *c);
+/* What RCCL itself reports (a first run on a node answers "did the library see N ranks, and which RCCL" by itself):
+ * *count_out = ncclCommCount of the rank's communicator, *device_out = ncclCommCuDevice (either may be NULL);
+ * *version_out = ncclGetVersion (e.g. 22203; needs no communicator). */
+int smh_comm_ranks_seen(const smh_comm *c, int *count_out, int *device_out);
+int smh_rccl_version(int *version_out);
 /* helpers for a host without a collective library of its own (bench, tests): a barrier across the
  * ranks (device work of this rank's device drained first), and max over ranks of one double */
 int smh_comm_barrier(smh_comm *c);

@@ -100,6 +100,8 @@ def _declare(L):
         getattr(L, "orc_laplace2d_" + suf).restype = _sz
         getattr(L, "orc_laplace3d_" + suf).argtypes = [_sz, _sz, _sz, _u32p, _u32p, fp]
         getattr(L, "orc_laplace3d_" + suf).restype = _sz
+        getattr(L, "orc_laplace3d_rows_" + suf).argtypes = [_sz, _sz, _sz, _sz, _sz, _u32p, _u32p, fp]
+        getattr(L, "orc_laplace3d_rows_" + suf).restype = _sz
         getattr(L, "orc_assemble_" + suf).argtypes = [_sz, _u32p, _u32p, fp, C.POINTER(C.c_uint8), C.POINTER(_sz),
                                                        C.POINTER(_sz), C.POINTER(_sz), _u32p, _u32p, fp]
         getattr(L, "orc_crs_replay_" + suf).argtypes = [_sz, _u32p, _u32p, fp, C.POINTER(C.c_uint8), C.POINTER(_sz),
@@ -379,6 +381,18 @@ def laplace3d(nx, ny, nz, dtype=np.float32):
     col = np.empty(nnz, dtype=np.uint32)
     val = np.empty(nnz, dtype=dtype)
     f(nx, ny, nz, _p(off, _u32p), _p(col, _u32p), _p(val, fp))
+    return off, col, val
+
+
+def laplace3d_rows(nx, ny, nz, row_begin, row_end, dtype=np.float32):
+    """Rows [row_begin, row_end) of laplace3d(nx, ny, nz): offsets rebased to 0, global columns (a sample of BASELINE C4)."""
+    suf, fp = _suf(dtype)
+    f = getattr(lib(), "orc_laplace3d_rows_" + suf)
+    nnz = f(nx, ny, nz, row_begin, row_end, None, None, None)
+    off = np.empty(row_end - row_begin + 1, dtype=np.uint32)
+    col = np.empty(nnz, dtype=np.uint32)
+    val = np.empty(nnz, dtype=dtype)
+    f(nx, ny, nz, row_begin, row_end, _p(off, _u32p), _p(col, _u32p), _p(val, fp))
     return off, col, val
 
 

@@ -389,6 +389,32 @@ void orc_gen_powerlaw_lengths(uint64_t seed, size_t row_begin, size_t row_end, u
                 }                                                                             \
         if (offset_rows) offset_rows[nxy * nz] = (uint32_t)nnz;                               \
         return nnz;                                                                           \
+    }                                                                                         \
+    /* rows [row_begin, row_end) of the same matrix: offsets rebased to 0 (row_end -          \
+     * row_begin + 1 of them), GLOBAL columns -- a sample of BASELINE C4 without its 8 GB */  \
+    size_t orc_laplace3d_rows_##SUF(size_t nx, size_t ny, size_t nz, size_t row_begin,        \
+                                    size_t row_end, uint32_t *offset_rows, uint32_t *columns, \
+                                    T *values) {                                              \
+        size_t nnz = 0;                                                                       \
+        size_t nxy = nx * ny;                                                                 \
+        for (size_t row = row_begin; row < row_end; ++row) {                                  \
+            size_t k = row / nxy, j = row % nxy / nx, i = row % nx;                           \
+            if (offset_rows) offset_rows[row - row_begin] = (uint32_t)nnz;                    \
+            long long nb[7] = {k > 0 ? (long long)(row - nxy) : -1,                           \
+                               j > 0 ? (long long)(row - nx) : -1,                            \
+                               i > 0 ? (long long)(row - 1) : -1, (long long)row,             \
+                               i + 1 < nx ? (long long)(row + 1) : -1,                        \
+                               j + 1 < ny ? (long long)(row + nx) : -1,                       \
+                               k + 1 < nz ? (long long)(row + nxy) : -1};                     \
+            for (int t = 0; t < 7; ++t)                                                       \
+                if (nb[t] >= 0) {                                                             \
+                    if (columns) columns[nnz] = (uint32_t)nb[t];                              \
+                    if (values) values[nnz] = t == 3 ? (T)6 : (T)-1;                          \
+                    ++nnz;                                                                    \
+                }                                                                             \
+        }                                                                                     \
+        if (offset_rows) offset_rows[row_end - row_begin] = (uint32_t)nnz;                    \
+        return nnz;                                                                           \
     }
 
 DEF_LAPLACE(f32, float)

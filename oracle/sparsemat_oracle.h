@@ -141,6 +141,9 @@ size_t orc_laplace2d_f32(size_t nx, size_t ny, uint32_t *offset_rows, uint32_t *
 size_t orc_laplace3d_f32(size_t nx, size_t ny, size_t nz, uint32_t *offset_rows, uint32_t *columns, float *values);
 size_t orc_laplace2d_f64(size_t nx, size_t ny, uint32_t *offset_rows, uint32_t *columns, double *values);
 size_t orc_laplace3d_f64(size_t nx, size_t ny, size_t nz, uint32_t *offset_rows, uint32_t *columns, double *values);
+/* rows [row_begin, row_end) of the 7-point matrix: offsets rebased to 0, global columns */
+size_t orc_laplace3d_rows_f32(size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end, uint32_t *offset_rows, uint32_t *columns, float *values);
+size_t orc_laplace3d_rows_f64(size_t nx, size_t ny, size_t nz, size_t row_begin, size_t row_end, uint32_t *offset_rows, uint32_t *columns, double *values);
 
 /* ---- assembly: add_to/set stream on a SparseMatIndexList, then to_crs() ----
  * sparsemat_indexlist.rs:29-53,61-63,158-164; indexlist.rs:62-83; sparsematrix.rs:226-233;

@@ -69,7 +69,9 @@ SIGNATURES = {
     "smh_crs_ring_bands": (_int, [_vp, _u32p, _vp]),
     "smh_crs_ring_plan": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(C.c_double), C.POINTER(_int), _vp, _vp]),
     "smh_crs_set_colblock_shift": (_int, [_vp, C.c_uint32]),
-    "smh_crs_tiled_layout": (_int, [_vp, _u32p, _u32p, _u32p, _u32p, C.POINTER(_sz), C.POINTER(_sz)]),
+    "smh_crs_tiled_layout": (_int, [_vp, _u32p, _u32p, _u32p, _u32p, C.POINTER(_sz)]),
+    "smh_crs_tiled_products": (_int, [_vp, C.POINTER(_sz)]),
+    "smh_crs_prepare_stats": (_int, [_vp, _int, C.POINTER(C.c_double), C.POINTER(_sz)]),
     "smh_crs_tiled_array": (_int, [_vp, _int, _vp, _sz, C.POINTER(_sz)]),
     "smh_crs_colblock": (_int, [_vp, _u32p, C.POINTER(_sz), C.POINTER(_int), C.POINTER(C.c_double), _vp, _vp, _vp]),
     "smh_crs_colfused": (_int, [_vp, C.POINTER(_int), _u32p, C.POINTER(_sz), _u32p, C.POINTER(_sz), _vp, _vp, _vp, _vp, _vp]),
@@ -116,6 +118,8 @@ SIGNATURES = {
     "smh_comm_destroy": (_int, [_vp]),
     "smh_comm_size": (_int, [_vp]),
     "smh_comm_rank": (_int, [_vp]),
+    "smh_comm_ranks_seen": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "smh_rccl_version": (_int, [C.POINTER(C.c_int)]),
     "smh_comm_barrier": (_int, [_vp]),
     "smh_comm_max_f64": (_int, [_vp, C.POINTER(C.c_double)]),
     "smh_par_create": (_int, [_int, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _int, C.POINTER(_vp)]),

@@ -3,6 +3,7 @@
 // Host-side logic only: argument checks with the reference's panic conditions, HBM residency of
 // the CRS arrays, kernel-variant selection, the CG driver loop.  No CPU compute path exists here:
 // every entry point that computes needs a HIP device.
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -644,7 +645,12 @@ struct StreamCfg {
     int xs = 0;         // ... and every tile's column intervals fit an LDS stage of x: 16-byte chunks per thread (2 or 4), 0 = no
     bool direct = false;  // `code` holds byte offsets into that stage, not column codes: only K1s XD (spmv_stream_xd.hip) reads it
 };
-static int stream_cfg(smh_crs *m, StreamCfg *c) {
+// recode = false (every launch path): the configuration is READ from the handle -- the code array keeps the meaning it has.
+// recode = true (the first build, smh_crs_prepare, the setters): the code array is rewritten in place when the choice between
+// column codes and K1s XD's stage offsets has changed -- behind a device synchronisation, because a product enqueued on any
+// stream may still read it; never under a stream capture (the callers say so in the header), and a graph captured before the
+// change must be captured again.
+static int stream_cfg(smh_crs *m, StreamCfg *c, bool recode = false) {
     *c = StreamCfg();
     // a 512-row tiling is only chosen when every such tile fits the LDS stage; the 256-row tiling takes
     // tiles of any density (loop-free body when the create-time statistic says that none overflows)
@@ -655,7 +661,9 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
     // (single-pass tiles only: on dense multi-pass tiles -- banded C2 through K1s -- the decode costs more than
     // the bytes save, 0.83 vs 0.80 ms)
     if (!(c16_env && atoi(c16_env) == 0) && c->rpt == 1 && c->single_pass) {
+        const bool first = !m->stream_coded;
         SMH_TRY(ensure_stream_codes(m));
+        if (first) recode = true;  // (the build itself: allocations and synchronisations anyway)
         c->code = m->d_stream_code;
         c->cwin = m->d_stream_code ? m->d_stream_cwin : nullptr;
         static const bool l8_off = getenv("SMH_STREAM_L8") && atoi(getenv("SMH_STREAM_L8")) == 0;  // tuning knob
@@ -675,11 +683,11 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
                 : (m->stream_xs_chunks <= 2u * kBlock && on2) ? 2
                 : (m->stream_xs_chunks <= 4u * kBlock && on4) ? 4 : 0;
         // K1s XD: the code array as stage offsets.  The unskewed product stage it goes with collides on rows of even length, so
-        // automatic = most rows odd (stencils with a diagonal); the array is rewritten in place when the choice changes
+        // automatic = most rows odd (stencils with a diagonal)
         static const bool xd_off = getenv("SMH_STREAM_XD") && atoi(getenv("SMH_STREAM_XD")) == 0;  // tuning knob
         const bool want_direct = c->code && c->xs != 0 && !xd_off && m->use_stream_direct != 0 &&
                                  (m->use_stream_direct == 1 || 2 * m->stream_odd_rows >= (uint64_t)m->n_rows);
-        if (c->code && want_direct != m->stream_direct) {
+        if (recode && c->code && want_direct != m->stream_direct) {
             SMH_HIP(hipDeviceSynchronize());  // (a product enqueued on any stream may still read the array)
             if (want_direct)
                 SMH_TRY(launch_stream_stage_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, (uint32_t)dtype_size(m->dtype), m->d_stream_code, m->stream));
@@ -688,6 +696,8 @@ static int stream_cfg(smh_crs *m, StreamCfg *c) {
             SMH_HIP(hipStreamSynchronize(m->stream));
             m->stream_direct = want_direct;
         }
+        // (stage offsets without a stage -- xs == 0 after a setter that was not followed by a prepare cannot happen: the setters
+        // recode; an x too short / misaligned for the stage is handled per call in stream_launch)
         c->direct = c->code && m->stream_direct;
     }
     return SMH_OK;
@@ -868,7 +878,17 @@ int spmv_enqueue_rows(smh_crs *m, const void *x, size_t x_len, void *y, int vari
                              (unsigned)(row0 / gran), (unsigned)((row1 + gran - 1) / gran));
 }
 
+static int finish_create_inner(smh_crs *m, int validate);
 static int finish_create(smh_crs *m, int validate) {
+    // (what the create-time inspection costs: the statistics passes and, for matrices AUTO needs it for, the K1r inspector)
+    const auto t0 = std::chrono::steady_clock::now();
+    const long long b0 = pool_thread_net_bytes();
+    const int rc = finish_create_inner(m, validate);
+    m->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m->create_bytes = pool_thread_net_bytes() - b0;
+    return rc;
+}
+static int finish_create_inner(smh_crs *m, int validate) {
     SMH_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     if (m->n_rows > 0) {
         CrsStats *d_st = nullptr, h_st;
@@ -1344,7 +1364,7 @@ int smh_crs_scale(smh_crs *m, double a) {
 }
 
 int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_columns_out, uint32_t *rows_per_block_out, uint32_t *n_row_blocks_out,
-                         size_t *copy_entries_out, size_t *n_products_out) {
+                         size_t *copy_entries_out) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(tiled_build(m));
     if (!m->t2_ok) return fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
@@ -1353,6 +1373,13 @@ int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_col
     if (rows_per_block_out) *rows_per_block_out = m->t2_R;
     if (n_row_blocks_out) *n_row_blocks_out = m->t2_n_rb;
     if (copy_entries_out) *copy_entries_out = (size_t)m->t2_tot;
+    return SMH_OK;
+}
+
+int smh_crs_tiled_products(smh_crs *m, size_t *n_products_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(tiled_build(m));
+    if (!m->t2_ok) return fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
     if (n_products_out) *n_products_out = (size_t)m->t3_n_prod;
     return SMH_OK;
 }
@@ -1434,6 +1461,10 @@ int smh_crs_set_stream_xs(smh_crs *m, int mode) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic), 0 (never) or 1 (whenever the tiles allow)");
     m->use_stream_xs = mode;
+    if (m->stream_coded) {  // the choice may flip the code array's meaning: now, not inside a later launch
+        StreamCfg c;
+        SMH_TRY(stream_cfg(m, &c, true));
+    }
     return SMH_OK;
 }
 
@@ -1441,6 +1472,10 @@ int smh_crs_set_stream_direct(smh_crs *m, int mode) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic), 0 (never) or 1 (whenever x is staged)");
     m->use_stream_direct = mode;
+    if (m->stream_coded) {
+        StreamCfg c;
+        SMH_TRY(stream_cfg(m, &c, true));
+    }
     return SMH_OK;
 }
 
@@ -1518,8 +1553,7 @@ int smh_crs_set_vector_lanes(smh_crs *m, int lanes) {
     return SMH_OK;
 }
 
-int smh_crs_prepare(smh_crs *m, int variant) {
-    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+static int prepare_inner(smh_crs *m, int variant) {
     switch (resolve_variant(m, variant)) {
         case SMH_SPMV_VECTOR: {
             bool ring = false;
@@ -1535,11 +1569,44 @@ int smh_crs_prepare(smh_crs *m, int variant) {
             if (!m->split_ok) return ensure_colblock(m);
             SMH_TRY(smh_crs_prepare(m->split_short, SMH_SPMV_AUTO));
             return smh_crs_prepare(m->split_long, SMH_SPMV_AUTO);
-        case SMH_SPMV_STREAM: return ensure_stream_codes(m);
+        case SMH_SPMV_STREAM: {
+            StreamCfg c;
+            return stream_cfg(m, &c, true);  // code tables; the code array in the form the current settings ask for
+        }
         case SMH_SPMV_TILED: return tiled_build(m);
         case SMH_SPMV_SEQ: return SMH_OK;
         default: return fail(SMH_ERR_INVALID, "unknown SpMV variant %d", variant);
     }
+}
+
+int smh_crs_prepare(smh_crs *m, int variant) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    // what the inspectors cost (smh_crs_prepare_stats): wall time of the build, device-synchronised at both ends, and the
+    // device memory it leaves allocated (pooled blocks: everything of 1 MiB and more; scratch freed inside the build nets out)
+    const auto t0 = std::chrono::steady_clock::now();
+    const long long b0 = pool_thread_net_bytes();
+    // AUTO's plan refused by its lazy build (marked so by the builder): resolve again, as the first product would
+    const int tried = resolve_variant(m, variant);
+    int rc = prepare_inner(m, variant);
+    if (rc != SMH_OK && variant == SMH_SPMV_AUTO && rc != SMH_ERR_INDEX_RANGE && resolve_variant(m, variant) != tried) {
+        g_err[0] = 0;
+        rc = prepare_inner(m, variant);
+    }
+    if (rc == SMH_OK && m->stream) {
+        const hipError_t e = hipStreamSynchronize(m->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    }
+    m->prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m->prepare_bytes += pool_thread_net_bytes() - b0;
+    return rc;
+}
+
+int smh_crs_prepare_stats(smh_crs *m, int variant, double *prepare_ms_out, size_t *derived_bytes_out) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    SMH_TRY(smh_crs_prepare(m, variant));
+    if (prepare_ms_out) *prepare_ms_out = m->create_ms + m->prepare_ms;
+    if (derived_bytes_out) *derived_bytes_out = (size_t)(m->prepare_bytes + m->create_bytes > 0 ? m->prepare_bytes + m->create_bytes : 0);
+    return SMH_OK;
 }
 
 int smh_crs_spmv_dev(smh_crs *m, const void *x_dev, size_t x_len, void *y_dev, int variant, void *stream) {

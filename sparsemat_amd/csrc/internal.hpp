@@ -273,6 +273,9 @@ struct smh_crs {
     uint64_t stream_odd_rows = 0; // rows of odd length (taken with the byte lengths)
     uint16_t *d_col16 = nullptr;  // K1r: 16-bit column array for the ring phases (lazy; null: not used)
     int use_col16 = -1;           // -1 automatic (when at least a quarter of the rows are ring rows), 0 never, 1 always
+    // what the inspectors cost (smh_crs_prepare_stats): wall ms / pooled device bytes left allocated, create-time and prepare-time
+    double create_ms = 0.0, prepare_ms = 0.0;
+    long long create_bytes = 0, prepare_bytes = 0;
     // staging for the host-pointer API (lazy, reused)
     void *d_x = nullptr, *d_y = nullptr;
     size_t d_x_cap = 0, d_y_cap = 0;
@@ -290,6 +293,7 @@ struct smh_vec {
 namespace smh {
 hipError_t pool_malloc(void **out, size_t bytes);
 hipError_t pool_free(void *p);
+long long pool_thread_net_bytes();  // pooled bytes this thread has allocated minus freed so far (differences measure a build)
 }  // namespace smh
 #ifndef SMH_POOL_IMPL
 #define hipMalloc(p, n) ::smh::pool_malloc((void **)(p), (n))

@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 using namespace smh;
@@ -707,6 +708,19 @@ int smh_comm_destroy(smh_comm *c) {
 int smh_comm_size(const smh_comm *c) { return c ? c->n_ranks : 0; }
 int smh_comm_rank(const smh_comm *c) { return c ? c->rank : -1; }
 
+int smh_comm_ranks_seen(const smh_comm *c, int *count_out, int *device_out) {
+    if (!c || !c->comm) return fail(SMH_ERR_INVALID, "NULL communicator");
+    if (count_out) SMH_NCCL(ncclCommCount(c->comm, count_out));
+    if (device_out) SMH_NCCL(ncclCommCuDevice(c->comm, device_out));
+    return SMH_OK;
+}
+
+int smh_rccl_version(int *version_out) {
+    if (!version_out) return fail(SMH_ERR_INVALID, "NULL argument");
+    SMH_NCCL(ncclGetVersion(version_out));
+    return SMH_OK;
+}
+
 int smh_comm_max_f64(smh_comm *c, double *value_inout) {
     if (!c || !value_inout) return fail(SMH_ERR_INVALID, "NULL argument");
     DeviceGuard g;
@@ -895,37 +909,58 @@ int smh_par_create_rank_split(smh_comm *comm, size_t n_rows, smh_crs *block, siz
         blk.device = block->device;
         if (own_split) { blk.r0 = row_begin; blk.r1 = row_begin + block->n_rows; }
         else block_rows(part_of(p), k, &blk.r0, &blk.r1);
-        if (block->n_rows != blk.r1 - blk.r0 || blk.r1 > n_rows)
-            return fail(SMH_ERR_DIM_MISMATCH, "rank %zu holds %zu rows, the partition of %zu rows into %zu blocks gives it %zu", k, block->n_rows,
-                        n_rows, n_blocks, blk.r1 - blk.r0);
-        SMH_TRY(use(blk));
-        SMH_TRY(own_interval(blk, p->n_cols, &p->needs[k], &p->lo[k], &p->hi[k]));
-        SMH_TRY(finish_par(p));
-        // the ranks publish their column intervals and row ranges (the exchange plan is global): 6 u32 per rank, all-gathered in place
-        constexpr size_t W = 6;  // needs, lo, hi, row_begin (low, high word), has its own split
+        // Everything a rank can check ALONE happens before the gather, but a rank that fails it must not return while its peers
+        // block inside the collective: it publishes the failure with its table row, every rank reads every row and all of them fail
+        // (or succeed) together, with the same verdict.
+        auto local = [&]() -> int {
+            SMH_TRY(use(blk));
+            SMH_TRY(finish_par(p));  // (streams and events first: independent of what the checks say)
+            if (block->n_rows != blk.r1 - blk.r0 || blk.r1 > n_rows)
+                return fail(SMH_ERR_DIM_MISMATCH, "rank %zu holds %zu rows, the partition of %zu rows into %zu blocks gives it %zu", k, block->n_rows,
+                            n_rows, n_blocks, blk.r1 - blk.r0);
+            return own_interval(blk, p->n_cols, &p->needs[k], &p->lo[k], &p->hi[k]);
+        };
+        const int lrc = local();
+        const std::string lmsg = lrc == SMH_OK ? std::string() : std::string(smh_last_error());
+        hipStream_t gs = blk.s ? blk.s : comm->s;  // (the communicator's own stream when this block's could not be made)
+        // the ranks publish their column intervals and row ranges (the exchange plan is global): 9 u32 per rank, all-gathered in place
+        constexpr size_t W = 9;  // needs, lo, hi, row_begin (low, high word), has its own split, row count (low, high word), local status
         std::vector<uint32_t> table(W * n_blocks, 0);
         table[W * k] = p->needs[k]; table[W * k + 1] = p->lo[k]; table[W * k + 2] = p->hi[k];
         table[W * k + 3] = (uint32_t)blk.r0; table[W * k + 4] = (uint32_t)((uint64_t)blk.r0 >> 32); table[W * k + 5] = own_split;
+        table[W * k + 6] = (uint32_t)block->n_rows; table[W * k + 7] = (uint32_t)((uint64_t)block->n_rows >> 32); table[W * k + 8] = (uint32_t)lrc;
         uint32_t *d_table = nullptr;
         SMH_HIP(hipMalloc((void **)&d_table, W * n_blocks * sizeof(uint32_t)));
         auto gather = [&]() -> int {
-            SMH_HIP(hipMemcpyAsync(d_table, table.data(), W * n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, blk.s));
-            SMH_NCCL(ncclAllGather(d_table + W * k, d_table, W, ncclUint32, comm->comm, blk.s));
-            SMH_HIP(hipMemcpyAsync(table.data(), d_table, W * n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, blk.s));
-            SMH_HIP(hipStreamSynchronize(blk.s));
+            SMH_HIP(hipMemcpyAsync(d_table, table.data(), W * n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, gs));
+            SMH_NCCL(ncclAllGather(d_table + W * k, d_table, W, ncclUint32, comm->comm, gs));
+            SMH_HIP(hipMemcpyAsync(table.data(), d_table, W * n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, gs));
+            SMH_HIP(hipStreamSynchronize(gs));
             return SMH_OK;
         };
         const int grc = gather();
         (void)hipFree(d_table);
         SMH_TRY(grc);
-        for (size_t q = 0; q < n_blocks; ++q) { p->needs[q] = (uint8_t)table[W * q]; p->lo[q] = table[W * q + 1]; p->hi[q] = table[W * q + 2]; }
+        // from here on every rank holds the same table and runs the same checks in the same order
+        if (lrc != SMH_OK) return fail(lrc, "%s", lmsg.c_str());
         for (size_t q = 0; q < n_blocks; ++q)
-            if ((table[W * q + 5] != 0) != own_split) return fail(SMH_ERR_INVALID, "rank %zu passes a row_begin, rank %zu does not (all or none)", own_split ? k : q, own_split ? q : k);
+            if (table[W * q + 8] != 0) return fail((int)table[W * q + 8], "rank %zu failed its local checks of the partition (status %u); no rank keeps a handle", q, table[W * q + 8]);
+        for (size_t q = 0; q < n_blocks; ++q) { p->needs[q] = (uint8_t)table[W * q]; p->lo[q] = table[W * q + 1]; p->hi[q] = table[W * q + 2]; }
+        size_t first_with = n_blocks, first_without = n_blocks;
+        for (size_t q = n_blocks; q-- > 0;) (table[W * q + 5] ? first_with : first_without) = q;
+        if (first_with < n_blocks && first_without < n_blocks)
+            return fail(SMH_ERR_INVALID, "rank %zu passes a row_begin, rank %zu does not (all or none)", first_with, first_without);
         if (own_split) {
             p->split.assign(n_blocks + 1, n_rows);
             for (size_t q = 0; q < n_blocks; ++q) p->split[q] = (size_t)((uint64_t)table[W * q + 3] | (uint64_t)table[W * q + 4] << 32);
+            // the ranges must tile [0, n_rows) in rank order: no gap, no overlap -- the WHOLE table, identically on every rank
+            for (size_t q = 0; q < n_blocks; ++q) {
+                const size_t rows_q = (size_t)((uint64_t)table[W * q + 6] | (uint64_t)table[W * q + 7] << 32);
+                if (p->split[q] + rows_q != p->split[q + 1])
+                    return fail(SMH_ERR_INVALID, "rank %zu: its rows [%zu, %zu) end at %zu, %s begins at %zu (the blocks must tile the rows in rank order)", q,
+                                p->split[q], p->split[q] + rows_q, p->split[q] + rows_q, q + 1 < n_blocks ? "the next rank" : "the end of the matrix", p->split[q + 1]);
+            }
             SMH_TRY(check_split(n_blocks, n_rows, p->split.data()));
-            if (p->split[k + 1] != blk.r1) return fail(SMH_ERR_INVALID, "rank %zu: its rows end at %zu, rank %zu begins at %zu", k, blk.r1, k + 1, p->split[k + 1]);
         }
         return find_interiors(p);
     };

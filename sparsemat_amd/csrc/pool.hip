@@ -41,6 +41,8 @@ struct Pool {
     }
 };
 
+thread_local long long t_net_bytes = 0;
+
 Pool &pool() {
     static Pool *p = new Pool();  // (never destroyed: frees may still arrive from static destructors of the host)
     return *p;
@@ -70,6 +72,7 @@ hipError_t pool_malloc(void **out, size_t bytes) {
         *out = it->second;
         P.live.emplace(it->second, Live{it->first, device});
         P.live_bytes += it->first;
+        t_net_bytes += (long long)it->first;
         P.kept_bytes[device] -= it->first;
         P.kept[device].erase(it);
         return hipSuccess;
@@ -83,6 +86,7 @@ hipError_t pool_malloc(void **out, size_t bytes) {
     if (e != hipSuccess) return e;
     P.live.emplace(*out, Live{want, device});
     P.live_bytes += want;
+    t_net_bytes += (long long)want;
     return hipSuccess;
 }
 
@@ -99,6 +103,7 @@ hipError_t pool_free(void *p) {
             blk = it->second;
             P.live.erase(it);
             P.live_bytes -= blk.bytes;
+            t_net_bytes -= (long long)blk.bytes;
         }
     }
     if (blk.bytes == 0) return hipFree(p);
@@ -115,6 +120,8 @@ hipError_t pool_free(void *p) {
     P.kept_bytes[blk.device] += blk.bytes;
     return hipSuccess;
 }
+
+long long pool_thread_net_bytes() { return t_net_bytes; }
 
 }  // namespace smh
 

@@ -244,8 +244,11 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
     // zeros / stores nothing, without a branch -- a branch around a load or store makes the compiler drain every load in flight
     // before the next use (it cannot count them any more), which is what kept the first form of this loop at one chunk in flight.
     auto issue = [&](T3Slot<T> &S, uint32_t i) {  // the i-th chunk of this wavefront (beyond its run: an empty one)
-        S.ob = (uint32_t)__builtin_amdgcn_readlane((int)my_ob, (int)(i & 63u));
-        S.ln = (uint32_t)__builtin_amdgcn_readlane((int)my_ln, (int)(i & 63u));
+        // (i can reach 64 and 65 when the run holds 64 chunks and AHEAD does not divide 64: `i & 63` would then name the run's FIRST
+        // chunks again and their product slots would be overwritten -- a slot past the run must be empty whatever lane it maps to)
+        const bool mine = w0 + i < w1;  // (wave-uniform)
+        S.ob = mine ? (uint32_t)__builtin_amdgcn_readlane((int)my_ob, (int)(i & 63u)) : 0u;
+        S.ln = mine ? (uint32_t)__builtin_amdgcn_readlane((int)my_ln, (int)(i & 63u)) : 0u;
         const uint64_t at = (uint64_t)(w0 + i) * CH;
         const uint32_t pieces = (S.ln + E - 1) & ~(uint32_t)(E - 1);  // whole pieces (the rest of the chunk's slots is zero)
         const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(val + at), 0, (int)(pieces * sizeof(T)), kT3Rsrc);

@@ -213,7 +213,8 @@ class SparseMatCRS:
         (``smh_crs_tiled_array``): slice_chunks, chunks (n x 2: first product slot, entries), codes, values, product_rows,
         row_block_start, tile_start ((n_row_blocks + 1) x n_slices), products (of the last launch)."""
         a, b, c, d, e, f = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_size_t(), C.c_size_t()
-        check(lib().smh_crs_tiled_layout(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f)))
+        check(lib().smh_crs_tiled_layout(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        check(lib().smh_crs_tiled_products(self._h, C.byref(f)))
         out = {"n_slices": a.value, "slice_columns": b.value, "rows_per_block": c.value, "n_row_blocks": d.value, "copy_entries": e.value,
                "n_products": f.value}
         if arrays:
@@ -403,6 +404,14 @@ class SparseMatCRS:
     def prepare(self, variant="auto"):
         """Build the lazily created workspaces of ``variant`` now (before capturing mvp_dev into a hipGraph)."""
         check(lib().smh_crs_prepare(self._h, _lib.VARIANTS[variant]))
+
+    def prepare_stats(self, variant="auto"):
+        """``smh_crs_prepare_stats``: (prepare_ms, derived_bytes) -- what the inspectors of ``variant`` cost: host wall time of
+        the create-time inspection plus the plan's build, and the device memory they hold beside the CRS arrays.  The reference
+        has no set-up step (sparsemat_crs.rs:102-110)."""
+        ms, nb = C.c_double(), C.c_size_t()
+        check(lib().smh_crs_prepare_stats(self._h, _lib.VARIANTS[variant], C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
 
     def mvp_dev(self, x_ptr, x_len, y_ptr, variant="auto", stream=None):
         """Asynchronous y = A.x on raw device pointers (stream: a hipStream_t value or None)."""

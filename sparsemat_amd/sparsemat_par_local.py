@@ -39,6 +39,18 @@ class Comm:
     def rank(self):
         return lib().smh_comm_rank(self._h)
 
+    def ranks_seen(self):
+        """(ncclCommCount, ncclCommCuDevice) of this rank's communicator -- what RCCL itself says (``smh_comm_ranks_seen``)."""
+        n, d = C.c_int(), C.c_int()
+        check(lib().smh_comm_ranks_seen(self._h, C.byref(n), C.byref(d)))
+        return n.value, d.value
+
+    @staticmethod
+    def rccl_version():
+        v = C.c_int()
+        check(lib().smh_rccl_version(C.byref(v)))
+        return v.value
+
     def barrier(self):
         check(lib().smh_comm_barrier(self._h))
 

@@ -267,6 +267,10 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t c, int *count) { *count = c->n; return ncclSuccess; }
+ncclResult_t ncclCommCuDevice(const ncclComm_t c, int *device) { (void)c; return hipGetDevice(device) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError; }
+ncclResult_t ncclGetVersion(int *version) { *version = 0; return ncclSuccess; }  // (0: "this is the stand-in")
+
 const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error (mock)" : "mock rccl: see stderr"; }
 
 ncclResult_t ncclGroupStart() {

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libsparsemat_hip.so lacks %s" % name
         assert name in _lib.SIGNATURES, "python binding lacks %s" % name
     assert sorted(_lib.SIGNATURES) == names, "binding declares symbols the header does not"
-    assert L.smh_abi_version() == 2
+    assert L.smh_abi_version() == 3
     out = subprocess.run(["nm", "-D", "--defined-only", sm.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (smh_[a-z0-9_]+)", out))
     assert exported == set(names), exported ^ set(names)

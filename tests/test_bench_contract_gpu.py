@@ -23,7 +23,8 @@ def run_bench(args, env=None, launcher=None, expect_rc=0):
 
 
 def test_single_gpu_line(gpu):
-    d = run_bench(["--rows", "1000000", "--steps", "7", "--warmup", "2", "--no-traffic"])
+    d = run_bench(["--rows", "1000000", "--steps", "7", "--warmup", "2", "--no-traffic", "--configs", "on", "--c3-rows", "600000", "--c4-grid", "96",
+                   "--cg-iters", "20"])
     for k in CONTRACT:
         assert k in d, k
     assert (d["n_gpus"], d["steps"], d["warmup"], d["dtype"], d["scaling"], d["vs_baseline"]) == (1, 7, 2, "f32", "weak", None)
@@ -42,11 +43,25 @@ def test_single_gpu_line(gpu):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["parity_ok"] is True and c["value"] > 0
     assert d["cpu_baseline_all_cores"]["cores"] >= 1
+    # what the inspectors cost, against north_star's two plain row-major kernels
+    i = d["inspector"]
+    assert i["prepare_ms"] > 0 and i["derived_bytes"] >= 2 * 32 * 1000000 and set(i["plain_row_major_ms"]) == {"vector_k1_no_ring", "merge_k2"}
+    # the other single-GPU BASELINE configs ride along, each with its roofline, parity gate and one-core baseline
+    c = d["configs"]
+    assert set(c) == {"C3", "C4_spmv", "C4_cg"}, c
+    for name in ("C3", "C4_spmv", "C4_cg"):
+        e = c[name]
+        assert e["roofline"]["bound"] == "hbm" and e["roofline"]["peak"] == 8000.0 and 0 < e["roofline"]["frac"] < 1.2, (name, e["roofline"])
+        assert e["parity"]["ok"] is True, (name, e["parity"])
+        assert e["cpu_baseline"]["cores"] == 1 and e["cpu_baseline"]["kind"] == "port" and e["cpu_baseline"]["value"] > 0 and "sample" in e["cpu_baseline"]
+    assert c["C3"]["dtype"] == "f64" and c["C3"]["parity"]["tol"] == 1e-12 and c["C3"]["launches"] == 20 and c["C3"]["inspector"]["prepare_ms"] > 0
+    assert c["C4_spmv"]["parity"]["bit_exact"] is True and c["C4_spmv"]["algorithmic_bytes"] > 0
+    assert c["C4_cg"]["iterations_per_solve"] == 20 and c["C4_cg"]["algorithmic_bytes"] == c["C4_spmv"]["algorithmic_bytes"] + 9 * 96 ** 3 * 4
 
 
 def test_n_gpus_rehearsal_checks_its_exchange(gpu):
     env = {"SMH_BENCH_SHARE_DEVICES": "1"}
-    d = run_bench(["--gpus", "4", "--rows", "500000", "--steps", "5", "--warmup", "2"], env)
+    d = run_bench(["--gpus", "4", "--one-process", "--rows", "500000", "--steps", "5", "--warmup", "2"], env)
     assert d["n_gpus"] == 4 and d["config"]["exchange"] == "window" and d["config"]["exchange_backend"] == "peer"
     assert d["roofline"]["traffic"] is None and d.get("cpu_baseline") is None
     x = d["exchange_check"]
@@ -59,10 +74,22 @@ def test_n_gpus_rehearsal_checks_its_exchange(gpu):
     assert a["received_bytes_per_gpu_step"] == 3 * 500000 * 4
     # whole-job value: all blocks' bytes over the step time
     assert abs(d["value"] - 4 * d["algorithmic_bytes_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
-    d = run_bench(["--gpus", "3", "--rows", "400000", "--steps", "3", "--warmup", "1", "--exchange", "allgather"], env)
+    d = run_bench(["--gpus", "3", "--one-process", "--rows", "400000", "--steps", "3", "--warmup", "1", "--exchange", "allgather"], env)
     assert d["config"]["exchange"] == "allgather" and d["exchange_check"]["ok"] is True and "allgather_leg" not in d
-    bad = run_bench(["--gpus", "4", "--rows", "500000", "--steps", "3", "--warmup", "1"], dict(env, SMH_BENCH_SKIP_EXCHANGE="1"))
+    bad = run_bench(["--gpus", "4", "--one-process", "--rows", "500000", "--steps", "3", "--warmup", "1"], dict(env, SMH_BENCH_SKIP_EXCHANGE="1"))
     assert bad["exchange_check"]["ok"] is False and bad["exchange_check"]["max_abs_err"] > 1e-2
+
+
+def test_bare_gpus_n_spawns_one_process_per_gpu(gpu):
+    """`bench.py --gpus 3` bare: the default is now three fresh child processes, one per GPU, started before the parent touches the
+    GPU (ranks meet through smh_comm_*, as under torch.distributed.run) -- here sharing the one device through the test suite's
+    stand-in for RCCL.  The line says how it was launched and what the communicator reports."""
+    from util import build_mock_rccl
+    mock = build_mock_rccl()
+    d = run_bench(["--gpus", "3", "--rows", "300000", "--steps", "3", "--warmup", "1"], {"LD_PRELOAD": mock, "SMH_BENCH_SHARE_DEVICES": "1"})
+    assert d["n_gpus"] == 3 and d["config"]["exchange_backend"] == "rccl" and "spawned ranks" in d["config"]["launch"]
+    assert d["ranks_seen"] == 3 and d["rccl"]["version"] == 0  # (0: the stand-in's version)
+    assert d["exchange_check"]["ok"] is True
 
 
 def test_one_rank_under_the_launcher(gpu):
@@ -73,6 +100,7 @@ def test_one_rank_under_the_launcher(gpu):
     d = run_bench(["--gpus", "1", "--rows", "500000", "--steps", "4", "--warmup", "1", "--no-traffic", "--no-cpu-baseline"],
                   {"SMH_BENCH_FORCE_PAR": "1", "SMH_PAR_EXCHANGE_SINGLE": "1"}, launcher)
     assert d["n_gpus"] == 1 and d["config"]["launch"].startswith("torch.distributed.run") and d["config"]["exchange_backend"] == "rccl"
+    assert d["ranks_seen"] == 1 and d["rccl"]["version"] > 20000  # real RCCL, a lone rank
 
 
 def test_a_hanging_optional_leg_does_not_cost_the_headline(gpu):
@@ -80,6 +108,6 @@ def test_a_hanging_optional_leg_does_not_cost_the_headline(gpu):
     never returns, the line still comes out, marked with the leg that hung -- and the process exits with status 3, not 0: a hung
     collective on a process that owns the GPU must not look like a successful run."""
     env = {"SMH_BENCH_SHARE_DEVICES": "1", "SMH_BENCH_HANG_IN_LEGS": "1", "SMH_BENCH_WATCHDOG_S": "3"}
-    d = run_bench(["--gpus", "2", "--rows", "300000", "--steps", "3", "--warmup", "1"], env, expect_rc=3)
+    d = run_bench(["--gpus", "2", "--one-process", "--rows", "300000", "--steps", "3", "--warmup", "1"], env, expect_rc=3)
     assert d["n_gpus"] == 2 and d["value"] > 0 and "gave up after 3 s" in d["optional_legs"] and d["hung_leg"] == "exchange_check"
     assert "exchange_check" not in d and "allgather_leg" not in d

@@ -14,16 +14,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MOCK_SRC = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
-MOCK_SO = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
 
 
 @pytest.fixture(scope="module")
 def mock_so(gpu):
-    if not os.path.exists(MOCK_SO) or os.path.getmtime(MOCK_SO) < os.path.getmtime(MOCK_SRC):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", MOCK_SRC, "-o", MOCK_SO,
-                        "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
-    return MOCK_SO
+    from util import build_mock_rccl
+    return build_mock_rccl()
 
 
 RANK = r"""
@@ -186,6 +182,53 @@ def test_bench_under_the_launcher_with_three_ranks(gpu, mock_so):
     assert d["config"]["launch"].startswith("torch.distributed.run")
     assert d["exchange_check"]["ok"] is True and d["exchange_check"]["rows_per_rank"] in (64, 128)
     assert d["allgather_leg"]["exchange_check"]["ok"] is True
+
+
+BAD_SPLIT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import sparsemat_amd as sm
+from sparsemat_amd import _lib
+rank, case = int(os.environ["SMH_T_RANK"]), os.environ["SMH_T_CASE"]
+_lib.check(sm.lib().smh_set_device(0))
+comm = sm.Comm(bytes.fromhex(os.environ["SMH_T_UID"]), 2, rank)
+n = 20
+# rank 0 / rank 1: (first row, rows) -- "gap": rows 10, 11 belong to nobody; "overlap": rows 8, 9 to both; "short": the reference
+# partition (no row_begin) with a block of 9 instead of 10 rows on rank 1
+first, rows = {"gap": ((0, 10), (12, 8)), "overlap": ((0, 10), (8, 12)), "short": ((None, 10), (None, 9))}[case][rank]
+off = (np.arange(rows + 1) * 1).astype(np.uint32)
+col = np.arange(rows, dtype=np.uint32)
+blk = sm.SparseMatCRS.from_raw_parts(rows, n, off, col, np.ones(rows, np.float32))
+try:
+    if first is None:
+        sm.SparseMatParLocal.for_rank(comm, n, blk)
+    else:
+        sm.SparseMatParLocal.for_rank(comm, n, blk, row_begin=first)
+    print("RANK %%d CREATED" %% rank)
+except sm.SparseMatPanic as e:
+    print("RANK %%d REFUSED: %%s" %% (rank, e))
+comm.barrier()   # both ranks are still in step: nobody was left inside the table's all-gather
+print("RANK %%d DONE" %% rank)
+"""
+
+
+@pytest.mark.parametrize("case,needle", [("gap", "must tile the rows"), ("overlap", "must tile the rows"), ("short", "failed its local checks")])
+def test_a_bad_partition_is_refused_on_every_rank_together(gpu, mock_so, case, needle):
+    """smh_par_create_rank[_split]: a gap, an overlap, or one rank holding the wrong number of rows.  Round 3 let the rank that saw the
+    problem return while its peer got a handle (and would have hung in its first collective), or return BEFORE the plan table's
+    all-gather while its peer blocked inside it.  Now the local verdicts travel with the table and every rank validates the whole
+    table: both refuse, both reach the barrier that follows."""
+    uid = ("smh_mock_b_%s" % secrets.token_hex(8)).encode().ljust(128, b"\0").hex()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, LD_PRELOAD=mock_so, SMH_T_RANK=str(rank), SMH_T_UID=uid, SMH_T_CASE=case)
+        procs.append(subprocess.Popen([sys.executable, "-c", BAD_SPLIT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=200) for p in procs]
+    for rank, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK %d DONE" % rank) in out, (rank, out[-800:], err[-2000:])
+        assert ("RANK %d REFUSED" % rank) in out and "CREATED" not in out, (rank, out)
+    assert any(needle in o[0] for o in outs), [o[0] for o in outs]
 
 
 NEGATIVE = r"""

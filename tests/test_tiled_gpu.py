@@ -133,6 +133,28 @@ def test_tiled_tiles_of_several_rounds(gpu):
         assert_spmv_close(y, off, col, val, x, "long tiles")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("chunks", [1009, 1013, 1024])
+def test_tiled_wavefront_runs_of_64_chunks(gpu, dtype, chunks):
+    """One slice of a 16-slice matrix holds every entry: pass 1 takes it as ONE part of 1009..1024 chunks, i.e. 64 chunks per
+    wavefront -- the most a wavefront's descriptor register holds.  With 3 chunks in flight the loop's last trip looks at slots
+    64 and 65 of the run, which must be empty (round 3's kernel took the run's first two descriptors for them and overwrote their
+    product slots with the NEXT wavefront's chunks)."""
+    rng = np.random.default_rng(400 + chunks)
+    n_rows, n_cols = 8000, 16 * SLICE
+    total = 240 * chunks - 57
+    lens = np.full(n_rows, total // n_rows)
+    lens[: total - lens.sum()] += 1
+    off, col, val = random_crs(rng, n_rows, SLICE - 3, lens, dtype)
+    col = (col + 3 * SLICE).astype(np.uint32)  # all of them in slice 3
+    x = rng.uniform(-1, 1, n_cols).astype(dtype)
+    m = sm.SparseMatCRS.from_raw_parts(n_rows, n_cols, off, col, val)
+    y, lay = check_against_model(m, off, col, val, x, n_rows, n_cols, "64-chunk runs (%d)" % chunks)
+    per_slice = np.diff(lay["slice_chunks"].astype(np.int64))
+    assert per_slice.max() == per_slice.sum() and (per_slice.max() + 15) // 16 == 64, per_slice.max()
+    assert_spmv_close(y, off, col, val, x, "64-chunk runs")
+
+
 def test_tiled_refuses_columns_beyond_n_cols(gpu):
     """A handle made without validation may hold a column >= n_cols (smh_crs_create_dev's default); the tiled / column-blocked
     builders size their tables from n_cols and must refuse it instead of walking past them."""

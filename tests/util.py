@@ -111,3 +111,16 @@ def assert_spmv_close(y, off, col, val, x, what=""):
             denom = float(np.abs(exact).max())
             assert err_gpu.max() / denom <= err_ref.max() / denom + tol, what
     return y_ref
+
+
+def build_mock_rccl():
+    """tests/mock_rccl/libmock_rccl.so (the stand-in for RCCL that lets several ranks share one device), rebuilt when stale."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "mock_rccl", "mock_rccl.cpp")
+    so = os.path.join(root, "tests", "mock_rccl", "libmock_rccl.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", so,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return so
