@@ -1369,7 +1369,7 @@ int smh_crs_tiled_layout(smh_crs *m, uint32_t *n_slices_out, uint32_t *slice_col
     SMH_TRY(tiled_build(m));
     if (!m->t2_ok) return fail(SMH_ERR_INVALID, "the tiled copy could not be built for this matrix");
     if (n_slices_out) *n_slices_out = m->t2_n_cb;
-    if (slice_columns_out) *slice_columns_out = 16384u;
+    if (slice_columns_out) *slice_columns_out = tiled_slice_columns(m->dtype);
     if (rows_per_block_out) *rows_per_block_out = m->t2_R;
     if (n_row_blocks_out) *n_row_blocks_out = m->t2_n_rb;
     if (copy_entries_out) *copy_entries_out = (size_t)m->t2_tot;

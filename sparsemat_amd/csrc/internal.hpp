@@ -162,6 +162,7 @@ int launch_crs_stats(const uint32_t *off, const uint32_t *col, size_t n_rows, si
 // K2t (spmv_tiled.hip)
 void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *rows_per_block, uint32_t *n_rb);
 int tiled_build(::smh_crs *m);   // lazy; sets t2_ok
+uint32_t tiled_slice_columns(int dtype);
 int columns_within_n_cols(const ::smh_crs *m, const char *what);  // capi.hip: SMH_ERR_INDEX_RANGE when max_col >= n_cols
 void tiled_free(::smh_crs *m);
 int tiled_array(::smh_crs *m, int which, void *out, size_t capacity_bytes, size_t *bytes_out);

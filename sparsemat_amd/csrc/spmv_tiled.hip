@@ -45,8 +45,22 @@ namespace smh {
 
 int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s, uint64_t *total_out);  // spmv_colblock.hip
 
-constexpr uint32_t kT3Slice = 16384;     // columns per slice: 64 KiB (f32) / 128 KiB (f64) of x in LDS
-constexpr int kT3ExpandThreads = 1024;   // 16 wavefronts: one chunk each per step
+// columns per slice and threads per pass-1 workgroup, per value type (A/B builds override them: sparsemat_amd/build.py extra_flags).
+// f32: 16384 columns = 64 KiB of x + a 16 KiB stage -> two 1024-thread workgroups per CU.  f64: 16384 columns = 128 KiB + 32 KiB: ONE
+// workgroup per CU; the alternative that gives two (8192 columns, 512 threads: 64 + 16 KiB) was measured in round 4 and lost what it
+// gained to the product stream, which grows by 18 % on BASELINE C3 when a long row's entries spread over twice as many slices
+#ifndef SMH_T3_SLICE_F32
+#define SMH_T3_SLICE_F32 16384
+#endif
+#ifndef SMH_T3_SLICE_F64
+#define SMH_T3_SLICE_F64 16384
+#endif
+#ifndef SMH_T3_THREADS_F32
+#define SMH_T3_THREADS_F32 1024
+#endif
+#ifndef SMH_T3_THREADS_F64
+#define SMH_T3_THREADS_F64 1024
+#endif
 constexpr uint32_t kT3Snap = 16;         // a chunk start moves forward by up to this many entries to the next row boundary
 constexpr int kT3Batch = 4;              // tiles whose loads are in flight together, per wavefront
 constexpr int kT3Ahead = 3;              // pass 1: chunks whose loads are in flight per wavefront
@@ -59,6 +73,8 @@ template <> struct T3<float> {
     typedef float V1 __attribute__((ext_vector_type(4)));
     typedef float V2 __attribute__((ext_vector_type(4)));
     typedef uint32_t C2 __attribute__((ext_vector_type(2))); // 4 x u16
+    static constexpr uint32_t kSlice = SMH_T3_SLICE_F32;
+    static constexpr int kThreads = SMH_T3_THREADS_F32;      // pass 1: 16 wavefronts, one chunk each per step
     static constexpr uint32_t kCapRows = 3328;               // most rows of a row block: 3329 sums = 13 KiB of LDS per (one-wavefront) workgroup; measured, profiles/r03_k2t_rewrite_sweep1.log
 };
 template <> struct T3<double> {
@@ -66,6 +82,8 @@ template <> struct T3<double> {
     typedef double V1 __attribute__((ext_vector_type(4)));
     typedef double V2 __attribute__((ext_vector_type(2)));
     typedef uint32_t C2;                                     // 2 x u16
+    static constexpr uint32_t kSlice = SMH_T3_SLICE_F64;
+    static constexpr int kThreads = SMH_T3_THREADS_F64;
     static constexpr uint32_t kCapRows = 1664;               // 1665 x 8 B = 13 KiB
 };
 typedef uint32_t T3C1 __attribute__((ext_vector_type(2)));   // pass 1: the 4 codes of a lane
@@ -84,6 +102,9 @@ static double t3_tile_target(int dtype) {
     }
     return v;
 }
+static uint32_t t3_slice(int dtype) { return dtype == SMH_F64 ? T3<double>::kSlice : T3<float>::kSlice; }
+static_assert(T3<float>::kSlice <= 16384 && T3<double>::kSlice <= 16384 && T3<float>::kSlice % T3<float>::kThreads == 0 &&
+              T3<double>::kSlice % T3<double>::kThreads == 0, "14-bit column codes; whole values of x per thread");
 static uint32_t t3_cap_rows(int dtype) {
     uint32_t cap = dtype == SMH_F64 ? T3<double>::kCapRows : T3<float>::kCapRows;
     if (const char *e = getenv("SMH_TILED_CAP")) {  // tuning knob: most rows of a row block
@@ -164,7 +185,7 @@ struct T3Slot {
 };
 
 template <typename T, int AHEAD>
-__global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
+__global__ __launch_bounds__(T3<T>::kThreads) void k_t3_expand(const T *__restrict__ x, uint64_t x_len, const T *__restrict__ val,
                                                                  const uint16_t *__restrict__ code, const uint32_t *__restrict__ cptr,
                                                                  const T3Chunk *__restrict__ chunk, T *__restrict__ prod, uint32_t parts,
                                                                  uint32_t n_items, uint32_t per_xcd) {
@@ -173,6 +194,8 @@ __global__ __launch_bounds__(kT3ExpandThreads) void k_t3_expand(const T *__restr
     constexpr int E = T3<T>::E1, E2 = T3<T>::E2;
     static_assert(sizeof(V2) == 16, "16 bytes per store");
     constexpr uint32_t CH = 64u * E;
+    constexpr uint32_t kT3Slice = T3<T>::kSlice;
+    constexpr int kT3ExpandThreads = T3<T>::kThreads;
     extern __shared__ __attribute__((aligned(16))) char t3_smem[];
     T *xs = (T *)t3_smem;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -464,9 +487,9 @@ __global__ __launch_bounds__(1024) void k_t3_reduce(const T *__restrict__ prod, 
 }
 
 // ---- plan -------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_t3_keys(const uint32_t *__restrict__ col, uint64_t nnz, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
+__global__ __launch_bounds__(kBlock) void k_t3_keys(const uint32_t *__restrict__ col, uint64_t nnz, uint32_t slice, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kBlock) {
-        key[i] = col[i] / kT3Slice;
+        key[i] = col[i] / slice;
         idx[i] = (uint32_t)i;
     }
 }
@@ -549,7 +572,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_fill(const uint32_t *__restrict__
             const uint64_t q = q0 + a + j;
             const uint32_t i = perm[q];
             v = val[i];
-            cd = col[i] - s * kT3Slice;
+            cd = col[i] - s * T3<T>::kSlice;
             if (j > 0 && rowq[q] == rowq[q - 1]) cd |= kT3Cont;
             else ++runs;
         }
@@ -665,6 +688,7 @@ struct T3Scratch {
 // the geometry for rows of equal length and no two entries of a row in one slice (AUTO's estimate; the build cuts the row blocks
 // by the products the rows really have)
 void tiled_geometry(size_t n_rows, size_t n_cols, size_t nnz, int dtype, uint32_t *n_cb, uint32_t *R, uint32_t *n_rb) {
+    const uint32_t kT3Slice = t3_slice(dtype);
     const uint64_t cb = ((uint64_t)n_cols + kT3Slice - 1) / kT3Slice;
     *n_cb = (uint32_t)(cb ? cb : 1);
     const double per_row_and_slice = n_rows ? (double)nnz / (double)n_rows / (double)*n_cb : 0.0;
@@ -681,7 +705,8 @@ template <typename T>
 static int build_t(::smh_crs *m) {
     hipStream_t s = m->stream;
     const uint64_t nnz = m->nnz;
-    constexpr uint32_t CH = t3_chunk<T>(), STRIDE = t3_stride<T>();
+    constexpr uint32_t CH = t3_chunk<T>(), STRIDE = t3_stride<T>(), kT3Slice = T3<T>::kSlice;
+    constexpr int kT3ExpandThreads = T3<T>::kThreads;
     const uint64_t n_cb64 = ((uint64_t)m->n_cols + kT3Slice - 1) / kT3Slice;
     const uint32_t n_cb = (uint32_t)(n_cb64 ? n_cb64 : 1);
     if (nnz + nnz / 64 + 1024 >= (1ull << 32)) return fail(SMH_ERR_INVALID, "tiled variant: %llu entries are too many for its 32-bit product index", (unsigned long long)nnz);
@@ -696,7 +721,7 @@ static int build_t(::smh_crs *m) {
     SMH_TRY(tmp.alloc(&d_start, (size_t)n_cb + 1));
     const unsigned grid = 2048;
     if (nnz) {
-        hipLaunchKernelGGL(k_t3_keys, dim3(grid), dim3(kBlock), 0, s, m->d_col, nnz, key, idx);
+        hipLaunchKernelGGL(k_t3_keys, dim3(grid), dim3(kBlock), 0, s, m->d_col, nnz, kT3Slice, key, idx);
         SMH_HIP(hipGetLastError());
         size_t bytes = 0;
         void *ws = nullptr;
@@ -825,6 +850,8 @@ static int build_t(::smh_crs *m) {
     return SMH_OK;
 }
 
+uint32_t tiled_slice_columns(int dtype) { return t3_slice(dtype); }
+
 void tiled_free(::smh_crs *m) {
     (void)hipFree(m->d_t2_val); (void)hipFree(m->d_t2_prod); (void)hipFree(m->d_t2_code); (void)hipFree(m->d_t2_row);
     (void)hipFree(m->d_t3_cptr); (void)hipFree(m->d_t3_chunk); (void)hipFree(m->d_t2_tstart); (void)hipFree(m->d_t2_rbstart);
@@ -879,7 +906,8 @@ int tiled_array(::smh_crs *m, int which, void *out, size_t capacity_bytes, size_
 
 template <typename T>
 static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStream_t s) {
-    constexpr uint32_t CH = t3_chunk<T>();
+    constexpr uint32_t CH = t3_chunk<T>(), kT3Slice = T3<T>::kSlice;
+    constexpr int kT3ExpandThreads = T3<T>::kThreads;
     const size_t lds1 = ((size_t)kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T), lds2 = ((size_t)m->t2_R + 1) * sizeof(T);
     static const uint32_t xcd_map = getenv("SMH_TILED_XCD") ? (uint32_t)atoi(getenv("SMH_TILED_XCD")) : 3u;  // tuning knob: bit 0 pass 1, bit 1 pass 2
     if (m->t3_n_chunks) {
@@ -888,8 +916,9 @@ static int launch_t(::smh_crs *m, const void *x, size_t x_len, void *y, hipStrea
         const uint64_t per_slice = (uint64_t)m->t3_n_chunks * CH / (m->t2_n_cb ? m->t2_n_cb : 1);
         uint32_t parts = (uint32_t)((per_slice + 32768) / 65536);
         parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
-        // (a wavefront keeps the descriptors of its chunks in one register: at most 64 chunks each, 1024 per workgroup)
-        const uint32_t need = (m->t3_max_slice_chunks + 1023u) / 1024u;
+        // (a wavefront keeps the descriptors of its chunks in one register: at most 64 chunks each, 1024 per 16-wavefront workgroup)
+        constexpr uint32_t per_wg = 64u * (uint32_t)(kT3ExpandThreads / 64);
+        const uint32_t need = (m->t3_max_slice_chunks + per_wg - 1u) / per_wg;
         if (parts < need) parts = need;
         static const int ahead = getenv("SMH_TILED_AHEAD") ? atoi(getenv("SMH_TILED_AHEAD")) : kT3Ahead;  // tuning knob: chunks in flight per wavefront
         auto *exp = ahead == 2 ? k_t3_expand<T, 2> : ahead == 4 ? k_t3_expand<T, 4> : k_t3_expand<T, 3>;
