@@ -35,8 +35,11 @@
 // run is its product sum.  Pass 2 adds the product sums of a row to its running sum in slice order (a (row, slice) pair cut by a
 // chunk boundary has its parts merged first by the same scan, inside one round of 64 E products).
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "internal.hpp"
@@ -64,6 +67,7 @@ int device_exclusive_scan_u32(uint32_t *data, uint64_t n, hipStream_t s, uint64_
 constexpr uint32_t kT3Snap = 16;         // a chunk start moves forward by up to this many entries to the next row boundary
 constexpr int kT3Batch = 4;              // tiles whose loads are in flight together, per wavefront
 constexpr int kT3Ahead = 3;              // pass 1: chunks whose loads are in flight per wavefront
+constexpr uint32_t kT3RowGroup = 32;      // row blocks begin at multiples of this many rows (the build counts products per group)
 constexpr uint32_t kT3Cont = 0x8000u;    // code bit 15: same row as the entry before (never set on a chunk's first entry)
 constexpr uint32_t kT3ColMask = 0x3FFFu;
 
@@ -487,12 +491,21 @@ __global__ __launch_bounds__(1024) void k_t3_reduce(const T *__restrict__ prod, 
 }
 
 // ---- plan -------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_t3_keys(const uint32_t *__restrict__ col, uint64_t nnz, uint32_t slice, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kBlock) {
-        key[i] = col[i] / slice;
-        idx[i] = (uint32_t)i;
-    }
-}
+// The build sorts the ENTRIES THEMSELVES -- {row, column, value} travels as the sort's payload -- by column slice (stable: inside a
+// slice the (row, storage) order of the CRS arrays stays).  Round 3 sorted entry indices and gathered values / columns / rows through
+// them afterwards: 320 M random 4- and 8-byte reads plus a binary search per entry for its row, 21 of the build's 54 ms on BASELINE
+// C2-uniform; now every later kernel streams the sorted entries.
+template <typename T> struct T3Entry { uint32_t row, col; T val; };
+template <typename T> struct T3LoadEntry {  // entry i of the CRS arrays (rows_e: the row of every entry, assemble.hip::expand_rows)
+    const uint32_t *rows_e, *col;
+    const T *val;
+    __device__ __forceinline__ T3Entry<T> operator()(uint64_t i) const { return T3Entry<T>{rows_e[i], col[i], val[i]}; }
+};
+struct T3LoadKey {
+    const uint32_t *col;
+    uint32_t slice;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return col[i] / slice; }
+};
 
 // start[b] = first position of the sorted keys holding a value >= b (b = 0 .. n_cb)
 __global__ __launch_bounds__(kBlock) void k_t3_bounds(const uint32_t *__restrict__ key_s, uint64_t nnz, uint32_t n_cb, uint64_t *__restrict__ start) {
@@ -504,20 +517,6 @@ __global__ __launch_bounds__(kBlock) void k_t3_bounds(const uint32_t *__restrict
         if (key_s[mid] < b) lo = mid + 1; else hi = mid;
     }
     start[b] = lo;
-}
-
-// rowq[q] = the row of the entry of sorted rank q: the last one with off[row] <= perm[q]
-__global__ __launch_bounds__(kBlock) void k_t3_rows(const uint32_t *__restrict__ off, uint64_t n_rows, const uint32_t *__restrict__ perm, uint64_t nnz,
-                                                     uint32_t *__restrict__ rowq) {
-    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nnz; q += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t i = perm[q];
-        uint64_t lo = 0, hi = n_rows;
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) / 2;
-            if (off[mid + 1] <= i) lo = mid + 1; else hi = mid;
-        }
-        rowq[q] = (uint32_t)lo;
-    }
 }
 
 // the slice of chunk c: the last s with cptr[s] <= c
@@ -532,8 +531,9 @@ __device__ __forceinline__ uint32_t t3_slice_of(const uint32_t *__restrict__ cpt
 
 // cstart[c] = where chunk c begins among its slice's sorted entries: nominally at (c - cptr[s]) * stride, moved forward to the
 // next row boundary when there is one within kT3Snap entries (so that a (row, slice) pair is not cut); never past the slice's end
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_t3_chunk_starts(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t n_chunks,
-                                                             const uint64_t *__restrict__ start, const uint32_t *__restrict__ rowq,
+                                                             const uint64_t *__restrict__ start, const T3Entry<T> *__restrict__ ps,
                                                              uint32_t stride, uint32_t *__restrict__ cstart) {
     const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= n_chunks) return;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_chunk_starts(const uint32_t *__re
     for (uint32_t j = 0; j < kT3Snap; ++j) {
         const uint64_t q = nominal + j;
         if (q >= cnt) { at = cnt; break; }
-        if (q == 0 || rowq[q0 + q] != rowq[q0 + q - 1]) { at = q; break; }
+        if (q == 0 || ps[q0 + q].row != ps[q0 + q - 1].row) { at = q; break; }
     }
     cstart[c] = (uint32_t)at;
 }
@@ -552,8 +552,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_chunk_starts(const uint32_t *__re
 // one wavefront per chunk: the chunk's slots of val / code (continuation bits included) and the number of its runs
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_t3_fill(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t n_chunks, const uint64_t *__restrict__ start,
-                                                     const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ rowq,
-                                                     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ col, const T *__restrict__ val,
+                                                     const uint32_t *__restrict__ cstart, const T3Entry<T> *__restrict__ ps,
                                                      T *__restrict__ val_a, uint16_t *__restrict__ code_a, uint32_t *__restrict__ clen,
                                                      uint32_t *__restrict__ ntails) {
     constexpr uint32_t CH = t3_chunk<T>();
@@ -570,10 +569,10 @@ __global__ __launch_bounds__(kBlock) void k_t3_fill(const uint32_t *__restrict__
         uint32_t cd = 0;
         if (j < len) {
             const uint64_t q = q0 + a + j;
-            const uint32_t i = perm[q];
-            v = val[i];
-            cd = col[i] - s * T3<T>::kSlice;
-            if (j > 0 && rowq[q] == rowq[q - 1]) cd |= kT3Cont;
+            const T3Entry<T> e = ps[q];
+            v = e.val;
+            cd = e.col - s * T3<T>::kSlice;
+            if (j > 0 && e.row == ps[q - 1].row) cd |= kT3Cont;
             else ++runs;
         }
         val_a[(uint64_t)c * CH + j] = v;
@@ -591,9 +590,9 @@ __global__ __launch_bounds__(kBlock) void k_t3_fill(const uint32_t *__restrict__
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__ cptr, uint32_t n_cb, uint32_t n_chunks, const uint64_t *__restrict__ start,
                                                      const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ clen,
-                                                     const uint32_t *__restrict__ obase, const uint32_t *__restrict__ rowq,
+                                                     const uint32_t *__restrict__ obase, const T3Entry<T> *__restrict__ ps,
                                                      const uint16_t *__restrict__ code_a, uint32_t *__restrict__ prow, uint32_t *__restrict__ preal,
-                                                     uint32_t *__restrict__ rcount, T3Chunk *__restrict__ desc, uint32_t *__restrict__ any_cut) {
+                                                     uint32_t *__restrict__ gcount, T3Chunk *__restrict__ desc, uint32_t *__restrict__ any_cut) {
     constexpr uint32_t CH = t3_chunk<T>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -609,17 +608,17 @@ __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__
         const uint64_t m = __ballot(head);
         const uint32_t rank = done + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (head) {
-            const uint32_t row = rowq[q0 + j];
+            const uint32_t row = ps[q0 + j].row;
             prow[ob + rank] = row;
-            atomicAdd(rcount + row, 1u);
+            atomicAdd(gcount + row / kT3RowGroup, 1u);  // products per group of rows: what the row blocks are cut by
         }
         done += (uint32_t)__popcll(m);
     }
-    if (len) last_row = rowq[q0 + len - 1];
+    if (len) last_row = ps[q0 + len - 1].row;
     for (uint32_t k = done + lane; k < slots; k += 64) prow[ob + k] = last_row;
     // does the chunk's last run go on in the next chunk (a (row, slice) pair longer than the snap distance, cut here)?
     bool cut = false;
-    if (len && c + 1 < cptr[s + 1] && clen[c + 1]) cut = rowq[start[s] + cstart[c + 1]] == last_row;
+    if (len && c + 1 < cptr[s + 1] && clen[c + 1]) cut = ps[start[s] + cstart[c + 1]].row == last_row;
     if (lane == 0) {
         preal[c] = done | (cut ? 0x80000000u : 0u);
         if (cut) atomicOr(any_cut, 1u);
@@ -710,36 +709,48 @@ static int build_t(::smh_crs *m) {
     const uint64_t n_cb64 = ((uint64_t)m->n_cols + kT3Slice - 1) / kT3Slice;
     const uint32_t n_cb = (uint32_t)(n_cb64 ? n_cb64 : 1);
     if (nnz + nnz / 64 + 1024 >= (1ull << 32)) return fail(SMH_ERR_INVALID, "tiled variant: %llu entries are too many for its 32-bit product index", (unsigned long long)nnz);
+    // SMH_TILED_BUILD_TRACE=1 (development aid): the stages' wall times, each behind a stream synchronisation, on stderr
+    static const bool trace = getenv("SMH_TILED_BUILD_TRACE") && atoi(getenv("SMH_TILED_BUILD_TRACE")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[k2t build] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     T3Scratch tmp;
-    uint32_t *key = nullptr, *key_s = nullptr, *idx = nullptr, *perm = nullptr, *rowq = nullptr;
+    uint32_t *rows_e = nullptr, *key_s = nullptr;
+    T3Entry<T> *ps = nullptr;  // the entries sorted by slice (inside a slice: row, storage order)
     uint64_t *d_start = nullptr;
-    SMH_TRY(tmp.alloc(&key, nnz));
+    SMH_TRY(tmp.alloc(&rows_e, nnz));
     SMH_TRY(tmp.alloc(&key_s, nnz));
-    SMH_TRY(tmp.alloc(&idx, nnz));
-    SMH_TRY(tmp.alloc(&perm, nnz));
-    SMH_TRY(tmp.alloc(&rowq, nnz));
+    SMH_TRY(tmp.alloc(&ps, nnz));
     SMH_TRY(tmp.alloc(&d_start, (size_t)n_cb + 1));
     const unsigned grid = 2048;
     if (nnz) {
-        hipLaunchKernelGGL(k_t3_keys, dim3(grid), dim3(kBlock), 0, s, m->d_col, nnz, kT3Slice, key, idx);
-        SMH_HIP(hipGetLastError());
+        SMH_TRY(expand_rows(m->d_off, m->n_rows, rows_e, s));
+        stage("scratch + rows of entries");
+        // keys and payload are READ through iterators over the CRS arrays (nothing is materialised before the first pass)
+        auto keys_in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(0), T3LoadKey{m->d_col, kT3Slice});
+        auto vals_in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(0), T3LoadEntry<T>{rows_e, m->d_col, (const T *)m->d_val});
         size_t bytes = 0;
         void *ws = nullptr;
-        SMH_HIP(rocprim::radix_sort_pairs(ws, bytes, key, key_s, idx, perm, (size_t)nnz, 0u, t3_bits_for(n_cb - 1), s));
+        SMH_HIP(rocprim::radix_sort_pairs(ws, bytes, keys_in, key_s, vals_in, ps, (size_t)nnz, 0u, t3_bits_for(n_cb - 1), s));
         SMH_HIP(hipMalloc(&ws, bytes ? bytes : 16));
-        const hipError_t e1 = rocprim::radix_sort_pairs(ws, bytes, key, key_s, idx, perm, (size_t)nnz, 0u, t3_bits_for(n_cb - 1), s);
+        const hipError_t e1 = rocprim::radix_sort_pairs(ws, bytes, keys_in, key_s, vals_in, ps, (size_t)nnz, 0u, t3_bits_for(n_cb - 1), s);
         const hipError_t e2 = hipStreamSynchronize(s);
         (void)hipFree(ws);
         SMH_HIP(e1);
         SMH_HIP(e2);
-        hipLaunchKernelGGL(k_t3_rows, dim3(grid), dim3(kBlock), 0, s, m->d_off, (uint64_t)m->n_rows, perm, nnz, rowq);
-        SMH_HIP(hipGetLastError());
+        stage("radix sort (entries as payload)");
     }
     hipLaunchKernelGGL(k_t3_bounds, dim3((n_cb + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, key_s, nnz, n_cb, d_start);
     SMH_HIP(hipGetLastError());
     std::vector<uint64_t> start((size_t)n_cb + 1);
     SMH_HIP(hipMemcpyAsync(start.data(), d_start, start.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     SMH_HIP(hipStreamSynchronize(s));
+    stage("slice bounds");
     // chunks: ceil(entries of the slice / stride) each (a chunk whose start was moved past the slice's end stays empty)
     std::vector<uint32_t> cptr((size_t)n_cb + 1);
     cptr[0] = 0;
@@ -752,12 +763,13 @@ static int build_t(::smh_crs *m) {
     uint32_t max_slice_chunks = 0;
     for (uint32_t b = 0; b < n_cb; ++b) max_slice_chunks = std::max(max_slice_chunks, cptr[b + 1] - cptr[b]);
     const uint64_t slots = (uint64_t)n_chunks * CH;
-    uint32_t *cstart = nullptr, *clen = nullptr, *obase = nullptr, *preal = nullptr, *rcount = nullptr, *prow = nullptr;
+    uint32_t *cstart = nullptr, *clen = nullptr, *obase = nullptr, *preal = nullptr, *gcount = nullptr, *prow = nullptr;
+    const size_t n_groups = (m->n_rows + kT3RowGroup - 1) / kT3RowGroup;
     SMH_TRY(tmp.alloc(&cstart, (size_t)n_chunks));
     SMH_TRY(tmp.alloc(&clen, (size_t)n_chunks));
     SMH_TRY(tmp.alloc(&obase, (size_t)n_chunks + 1));
     SMH_TRY(tmp.alloc(&preal, (size_t)n_chunks));
-    SMH_TRY(tmp.alloc(&rcount, m->n_rows));
+    SMH_TRY(tmp.alloc(&gcount, n_groups));
     uint32_t *any_cut = nullptr;  // does any chunk boundary cut a (row, slice) pair?
     SMH_TRY(tmp.alloc(&any_cut, 1));
     SMH_HIP(hipMemsetAsync(any_cut, 0, sizeof(uint32_t), s));
@@ -766,43 +778,49 @@ static int build_t(::smh_crs *m) {
     SMH_HIP(hipMalloc((void **)&m->d_t3_cptr, ((size_t)n_cb + 1) * sizeof(uint32_t)));
     SMH_HIP(hipMalloc((void **)&m->d_t3_chunk, ((size_t)n_chunks + 1) * sizeof(T3Chunk)));
     SMH_HIP(hipMemcpyAsync(m->d_t3_cptr, cptr.data(), cptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    SMH_HIP(hipMemsetAsync(rcount, 0, (m->n_rows ? m->n_rows : 1) * sizeof(uint32_t), s));
+    SMH_HIP(hipMemsetAsync(gcount, 0, (n_groups ? n_groups : 1) * sizeof(uint32_t), s));
     SMH_HIP(hipMemsetAsync(obase, 0, ((size_t)n_chunks + 1) * sizeof(uint32_t), s));
     const unsigned wgrid = (n_chunks + kBlock / 64 - 1) / (kBlock / 64);
     if (n_chunks) {
-        hipLaunchKernelGGL(k_t3_chunk_starts, dim3((n_chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, rowq, STRIDE, cstart);
+        hipLaunchKernelGGL(k_t3_chunk_starts<T>, dim3((n_chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, ps, STRIDE, cstart);
         SMH_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_t3_fill<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, rowq, perm, m->d_col, (const T *)m->d_val,
+    stage("allocs + chunk starts");
+        hipLaunchKernelGGL(k_t3_fill<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, ps,
                            (T *)m->d_t2_val, m->d_t2_code, clen, obase);
         SMH_HIP(hipGetLastError());
+    stage("fill");
     }
     uint64_t n_prod = 0;
     SMH_TRY(device_exclusive_scan_u32(obase, (uint64_t)n_chunks + 1, s, &n_prod));  // obase[c] = products before chunk c; obase[n_chunks] = all
+    stage("scan");
     if (n_prod >= (1ull << 32) - 4 * CH) return fail(SMH_ERR_INVALID, "tiled variant: %llu products are too many for its 32-bit index", (unsigned long long)n_prod);
     SMH_TRY(tmp.alloc(&prow, (size_t)n_prod));
     if (n_chunks) {
-        hipLaunchKernelGGL(k_t3_prow<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, clen, obase, rowq, m->d_t2_code, prow, preal,
-                           rcount, (T3Chunk *)m->d_t3_chunk, any_cut);
+        hipLaunchKernelGGL(k_t3_prow<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, clen, obase, ps, m->d_t2_code, prow, preal,
+                           gcount, (T3Chunk *)m->d_t3_chunk, any_cut);
         SMH_HIP(hipGetLastError());
+    stage("prow");
     }
     uint32_t h_cut = 0;
     SMH_HIP(hipMemcpyAsync(&h_cut, any_cut, sizeof h_cut, hipMemcpyDeviceToHost, s));  // (synchronised with the row counts below)
     // row blocks of equal PRODUCT counts (a tile = one slice of a block: ~target products whatever the row lengths), at most `cap`
-    // rows each (their sums share the LDS); greedy over the rows' product counts, on the host
+    // rows each (their sums share the LDS); greedy on the host over the product counts of GROUPS of 32 rows -- 1.25 MB to fetch for
+    // 10 M rows, where round 3 fetched a count per row and walked them all (15 of the build's 54 ms).  Row blocks therefore begin at
+    // multiples of 32 rows; which rows share a block changes nothing in any row's sum.
     std::vector<uint32_t> rb_start;
     uint32_t n_rb = 0, R = 1;
     {
-        const uint32_t cap = t3_cap_rows(m->dtype);
+        const uint32_t cap_g = std::max(1u, t3_cap_rows(m->dtype) / kT3RowGroup);
         const uint64_t per_block = (uint64_t)(t3_tile_target(m->dtype) * (double)n_cb);
-        std::vector<uint32_t> h_cnt(m->n_rows);
-        if (m->n_rows) SMH_HIP(hipMemcpyAsync(h_cnt.data(), rcount, h_cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        std::vector<uint32_t> h_cnt(n_groups);
+        if (n_groups) SMH_HIP(hipMemcpyAsync(h_cnt.data(), gcount, h_cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         SMH_HIP(hipStreamSynchronize(s));
         size_t r = 0;
-        while (r < m->n_rows) {
-            rb_start.push_back((uint32_t)r);
+        while (r < n_groups) {
+            rb_start.push_back((uint32_t)(r * kT3RowGroup));
             uint64_t have = 0;
             size_t e = r;
-            while (e < m->n_rows && e - r < cap && (e == r || have + h_cnt[e] <= per_block)) have += h_cnt[e++];
+            while (e < n_groups && e - r < cap_g && (e == r || have + h_cnt[e] <= per_block)) have += h_cnt[e++];
             r = e;
         }
         if (rb_start.empty()) rb_start.push_back(0);
@@ -810,6 +828,7 @@ static int build_t(::smh_crs *m) {
         n_rb = (uint32_t)(rb_start.size() - 1);
         for (uint32_t b = 0; b < n_rb; ++b) R = std::max(R, rb_start[b + 1] - rb_start[b]);
     }
+    stage("group counts to host + greedy");
     const uint64_t table_entries = (uint64_t)(n_rb + 1) * n_cb;
     if (table_entries * 4 > (4ull << 30))
         return fail(SMH_ERR_INVALID, "tiled variant: %u column slices x %u row blocks need a tile table beyond 4 GiB", n_cb, n_rb);
@@ -824,11 +843,13 @@ static int build_t(::smh_crs *m) {
     if (n_chunks) {
         hipLaunchKernelGGL(k_t3_rowcode, dim3(wgrid), dim3(kBlock), 0, s, n_chunks, obase, preal, prow, m->d_t2_rbstart, n_rb, (uint32_t)sizeof(T), m->d_t2_row);
         SMH_HIP(hipGetLastError());
+    stage("allocs + rowcode");
     }
     // (obase of a slice's first chunk = where its products begin; empty slices have none)
     hipLaunchKernelGGL(k_t3_table, dim3(grid), dim3(kBlock), 0, s, prow, m->d_t3_cptr, obase, n_cb, n_rb, m->d_t2_rbstart, m->d_t2_tstart);
     SMH_HIP(hipGetLastError());
     SMH_HIP(hipStreamSynchronize(s));
+    stage("table");
     // 128 KiB and more of dynamic LDS need the attribute on every device the kernel runs on: set with each build, on the matrix's device
     for (const void *f : {reinterpret_cast<const void *>(k_t3_expand<T, 2>), reinterpret_cast<const void *>(k_t3_expand<T, 3>), reinterpret_cast<const void *>(k_t3_expand<T, 4>)})
         SMH_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kT3Slice + (kT3ExpandThreads / 64) * CH) * sizeof(T))));

@@ -11,6 +11,7 @@ import numpy as np
 
 SLICE = 16384
 SNAP = 16
+GROUP = 32  # row blocks begin at multiples of this many rows
 CONT = 0x8000
 TARGET = {np.dtype(np.float32): 174.0, np.dtype(np.float64): 60.0}
 CAP = {np.dtype(np.float32): 3328, np.dtype(np.float64): 1664}
@@ -154,18 +155,21 @@ class TiledModel:
             if c_slice[c + 1] == c_slice[c] and self.c_len[c] and self.c_len[c + 1] and row_s[c + 1][0] == row_s[c][self.c_len[c] - 1]:
                 counts[obase[c]:obase[c + 1]] = True
         self.counts = counts  # slots that take part in pass 2 (real ones + the zero padding of cut pairs)
-        # row blocks of equal product counts
+        # row blocks of equal product counts, cut at multiples of GROUP rows (the build counts products per group of rows)
         rcount = np.bincount(prow[real], minlength=n_rows) if self.n_prod else np.zeros(n_rows, dtype=np.int64)
+        n_groups = -(-n_rows // GROUP)
+        gcount = np.add.reduceat(rcount, np.arange(0, n_rows, GROUP)) if n_rows else np.zeros(0, dtype=np.int64)
         target = TARGET[dt] if target is None else target
         cap = CAP[dt] if cap is None else cap
+        cap_g = max(1, cap // GROUP)
         per_block = int(target * self.n_cb)
         rb = []
         r = 0
-        while r < n_rows:
-            rb.append(r)
+        while r < n_groups:
+            rb.append(r * GROUP)
             have_n, e = 0, r
-            while e < n_rows and e - r < cap and (e == r or have_n + rcount[e] <= per_block):
-                have_n += rcount[e]
+            while e < n_groups and e - r < cap_g and (e == r or have_n + gcount[e] <= per_block):
+                have_n += gcount[e]
                 e += 1
             r = e
         if not rb:
