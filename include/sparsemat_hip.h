@@ -38,7 +38,7 @@ extern "C" {
  * pointer) and the product count has its own entry point, smh_crs_tiled_products; REMOVED since version 2:
  * smh_crs_set_stream_windows and smh_crs_stream_windows (K1s's column windows are chosen by the inspector alone; the K1s-w kernel
  * they steered left the library); ADDED: smh_crs_tiled_products, smh_crs_prepare_stats,
- * smh_comm_ranks_seen, smh_rccl_version.  A caller checks smh_abi_version() ==
+ * smh_comm_ranks_seen, smh_rccl_version, smh_par_set_threads.  A caller checks smh_abi_version() ==
  * SMH_ABI_VERSION once at load time (rust/src/lib.rs does). */
 #define SMH_ABI_VERSION 3
 
@@ -498,6 +498,13 @@ int smh_par_backend(const smh_par *p);
  * the rows [*row_begin, *row_end) (local) of local block i that its kernel for `variant` treats as interior (equal: none -- the
  * call is then not split for that block). */
 int smh_par_set_overlap(smh_par *p, int on);
+/* One-process handles with several local blocks: every block's runtime calls (kernel launches, event records and waits) are issued
+ * by a host thread of its own -- block 0's by the caller -- instead of one thread issuing them block after block (the reference's
+ * intended design is independent blocks, sparsemat_par.rs:54-64).  mode: -1 automatic (off unless SMH_PAR_THREADS=1: with the blocks
+ * on ONE device, the only set-up measured so far, the runtime serialises its callers and nothing is gained), 0 one issuing thread,
+ * 1 a thread per block.  Streams, events, kernels and their order per block do not depend on it: results are
+ * bit for bit the same.  Synchronises the handle's streams. */
+int smh_par_set_threads(smh_par *p, int mode);
 int smh_par_interior(const smh_par *p, size_t local_block, int variant, size_t *row_begin, size_t *row_end);
 /* what SMH_EXCHANGE_AUTO resolves to for this matrix (WINDOW when the matrix is square and no block
  * receives half of the vector or more, else ALLGATHER; NONE for one block) and the largest number of

@@ -134,6 +134,7 @@ SIGNATURES = {
     "smh_par_set_backend": (_int, [_vp, _int]),
     "smh_par_backend": (_int, [_vp]),
     "smh_par_set_overlap": (_int, [_vp, _int]),
+    "smh_par_set_threads": (_int, [_vp, _int]),
     "smh_par_interior": (_int, [_vp, _sz, _int, C.POINTER(_sz), C.POINTER(_sz)]),
     "smh_par_exchange_mode": (_int, [_vp, _int, C.POINTER(_int), C.POINTER(_sz)]),
     "smh_par_plan": (_int, [_sz, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_int), C.POINTER(_sz)]),

@@ -29,10 +29,16 @@
 
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace smh;
@@ -142,6 +148,27 @@ __global__ void __launch_bounds__(kBlock) k_par_remote_tiles(const uint32_t *__r
 
 }  // namespace
 
+// One ISSUING HOST THREAD per local block (one-process handles with several blocks).  The solver and the product step are
+// sequences of PHASES -- "every block does X on its streams" -- separated by the points where one block's stream must wait for an
+// event another block has recorded (the record has to be issued, on the host, before the wait is).  Round 3 issued every phase from
+// the caller's thread: ~30 runtime calls per block and CG iteration, 0.84-0.92 ms per iteration with 8 blocks on one device against
+// 0.27 ms of kernels.  Now block k's calls are issued by thread k (block 0's by the caller), all at once, and the phases meet at a
+// host barrier; the streams, events, kernels and their order per block are unchanged, so every result is bit for bit the same.
+// (An earlier attempt to get rid of the calls -- ONE hipGraph captured across all blocks' streams -- died inside the runtime during
+// capture from 4 blocks on; this needs nothing of the graph machinery.)
+struct ParPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> gen{0};       // phases handed out so far
+    std::atomic<uint32_t> pending{0};   // workers still inside the current phase
+    std::atomic<uint32_t> sleepers{0};  // workers blocked on cv (a phase start wakes them)
+    std::atomic<bool> stop{false};
+    const std::function<int(size_t)> *fn = nullptr;
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+};
+
 struct smh_par {
     int dtype = SMH_F32;
     size_t n_rows = 0, n_cols = 0, rows_per_block = 0, n_blocks = 0;
@@ -159,6 +186,8 @@ struct smh_par {
     void *h_sc = nullptr;           // pinned copy of block 0's CG scalars
     smh_par_vec *cg_p = nullptr;    // the search direction of the solver (full-length per block)
     smh_par_vec *io_b = nullptr, *io_x = nullptr;  // staging of the host-vector solve
+    ParPool *pool = nullptr;        // issuing threads (lazy; blocks 1 .. n_local - 1)
+    int use_threads = -1;           // -1 automatic (on with more than one local block; SMH_PAR_THREADS=0 switches it off), 0 never, 1 always
 };
 
 struct smh_par_vec {
@@ -170,6 +199,10 @@ struct smh_par_vec {
 namespace {
 
 int use(const ParBlock &blk) {
+    // (called before every runtime call of a block; a thread that already is on the block's device -- always, when the blocks share
+    // one -- skips the runtime's device switch)
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == blk.device) return SMH_OK;
     SMH_HIP(hipSetDevice(blk.device));
     return SMH_OK;
 }
@@ -186,6 +219,88 @@ int sync_all(smh_par *p) {
         SMH_HIP(hipStreamSynchronize(blk.s));
         if (blk.sx) SMH_HIP(hipStreamSynchronize(blk.sx));
     }
+    return SMH_OK;
+}
+
+bool threads_wanted(const smh_par *p) {
+    if (p->b.size() < 2) return false;
+    if (p->use_threads >= 0) return p->use_threads != 0;
+    // automatic = OFF: measured with 8 blocks on one device (the only multi-block set-up this build has had), the runtime serialises
+    // its callers -- 8 threads issue an iteration of the solver in 0.37 ms where one thread takes 0.47 ms, and the interleaving they
+    // produce costs the device more than that saves (0.59 against 0.475 ms per iteration, profiles/r04_par_cg_threads.log).  On a
+    // node, a device per block, the runtime's per-device queues may make it pay: SMH_PAR_THREADS=1 / smh_par_set_threads(p, 1)
+    static const bool on = getenv("SMH_PAR_THREADS") && atoi(getenv("SMH_PAR_THREADS")) != 0;  // tuning knob
+    return on;
+}
+
+void pool_worker(smh_par *p, size_t k) {
+    ParPool &P = *p->pool;
+    (void)hipSetDevice(p->b[k].device);
+    uint64_t seen = 0;
+    for (;;) {
+        // wait for the next phase: spin while the solver is running (phases follow each other within microseconds), sleep otherwise
+        unsigned spins = 0;
+        while (P.gen.load(std::memory_order_acquire) == seen && !P.stop.load(std::memory_order_acquire)) {
+            if (++spins < 200000u) {
+                __builtin_ia32_pause();
+            } else {
+                std::unique_lock<std::mutex> lk(P.mu);
+                P.sleepers.fetch_add(1, std::memory_order_acq_rel);
+                P.cv.wait(lk, [&] { return P.gen.load(std::memory_order_acquire) != seen || P.stop.load(std::memory_order_acquire); });
+                P.sleepers.fetch_sub(1, std::memory_order_acq_rel);
+                spins = 0;
+            }
+        }
+        if (P.stop.load(std::memory_order_acquire)) return;
+        seen = P.gen.load(std::memory_order_acquire);
+        const int rc = (*P.fn)(k);
+        P.rc[k] = rc;
+        if (rc != SMH_OK) P.msg[k] = smh_last_error();  // (the message is thread-local: hand it to the caller)
+        P.pending.fetch_sub(1, std::memory_order_acq_rel);
+    }
+}
+
+void pool_destroy(smh_par *p) {
+    if (!p->pool) return;
+    {
+        std::lock_guard<std::mutex> lk(p->pool->mu);
+        p->pool->stop.store(true, std::memory_order_release);
+    }
+    p->pool->cv.notify_all();
+    for (std::thread &t : p->pool->th) t.join();
+    delete p->pool;
+    p->pool = nullptr;
+}
+
+// fn(k) for every local block k -- concurrently, one thread per block, when the handle has its issuing threads; returns when all
+// have returned (a HOST barrier: what fn issued is on the streams, not necessarily executed), with the first failure
+int par_for(smh_par *p, const std::function<int(size_t)> &fn) {
+    const size_t nl = p->b.size();
+    if (!threads_wanted(p)) {
+        for (size_t k = 0; k < nl; ++k) SMH_TRY(fn(k));
+        return SMH_OK;
+    }
+    if (!p->pool) {
+        p->pool = new (std::nothrow) ParPool();
+        if (!p->pool) return fail(SMH_ERR_OOM, "host allocation failed");
+        p->pool->rc.assign(nl, SMH_OK);
+        p->pool->msg.assign(nl, std::string());
+        for (size_t k = 1; k < nl; ++k) p->pool->th.emplace_back(pool_worker, p, k);
+    }
+    ParPool &P = *p->pool;
+    P.fn = &fn;
+    P.pending.store((uint32_t)(nl - 1), std::memory_order_release);
+    {
+        // (the generation changes under the lock a sleeper checks it under: no wake-up is lost)
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.gen.fetch_add(1, std::memory_order_acq_rel);
+    }
+    if (P.sleepers.load(std::memory_order_acquire)) P.cv.notify_all();
+    const int rc0 = fn(0);  // block 0 is the caller's
+    while (P.pending.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    if (rc0 != SMH_OK) return rc0;
+    for (size_t k = 1; k < nl; ++k)
+        if (P.rc[k] != SMH_OK) return fail(P.rc[k], "%s", P.msg[k].c_str());
     return SMH_OK;
 }
 
@@ -343,62 +458,74 @@ int exchange_rccl(smh_par *p, smh_par_vec *v, int mode, bool side) {
     return SMH_OK;
 }
 
-int exchange_peer(smh_par *p, smh_par_vec *v, int mode, bool side) {
-    const size_t vs = dtype_size(p->dtype), nb = p->n_blocks, nl = p->b.size();
-    const size_t wpe = vs / 4;  // 32-bit words per entry
-    // 1. every block's slice is complete once what its stream holds so far has run
-    for (ParBlock &blk : p->b) {
-        SMH_TRY(use(blk));
-        SMH_HIP(hipEventRecord(blk.ev_slice, xs(blk, side)));
-    }
-    // 2. every block pulls what it needs from the owners' buffers
-    std::vector<uint8_t> pulled(nl * nl, 0);  // [q * nl + src]: q read from src
-    for (size_t qi = 0; qi < nl; ++qi) {
-        ParBlock &q = p->b[qi];
-        SMH_TRY(use(q));
-        PullArgs args;
-        args.n = 0;
-        uint64_t words = 0;
-        auto flush = [&]() -> int {
-            if (args.n == 0) return SMH_OK;
-            uint64_t blocks = (words / 4 + kBlock - 1) / kBlock;
-            blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-            hipLaunchKernelGGL(k_peer_pull, dim3((unsigned)blocks), dim3(kBlock), 0, xs(q, side), (uint32_t *)v->d[qi], args);
-            SMH_HIP(hipGetLastError());
-            args.n = 0;
-            words = 0;
-            return SMH_OK;
-        };
-        for (size_t si = 0; si < nl; ++si) {
-            if (si == qi) continue;
-            ParBlock &src = p->b[si];
-            size_t a = src.r0, e = src.r1;
-            if (mode == SMH_EXCHANGE_WINDOW)
-                recv_range(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), q.index, src.index, &a, &e);
-            if (a >= e) continue;
-            pulled[qi * nl + si] = 1;
-            SMH_HIP(hipStreamWaitEvent(xs(q, side), src.ev_slice, 0));
-            if (p->peer_ok[qi * nl + si]) {
-                args.src[args.n] = (const uint32_t *)v->d[si];
-                args.w0[args.n] = (uint64_t)a * wpe;
-                args.w1[args.n] = (uint64_t)e * wpe;
-                words += (uint64_t)(e - a) * wpe;
-                if (++args.n == kMaxPull) SMH_TRY(flush());
-            } else {  // no direct access between the two devices: the runtime stages the copy
-                SMH_HIP(hipMemcpyPeerAsync((char *)v->d[qi] + a * vs, q.device, (const char *)v->d[si] + a * vs, src.device, (e - a) * vs, xs(q, side)));
-            }
-        }
-        SMH_TRY(flush());
-        SMH_HIP(hipEventRecord(q.ev_done, xs(q, side)));
-    }
-    // 3. nobody overwrites its slice while a peer may still be reading it
-    for (size_t si = 0; si < nl; ++si) {
-        ParBlock &src = p->b[si];
-        SMH_TRY(use(src));
-        for (size_t qi = 0; qi < nl; ++qi)
-            if (pulled[qi * nl + si]) SMH_HIP(hipStreamWaitEvent(xs(src, side), p->b[qi].ev_done, 0));
-    }
+// The PEER exchange in three per-block steps; between two of them every block's calls of the step before must have been ISSUED
+// (a wait names an event another block records).  pulled: [q * n_local + src] = q read from src (filled by step 2, read by step 3).
+// 1. block k's slice is complete once what its stream holds so far has run
+int peer_mark(smh_par *p, size_t k, bool side) {
+    ParBlock &blk = p->b[k];
+    SMH_TRY(use(blk));
+    SMH_HIP(hipEventRecord(blk.ev_slice, xs(blk, side)));
     return SMH_OK;
+}
+// 2. block qi pulls what it needs from the owners' buffers
+int peer_pull(smh_par *p, smh_par_vec *v, int mode, size_t qi, bool side, uint8_t *pulled) {
+    const size_t vs = dtype_size(p->dtype), nl = p->b.size();
+    const size_t wpe = vs / 4;  // 32-bit words per entry
+    ParBlock &q = p->b[qi];
+    SMH_TRY(use(q));
+    PullArgs args;
+    args.n = 0;
+    uint64_t words = 0;
+    auto flush = [&]() -> int {
+        if (args.n == 0) return SMH_OK;
+        uint64_t blocks = (words / 4 + kBlock - 1) / kBlock;
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        hipLaunchKernelGGL(k_peer_pull, dim3((unsigned)blocks), dim3(kBlock), 0, xs(q, side), (uint32_t *)v->d[qi], args);
+        SMH_HIP(hipGetLastError());
+        args.n = 0;
+        words = 0;
+        return SMH_OK;
+    };
+    for (size_t si = 0; si < nl; ++si) {
+        pulled[qi * nl + si] = 0;
+        if (si == qi) continue;
+        ParBlock &src = p->b[si];
+        size_t a = src.r0, e = src.r1;
+        if (mode == SMH_EXCHANGE_WINDOW)
+            recv_range(part_of(p), p->needs.data(), p->lo.data(), p->hi.data(), q.index, src.index, &a, &e);
+        if (a >= e) continue;
+        pulled[qi * nl + si] = 1;
+        SMH_HIP(hipStreamWaitEvent(xs(q, side), src.ev_slice, 0));
+        if (p->peer_ok[qi * nl + si]) {
+            args.src[args.n] = (const uint32_t *)v->d[si];
+            args.w0[args.n] = (uint64_t)a * wpe;
+            args.w1[args.n] = (uint64_t)e * wpe;
+            words += (uint64_t)(e - a) * wpe;
+            if (++args.n == kMaxPull) SMH_TRY(flush());
+        } else {  // no direct access between the two devices: the runtime stages the copy
+            SMH_HIP(hipMemcpyPeerAsync((char *)v->d[qi] + a * vs, q.device, (const char *)v->d[si] + a * vs, src.device, (e - a) * vs, xs(q, side)));
+        }
+    }
+    SMH_TRY(flush());
+    SMH_HIP(hipEventRecord(q.ev_done, xs(q, side)));
+    return SMH_OK;
+}
+// 3. block si does not overwrite its slice while a peer may still be reading it
+int peer_guard(smh_par *p, size_t si, bool side, const uint8_t *pulled) {
+    const size_t nl = p->b.size();
+    ParBlock &src = p->b[si];
+    SMH_TRY(use(src));
+    for (size_t qi = 0; qi < nl; ++qi)
+        if (pulled[qi * nl + si]) SMH_HIP(hipStreamWaitEvent(xs(src, side), p->b[qi].ev_done, 0));
+    return SMH_OK;
+}
+
+int exchange_peer(smh_par *p, smh_par_vec *v, int mode, bool side) {
+    const size_t nl = p->b.size();
+    std::vector<uint8_t> pulled(nl * nl, 0);
+    SMH_TRY(par_for(p, [&](size_t k) { return peer_mark(p, k, side); }));
+    SMH_TRY(par_for(p, [&](size_t k) { return peer_pull(p, v, mode, k, side, pulled.data()); }));
+    return par_for(p, [&](size_t k) { return peer_guard(p, k, side, pulled.data()); });
 }
 
 int exchange(smh_par *p, smh_par_vec *v, int mode, bool side = false) {
@@ -415,20 +542,24 @@ int exchange(smh_par *p, smh_par_vec *v, int mode, bool side = false) {
 // rows are multiplied first is free of semantics.  A WINDOW exchange moves only what blocks reference of each other; a block's
 // interior rows [in0, in1) neither feed it nor need it.  So the exchange runs on a second stream per block while the interior
 // rows are multiplied: fork() after what the exchange reads is written, join() before what it writes is read.
+int fork_one(ParBlock &blk) {
+    SMH_TRY(use(blk));
+    SMH_HIP(hipEventRecord(blk.ev_fork, blk.s));
+    SMH_HIP(hipStreamWaitEvent(blk.sx, blk.ev_fork, 0));
+    return SMH_OK;
+}
+int join_one(ParBlock &blk) {
+    SMH_TRY(use(blk));
+    SMH_HIP(hipEventRecord(blk.ev_join, blk.sx));
+    SMH_HIP(hipStreamWaitEvent(blk.s, blk.ev_join, 0));
+    return SMH_OK;
+}
 int fork_side(smh_par *p) {
-    for (ParBlock &blk : p->b) {
-        SMH_TRY(use(blk));
-        SMH_HIP(hipEventRecord(blk.ev_fork, blk.s));
-        SMH_HIP(hipStreamWaitEvent(blk.sx, blk.ev_fork, 0));
-    }
+    for (ParBlock &blk : p->b) SMH_TRY(fork_one(blk));
     return SMH_OK;
 }
 int join_side(smh_par *p) {
-    for (ParBlock &blk : p->b) {
-        SMH_TRY(use(blk));
-        SMH_HIP(hipEventRecord(blk.ev_join, blk.sx));
-        SMH_HIP(hipStreamWaitEvent(blk.s, blk.ev_join, 0));
-    }
+    for (ParBlock &blk : p->b) SMH_TRY(join_one(blk));
     return SMH_OK;
 }
 
@@ -502,6 +633,27 @@ void *red_all(const smh_par *p, const ParBlock &blk, int slot) {
 }
 void *red_mine(const smh_par *p, const ParBlock &blk, int slot) { return (char *)red_all(p, blk, slot) + blk.index * dtype_size(p->dtype); }
 
+// PEER backend, the three steps of a fold's meeting (each needs the step before ISSUED by every block it names):
+int red_mark(smh_par *p, size_t k, int slot) {  // block k's value of the slot is written once its stream gets here
+    ParBlock &blk = p->b[k];
+    SMH_TRY(use(blk));
+    SMH_HIP(hipEventRecord(blk.ev_red[slot], blk.s));
+    return SMH_OK;
+}
+int red_hub(smh_par *p, int slot) {  // block 0's stream has seen them all
+    ParBlock &hub = p->b[0];
+    SMH_TRY(use(hub));
+    for (size_t k = 1; k < p->b.size(); ++k) SMH_HIP(hipStreamWaitEvent(hub.s, p->b[k].ev_red[slot], 0));
+    if (p->b.size() > 1) SMH_HIP(hipEventRecord(hub.ev_all[slot], hub.s));
+    return SMH_OK;
+}
+int red_wait(smh_par *p, size_t k, int slot) {  // ... and block k's waits for that
+    if (k == 0) return SMH_OK;
+    SMH_TRY(use(p->b[k]));
+    SMH_HIP(hipStreamWaitEvent(p->b[k].s, p->b[0].ev_all[slot], 0));
+    return SMH_OK;
+}
+
 // after every local block wrote red_mine(slot): make all n_blocks values visible to every block's stream
 int combine(smh_par *p, int slot) {
     if (lone_block_skips(p)) return SMH_OK;
@@ -516,20 +668,10 @@ int combine(smh_par *p, int slot) {
         return SMH_OK;
     }
     // every block's value is written -> every block may read all of them.  Through ONE meeting point (block 0's stream waits for
-    // the others' records, the others wait for its record after that): 2 (n - 1) waits instead of n (n - 1) -- with 8 blocks the
-    // all-to-all form was 112 of the ~320 API calls the one host thread issues per iteration of the solver
-    for (ParBlock &blk : p->b) {
-        SMH_TRY(use(blk));
-        SMH_HIP(hipEventRecord(blk.ev_red[slot], blk.s));
-    }
-    ParBlock &hub = p->b[0];
-    SMH_TRY(use(hub));
-    for (size_t k = 1; k < p->b.size(); ++k) SMH_HIP(hipStreamWaitEvent(hub.s, p->b[k].ev_red[slot], 0));
-    if (p->b.size() > 1) SMH_HIP(hipEventRecord(hub.ev_all[slot], hub.s));
-    for (size_t k = 1; k < p->b.size(); ++k) {
-        SMH_TRY(use(p->b[k]));
-        SMH_HIP(hipStreamWaitEvent(p->b[k].s, hub.ev_all[slot], 0));
-    }
+    // the others' records, the others wait for its record after that): 2 (n - 1) waits instead of n (n - 1)
+    for (size_t k = 0; k < p->b.size(); ++k) SMH_TRY(red_mark(p, k, slot));
+    SMH_TRY(red_hub(p, slot));
+    for (size_t k = 0; k < p->b.size(); ++k) SMH_TRY(red_wait(p, k, slot));
     return SMH_OK;
 }
 
@@ -973,6 +1115,7 @@ int smh_par_create_rank_split(smh_comm *comm, size_t n_rows, smh_crs *block, siz
 
 int smh_par_destroy(smh_par *p) {
     if (!p) return SMH_OK;
+    pool_destroy(p);
     int prev = 0;
     (void)hipGetDevice(&prev);
     for (ParBlock &blk : p->b) {
@@ -1201,16 +1344,26 @@ int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int varia
     int m = SMH_EXCHANGE_NONE;
     SMH_TRY(resolve_mode(p, mode, &m));
     if (!overlapped(p, m)) {
-        for (size_t k = 0; k < p->b.size(); ++k) {
+        SMH_TRY(par_for(p, [&](size_t k) -> int {
             ParBlock &blk = p->b[k];
             SMH_TRY(use(blk));
-            SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s));  // results at b R (:64)
-        }
+            return smh_crs_spmv_dev(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s);  // results at b R (:64)
+        }));
         return exchange(p, y, mode);
     }
-    // the rows other blocks reference first, then the exchange on the side streams while the interior rows are multiplied
-    std::vector<size_t> ia(p->b.size(), 0), ie(p->b.size(), 0);
-    for (size_t k = 0; k < p->b.size(); ++k) {
+    // the rows other blocks reference first, then the exchange on the side streams while the interior rows are multiplied; every
+    // block's calls from its own issuing thread, the phases meeting where a wait names another block's event (see ParPool)
+    const size_t nl = p->b.size();
+    std::vector<size_t> ia(nl, 0), ie(nl, 0);
+    std::vector<uint8_t> pulled(nl * nl, 0);
+    const bool peer = p->backend != SMH_PAR_BACKEND_RCCL;
+    auto interior = [&](size_t k) -> int {
+        ParBlock &blk = p->b[k];
+        if (ie[k] <= ia[k]) return SMH_OK;
+        SMH_TRY(use(blk));
+        return spmv_enqueue_rows(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s, ia[k], ie[k]);
+    };
+    SMH_TRY(par_for(p, [&](size_t k) -> int {
         ParBlock &blk = p->b[k];
         SMH_TRY(use(blk));
         SMH_TRY(interior_for(blk, variant, &ia[k], &ie[k]));
@@ -1221,16 +1374,33 @@ int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int varia
         } else {
             SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, yk, variant, blk.s));
         }
+        SMH_TRY(fork_one(blk));
+        return peer ? peer_mark(p, k, true) : SMH_OK;
+    }));
+    if (!peer) {
+        SMH_TRY(exchange(p, y, mode, true));  // (RCCL: one group for all local blocks, issued here)
+        SMH_TRY(par_for(p, interior));
+        return join_side(p);
     }
-    SMH_TRY(fork_side(p));
-    SMH_TRY(exchange(p, y, mode, true));
-    for (size_t k = 0; k < p->b.size(); ++k) {
-        ParBlock &blk = p->b[k];
-        if (ie[k] <= ia[k]) continue;
-        SMH_TRY(use(blk));
-        SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, (char *)y->d[k] + blk.r0 * vs, variant, blk.s, ia[k], ie[k]));
-    }
-    return join_side(p);
+    if (y->n != p->n_rows) return fail(SMH_ERR_DIM_MISMATCH, "exchange: the vector has %zu entries, the partition owns %zu rows", y->n, p->n_rows);
+    SMH_TRY(par_for(p, [&](size_t k) -> int {
+        SMH_TRY(peer_pull(p, y, m, k, true, pulled.data()));
+        return interior(k);
+    }));
+    return par_for(p, [&](size_t k) -> int {
+        SMH_TRY(peer_guard(p, k, true, pulled.data()));
+        return join_one(p->b[k]);
+    });
+}
+
+int smh_par_set_threads(smh_par *p, int mode) {
+    if (!p) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (mode < -1 || mode > 1) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic), 0 (one issuing thread) or 1 (a thread per local block)");
+    DeviceGuard g;
+    SMH_TRY(sync_all(p));
+    p->use_threads = mode;
+    if (!threads_wanted(p)) pool_destroy(p);
+    return SMH_OK;
 }
 
 int smh_par_set_overlap(smh_par *p, int on) {
@@ -1333,13 +1503,108 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
             SMH_TRY(use(blk));
             SMH_TRY(cg_par_set_rr(dt, blk.d_sc, red_all(p, blk, 1), nb, blk.s));
         }
+        // ---- one iteration (:41-60) as phases: within a phase every block's calls are issued by its own host thread (par_for);
+        // between phases all of them have been issued -- what a wait on another block's event needs.  Streams, events, kernels and
+        // their order per block are those of the one-thread form, whatever the number of threads.
+        const bool peer = p->backend != SMH_PAR_BACKEND_RCCL;
+        const bool lone = lone_block_skips(p);
+        const size_t nl = p->b.size();
+        std::vector<uint8_t> pulled(nl * nl, 0);
+        // the product of block k's rows [part 0: its interior | part 1: the rest, or all of them] and, after part 1, its p.Ap
+        auto products = [&](size_t k, int part, bool side) -> int {
+            ParBlock &blk = p->b[k];
+            SMH_TRY(use(blk));
+            const size_t n_loc = blk.r1 - blk.r0;
+            size_t ia = 0, ie = 0;
+            if (side) SMH_TRY(interior_for(blk, variant, &ia, &ie));
+            const bool split = ie > ia;
+            if (part == 0 && !split) return SMH_OK;
+            // :43 and :45 -- with the CSR-stream kernel p.Ap rides the product's epilogue (one partial per tile, lhs = this
+            // block's slice of p) as in the single-matrix solver: no second pass over p and Ap
+            const size_t n_dot = spmv_fused_dot_partials(blk.m, n, variant, true);
+            const bool fused = n_dot && n_dot <= blk.dotp_cap;
+            void *dotp = fused ? blk.d_dotp : nullptr;
+            const void *lhs = fused ? (const char *)pv->d[k] + blk.r0 * vs : nullptr;
+            if (part == 0) return spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ia, ie, dotp, lhs);
+            if (split) {
+                SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, 0, ia, dotp, lhs));
+                SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ie, n_loc, dotp, lhs));
+            } else if (fused) {
+                SMH_TRY(spmv_enqueue(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, blk.d_dotp, lhs));
+            } else {
+                SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));
+            }
+            if (fused) return launch_fold2(dt, blk.d_dotp, n_dot, blk.d_partials, red_mine(p, blk, 0), blk.s);
+            return launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, n_loc, blk.d_partials, red_mine(p, blk, 0), blk.s);
+        };
+        auto update_xr = [&](size_t k) -> int {  // alpha, then x / r and this block's share of r.r
+            ParBlock &blk = p->b[k];
+            SMH_TRY(use(blk));
+            uint32_t cnt = 0;
+            SMH_TRY(cg_par_alpha(dt, blk.d_sc, red_all(p, blk, 0), nb, blk.s));
+            SMH_TRY(cg_par_update(dt, blk.d_sc, blk.d_r, blk.d_ap, blk.r1 - blk.r0, blk.d_partials, &cnt, blk.s));           // :49-51
+            return cg_fold(dt, blk.d_partials, cnt, red_mine(p, blk, 1), blk.s);
+        };
+        auto update_p = [&](size_t k) -> int {  // beta (and the stop test before it), then p
+            ParBlock &blk = p->b[k];
+            SMH_TRY(use(blk));
+            SMH_TRY(cg_par_beta(dt, blk.d_sc, red_all(p, blk, 1), nb, blk.s));                                          // :52-56
+            return cg_par_p(dt, blk.d_sc, (char *)pv->d[k] + blk.r0 * vs, blk.d_r, (char *)x->d[k] + blk.r0 * vs, blk.r1 - blk.r0, blk.s);  // :47, :58-59
+        };
+        auto iteration = [&]() -> int {
+            // the entries of p a block references and another owns -- beside the product of the interior rows, which need none
+            // of them, when the exchange is a window (the rows that do wait for it at the join)
+            const bool side = overlapped(p, mode);
+            const bool xchg = mode != SMH_EXCHANGE_NONE;
+            if (peer) {
+                if (xchg) SMH_TRY(par_for(p, [&](size_t k) -> int {
+                    if (side) SMH_TRY(fork_one(p->b[k]));
+                    return peer_mark(p, k, side);
+                }));
+                SMH_TRY(par_for(p, [&](size_t k) -> int {
+                    if (xchg) SMH_TRY(peer_pull(p, pv, mode, k, side, pulled.data()));
+                    return side ? products(k, 0, side) : SMH_OK;
+                }));
+                SMH_TRY(par_for(p, [&](size_t k) -> int {
+                    if (xchg) SMH_TRY(peer_guard(p, k, side, pulled.data()));
+                    if (side) SMH_TRY(join_one(p->b[k]));
+                    SMH_TRY(products(k, 1, side));
+                    return lone ? SMH_OK : red_mark(p, k, 0);
+                }));
+                if (!lone) SMH_TRY(red_hub(p, 0));
+                SMH_TRY(par_for(p, [&](size_t k) -> int {
+                    if (!lone) SMH_TRY(red_wait(p, k, 0));
+                    SMH_TRY(update_xr(k));
+                    return lone ? SMH_OK : red_mark(p, k, 1);
+                }));
+                if (!lone) SMH_TRY(red_hub(p, 1));
+                return par_for(p, [&](size_t k) -> int {
+                    if (!lone) SMH_TRY(red_wait(p, k, 1));
+                    return update_p(k);
+                });
+            }
+            // RCCL: the collectives of all local blocks are ONE group issued by the caller (a process per GPU has one block anyway)
+            if (side) SMH_TRY(fork_side(p));
+            SMH_TRY(exchange(p, pv, mode, side));
+            if (side) {
+                SMH_TRY(par_for(p, [&](size_t k) { return products(k, 0, side); }));
+                SMH_TRY(join_side(p));
+            }
+            SMH_TRY(par_for(p, [&](size_t k) { return products(k, 1, side); }));
+            SMH_TRY(combine(p, 0));
+            SMH_TRY(par_for(p, update_xr));
+            SMH_TRY(combine(p, 1));
+            return par_for(p, update_p);
+        };
         size_t launched = 0;
         int converged = 0;
         auto poll = [&]() -> int {
             ParBlock &b0 = p->b[0];
             SMH_TRY(use(b0));
             SMH_HIP(hipMemcpyAsync(p->h_sc, b0.d_sc, cg_scalars_bytes(dt), hipMemcpyDeviceToHost, b0.s));
-            SMH_TRY(sync_all(p));
+            // (block 0's stream alone: its scalars are every block's scalars -- all fold the same values -- and the other blocks'
+            // streams keep their queues full across the poll; everything is drained once, when the solve returns)
+            SMH_HIP(hipStreamSynchronize(b0.s));
             uint64_t it64 = 0;
             cg_read_scalars(dt, p->h_sc, &converged, &it64, &rr);
             iters = (size_t)it64;
@@ -1347,68 +1612,22 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
         };
         while (launched < iter_max) {
             const size_t batch = iter_max - launched < check_every ? iter_max - launched : check_every;
-            for (size_t i = 0; i < batch; ++i) {
-                // the entries of p a block references and another owns -- beside the product of the interior rows, which need none
-                // of them, when the exchange is a window (the rows that do wait for it at the join)
-                const bool side = overlapped(p, mode);
-                if (side) SMH_TRY(fork_side(p));
-                SMH_TRY(exchange(p, pv, mode, side));
-                for (int part = side ? 0 : 1; part < 2; ++part) {  // 0: interior rows (before the join), 1: the rest / everything
-                    if (part == 1 && side) SMH_TRY(join_side(p));
-                    for (size_t k = 0; k < p->b.size(); ++k) {
-                        ParBlock &blk = p->b[k];
-                        SMH_TRY(use(blk));
-                        const size_t n_loc = blk.r1 - blk.r0;
-                        size_t ia = 0, ie = 0;
-                        if (side) SMH_TRY(interior_for(blk, variant, &ia, &ie));
-                        const bool split = ie > ia;
-                        if (part == 0 && !split) continue;
-                        // :43 and :45 -- with the CSR-stream kernel p.Ap rides the product's epilogue (one partial per tile, lhs = this
-                        // block's slice of p) as in the single-matrix solver: no second pass over p and Ap
-                        const size_t n_dot = spmv_fused_dot_partials(blk.m, n, variant, true);
-                        const bool fused = n_dot && n_dot <= blk.dotp_cap;
-                        void *dotp = fused ? blk.d_dotp : nullptr;
-                        const void *lhs = fused ? (const char *)pv->d[k] + blk.r0 * vs : nullptr;
-                        if (part == 0) {
-                            SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ia, ie, dotp, lhs));
-                            continue;
-                        }
-                        if (split) {
-                            SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, 0, ia, dotp, lhs));
-                            SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ie, n_loc, dotp, lhs));
-                        } else if (fused) {
-                            SMH_TRY(spmv_enqueue(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, blk.d_dotp, lhs));
-                        } else {
-                            SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));
-                        }
-                        if (fused) SMH_TRY(launch_fold2(dt, blk.d_dotp, n_dot, blk.d_partials, red_mine(p, blk, 0), blk.s));
-                        else SMH_TRY(launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, n_loc, blk.d_partials, red_mine(p, blk, 0), blk.s));
-                    }
-                }
-                SMH_TRY(combine(p, 0));
-                for (size_t k = 0; k < p->b.size(); ++k) {
-                    ParBlock &blk = p->b[k];
-                    SMH_TRY(use(blk));
-                    uint32_t cnt = 0;
-                    SMH_TRY(cg_par_alpha(dt, blk.d_sc, red_all(p, blk, 0), nb, blk.s));
-                    SMH_TRY(cg_par_update(dt, blk.d_sc, blk.d_r, blk.d_ap, blk.r1 - blk.r0, blk.d_partials, &cnt, blk.s));           // :49-51
-                    SMH_TRY(cg_fold(dt, blk.d_partials, cnt, red_mine(p, blk, 1), blk.s));
-                }
-                SMH_TRY(combine(p, 1));
-                for (size_t k = 0; k < p->b.size(); ++k) {
-                    ParBlock &blk = p->b[k];
-                    SMH_TRY(use(blk));
-                    SMH_TRY(cg_par_beta(dt, blk.d_sc, red_all(p, blk, 1), nb, blk.s));                                          // :52-56
-                    SMH_TRY(cg_par_p(dt, blk.d_sc, (char *)pv->d[k] + blk.r0 * vs, blk.d_r, (char *)x->d[k] + blk.r0 * vs, blk.r1 - blk.r0,
-                                     blk.s));                                                                                   // :47, :58-59
-                }
-            }
+            static const bool trace = getenv("SMH_PAR_TRACE") && atoi(getenv("SMH_PAR_TRACE")) != 0;  // development aid
+            const auto t_a = std::chrono::steady_clock::now();
+            for (size_t i = 0; i < batch; ++i) SMH_TRY(iteration());
+            const auto t_b = std::chrono::steady_clock::now();
             launched += batch;
             SMH_TRY(poll());
+            if (trace) {
+                const auto t_c = std::chrono::steady_clock::now();
+                fprintf(stderr, "[par cg] %zu iterations: issued in %.3f ms (%.3f per iteration), drained %.3f ms later\n", batch,
+                        std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(t_b - t_a).count() / (double)batch,
+                        std::chrono::duration<double, std::milli>(t_c - t_b).count());
+            }
             if (converged) break;
         }
         if (iter_max == 0) SMH_TRY(poll());
-        return SMH_OK;
+        return sync_all(p);
     };
     const int rc = go();
     if (rc != SMH_OK) {

@@ -221,6 +221,11 @@ class SparseMatParLocal:
     def backend(self):
         return {v: k for k, v in _lib.PAR_BACKENDS.items()}[lib().smh_par_backend(self._h)]
 
+    def set_threads(self, mode):
+        """One issuing host thread per local block (``smh_par_set_threads``): -1 automatic (off unless SMH_PAR_THREADS=1), 0 off, 1 on.  Results do not
+        depend on it."""
+        check(lib().smh_par_set_threads(self._h, int(mode)))
+
     def set_overlap(self, on):
         """Window exchanges beside the interior rows' product (``smh_par_set_overlap``; on by default)."""
         check(lib().smh_par_set_overlap(self._h, 1 if on else 0))

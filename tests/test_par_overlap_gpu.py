@@ -87,6 +87,43 @@ def test_cg_iterates_are_bit_identical_with_and_without_the_overlap(gpu, dtype):
         assert res[(True, 400)][0][0] < 400 and np.abs(res[(True, 400)][1] - 1).max() < 1e-3
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_issuing_threads_change_no_bit(gpu, dtype):
+    """One issuing host thread per block (smh_par_set_threads(1)) against ONE thread issuing
+    block after block: the product step and every CG iterate are bit for bit the same -- streams, events, kernels and their order
+    per block do not depend on who issues them -- with the overlap on and off, window and all-gather exchange, 3 and 8 blocks."""
+    g = 40
+    off, col, val = oracle.laplace3d(g, g, g, dtype)
+    n = g * g * g
+    rng = np.random.default_rng(12)
+    x_host = rng.uniform(-1, 1, n).astype(dtype)
+    b_host = oracle.spmv(off, col, val, np.ones(n, dtype))
+    want = oracle.spmv(off, col, val, x_host)
+    for n_blocks in (3, 8):
+        m = sm.SparseMatParLocal.with_sub_matrices(n_blocks, n, n, off, col, val, device_ids=[0] * n_blocks)
+        res = {}
+        for threads in (1, 0):
+            m.set_threads(threads)
+            for overlap in (True, False):
+                m.set_overlap(overlap)
+                for exch in ("window", "allgather"):
+                    x, y, z = m.vec(host=x_host), m.vec(), m.vec()
+                    m.mvp_dev(x, y, variant="stream", exchange=exch)
+                    m.mvp_dev(y, z, variant="stream", exchange=exch)
+                    m.synchronize()
+                    assert y.download().tobytes() == want.tobytes(), (threads, overlap, exch)
+                    res[(threads, overlap, exch)] = z.download().tobytes()
+                for iters in (1, 9, 300):
+                    b, xs = m.vec(host=b_host), m.vec()
+                    res[(threads, overlap, iters)] = (m.cg_solve_vec(b, xs, tol=1e-6 if dtype == np.float32 else 1e-10, iter_max=iters, check_every=4),
+                                                      xs.download().tobytes())
+        for key in [k for k in res if k[0] == 1]:
+            assert res[key] == res[(0,) + key[1:]], (n_blocks, key)
+        assert res[(1, True, 300)][0][0] < 300
+        m.set_threads(-1)
+        m.set_overlap(True)
+
+
 def test_blocks_without_an_interior_still_multiply(gpu):
     """Scattered columns: every row references other blocks -- AUTO's exchange is the all-gather (no overlap), and a forced window
     finds no interior: the call is then simply not split."""
