@@ -34,11 +34,22 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // LDS is dynamic (above the 64 KiB static limit for f64).
 // RING = columns the ring holds: 16384 by default; f32 matrices whose rows do not fit that but fit 32768 take the
 // 128 KiB / 1024-thread configuration too (chosen by the plan builder's caller).
-template <typename T, int RING> struct Ring2Cfg { static constexpr int kThreads = (size_t)RING * sizeof(T) > 65536 ? 1024 : 512; };
+#ifndef SMH_RING2_THREADS64
+#define SMH_RING2_THREADS64 1024
+#endif
+template <typename T, int RING> struct Ring2Cfg {
+    static constexpr bool kBig = (size_t)RING * sizeof(T) > 65536;  // 128 KiB of LDS: one workgroup per CU
+    static constexpr int kThreads = kBig ? (sizeof(T) == 8 ? SMH_RING2_THREADS64 : 1024) : 512;
+    // wavefronts per SIMD the register budget is sized for: the CU's resident workgroups' wavefronts over its 4 SIMDs
+    static constexpr int kWavesPerSimd = (kBig ? 1 : 2) * (kThreads / 64) / 4;
+};
 #ifndef SMH_RING2_SB
 #define SMH_RING2_SB 2
 #endif
 constexpr int kRing2SB = SMH_RING2_SB;
+#ifndef SMH_RING2_SB64
+#define SMH_RING2_SB64 1
+#endif
 // steps per unit: two units x SB x 32 B per lane live in VGPRs
 // Addressing A/B (same box, interleaved runs): 32-bit byte offsets (saddr form, would also need a < 2^30
 // entries-per-phase guard) gave 0.465 vs 0.465 ms on C2 and 2.89 vs 2.76 ms on the 512^3 Laplacian against
@@ -59,30 +70,57 @@ struct Unit {
     T v[NCH][4];
 };
 
-// colp/valp are wave-uniform (SGPR) base pointers of the phase's first chunk, rel a 32-bit element offset
-// from it: hipcc emits the saddr form `global_load_dwordx4 v, v_off, s[base]`, one address VGPR per load
+// WHICH entries of a pass (4 LANES consecutive entry slots of a row, starting on the 4-entry grid) lane j of the row's group takes.
+//   f32: slots 4j .. 4j+3 -- 16 bytes of values per lane, one load instruction covers 16 LANES contiguous bytes per row.
+//   f64: slots 2j, 2j+1 and 2 LANES + 2j, 2 LANES + 2j + 1 -- TWO 16-byte loads per lane, each of which covers 16 LANES contiguous bytes
+//        per row (LANES 8: a whole 128-byte line).  Round 3 gave an f64 lane 32 contiguous bytes: each of its two load instructions
+//        then touched every line of the row but used half of it, and the kernel ran at 4.9 TB/s where the f32 one reaches 6.2; with
+//        whole lines per instruction 0.67-0.70 -> 0.58-0.60 ms on the headline shape (profiles/r04_k1r_f64_line_loads.log).
+template <typename T, int LANES>
+__device__ __forceinline__ uint32_t lane_pos(uint32_t j, int q) {
+    if constexpr (sizeof(T) == 8) return q < 2 ? 2u * j + (uint32_t)q : 2u * LANES + 2u * j + (uint32_t)(q - 2);
+    else return 4u * j + (uint32_t)q;
+}
+
+// colp/valp are wave-uniform (SGPR) base pointers of the phase's first chunk, pass_rel the 32-bit element offset of the pass from
+// it: hipcc emits the saddr form `global_load_dwordx4 v, v_off, s[base]`, one address VGPR per load.  Every address is clamped to the
+// last piece that is safe to read (last_rel: the last whole 4-entry chunk of the arrays): lanes without work re-read a valid piece,
+// which the caller masks.
 // C16: colp points into the 16-bit column array (the low halves of the columns: all a ring phase needs, since the
-// ring slot of a column is `column mod 16384`) -- a chunk of 4 columns is then one 8-byte load instead of 16 bytes
-template <typename T, bool C16>
-__device__ __forceinline__ void load_chunk_nb(const void *__restrict__ colp, const T *__restrict__ valp, uint32_t rel,
-                                              uint32_t (&c)[4], T (&v)[4]) {
-    if constexpr (C16) {  // kept packed: c[0], c[1] hold two columns each (unpacked where they are used, see ring_slot)
-        const u32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(
-            reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 2u)));
-        c[0] = cc.x; c[1] = cc.y;  // (unpacking here instead measured the same: 0.343-0.345 ms either way)
-    } else {
-        const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(
-            reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 4u)));
-        c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
-    }
+// ring slot of a column is `column mod 16384`) -- 4 columns are then 8 bytes (f32: one load; f64: two of 4 bytes)
+template <typename T, bool C16, int LANES>
+__device__ __forceinline__ void load_chunk_nb(const void *__restrict__ colp, const T *__restrict__ valp, uint32_t pass_rel, uint32_t j,
+                                              uint32_t last_rel, uint32_t (&c)[4], T (&v)[4]) {
     if constexpr (sizeof(T) == 4) {
+        uint32_t rel = pass_rel + 4u * j;
+        rel = rel < last_rel ? rel : last_rel;
+        if constexpr (C16) {  // kept packed: c[0], c[1] hold two columns each (unpacked where they are used, see ring_slot)
+            const u32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(
+                reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 2u)));
+            c[0] = cc.x; c[1] = cc.y;  // (unpacking here instead measured the same: 0.343-0.345 ms either way)
+        } else {
+            const u32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(
+                reinterpret_cast<const char *>(colp) + SMH_R2_OFF(rel, 4u)));
+            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+        }
         const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
             reinterpret_cast<const char *>(valp) + SMH_R2_OFF(rel, 4u)));
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
     } else {
-        const char *pv = reinterpret_cast<const char *>(valp) + SMH_R2_OFF(rel, 8u);
-        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(pv));
-        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(pv) + 1);
+        // two pieces of 2 entries (even positions; the last readable one is last_rel + 2)
+        uint32_t e0 = pass_rel + 2u * j, e1 = pass_rel + 2u * LANES + 2u * j;
+        e0 = e0 < last_rel + 2u ? e0 : last_rel + 2u;
+        e1 = e1 < last_rel + 2u ? e1 : last_rel + 2u;
+        if constexpr (C16) {
+            c[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(colp) + SMH_R2_OFF(e0, 2u)));
+            c[1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(colp) + SMH_R2_OFF(e1, 2u)));
+        } else {
+            const u32x2 c0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(colp) + SMH_R2_OFF(e0, 4u)));
+            const u32x2 c1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(colp) + SMH_R2_OFF(e1, 4u)));
+            c[0] = c0.x; c[1] = c0.y; c[2] = c1.x; c[3] = c1.y;
+        }
+        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>(valp) + SMH_R2_OFF(e0, 8u)));
+        const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>(valp) + SMH_R2_OFF(e1, 8u)));
         v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
     }
 }
@@ -138,9 +176,8 @@ __device__ __forceinline__ void issue_unit(Unit<T, SB * CH> &u, const void *__re
         s = s > kb ? s : kb;  // (only rows past the arrays' readable end are below kb: they are empty)
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
-            uint32_t rel = (s & ~3u) - kb + 4u * (ch * LANES + j);
-            rel = rel < last_rel ? rel : last_rel;  // lanes without work re-read a valid chunk (masked later)
-            load_chunk_nb<T, C16>(colp, valp, rel, u.c[t * CH + ch], u.v[t * CH + ch]);
+            // (lanes without work re-read a valid piece: clamped inside, masked when consumed)
+            load_chunk_nb<T, C16, LANES>(colp, valp, (s & ~3u) - kb + 4u * (uint32_t)(ch * LANES), j, last_rel, u.c[t * CH + ch], u.v[t * CH + ch]);
         }
     }
 }
@@ -151,7 +188,7 @@ template <typename T, int LANES, int CH, int SB, int GM, bool C16, int RING, boo
 __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t base, uint64_t row_end,
                                              const void *__restrict__ colp, const T *__restrict__ valp,
                                              const T *__restrict__ x, const T *ring, T *__restrict__ y, uint32_t kb,
-                                             uint32_t nnz_lim, uint32_t lane, T *dacc = nullptr) {
+                                             uint32_t nnz_lim, uint32_t last_rel, uint32_t lane, T *dacc = nullptr) {
     constexpr int RPS = kWave / LANES;
     const uint32_t j = lane % LANES;
     T out = T(0);
@@ -169,9 +206,11 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
         for (int ch = 0; ch < CH; ++ch) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t rel = 4u * (ch * LANES + j) + q;
+                const uint32_t rel = 4u * (uint32_t)(ch * LANES) + lane_pos<T, LANES>(j, q);
                 const bool in = rel >= lo && rel < len;
                 T xv;
+                // (round 4, a build that is wrong on purpose: every lane gathering its OWN slot -- no bank conflicts -- ran exactly as
+                // fast, 0.699 against 0.698 ms on f64 and 0.353 against 0.353 on f32: the random LDS gathers are not what bounds K1r)
                 if constexpr (GM == 1) xv = ring[ring_slot<C16, RING>(u.c[t * CH + ch], q)];
                 else if constexpr (GM == 2) xv = __builtin_nontemporal_load(&x[in ? u.c[t * CH + ch][q] : 0u]);
                 else xv = x[in ? u.c[t * CH + ch][q] : 0u];
@@ -180,13 +219,13 @@ __device__ __forceinline__ void consume_unit(const Unit<T, SB * CH> &u, uint64_t
             }
         }
         // rows longer than one pass of the lane group (rare; not pipelined)
-        for (uint32_t rel = 4u * (CH * LANES + j); rel < len; rel += 4u * LANES) {
+        for (uint32_t pass = 4u * (uint32_t)(CH * LANES); pass + lane_pos<T, LANES>(j, 0) < len; pass += 4u * LANES) {
             uint32_t cc[4];
             T vv[4];
-            load_chunk_nb<T, C16>(colp, valp, sa - kb + rel, cc, vv);
+            load_chunk_nb<T, C16, LANES>(colp, valp, sa - kb + pass, j, last_rel, cc, vv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bool in = rel + q < len;
+                const bool in = pass + lane_pos<T, LANES>(j, q) < len;
                 T xv;
                 if constexpr (GM == 1) xv = ring[ring_slot<C16, RING>(cc, q)];
                 else if constexpr (GM == 2) xv = __builtin_nontemporal_load(&x[in ? cc[q] : 0u]);
@@ -220,7 +259,7 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
                                            T *__restrict__ y, uint64_t rb, uint64_t re, uint32_t nnz_lim,
                                            uint64_t last_chunk, uint32_t wave, uint32_t lane, T *dacc = nullptr) {
     constexpr int STEPS = LANES;
-    constexpr int SBMAX = sizeof(T) == 8 ? 1 : kRing2SB;  // f64 chunks take 12 VGPRs: one step per unit
+    constexpr int SBMAX = sizeof(T) == 8 ? SMH_RING2_SB64 : kRing2SB;  // f64 chunks take 12 VGPRs: one step per unit (two: A/B in round 4)
     constexpr int SB = STEPS < SBMAX ? STEPS : SBMAX;
     constexpr int RU = SB * (kWave / LANES);                 // rows per unit
     constexpr uint64_t STRIDE = (uint64_t)(Ring2Cfg<T, RING>::kThreads / kWave) * RU;  // rows between two units of a wave
@@ -238,22 +277,22 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
     issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
     for (;;) {
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
+            consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, last_rel, lane, dacc);
             break;
         }
         // program order = age order: offsets(+2) older than chunks(+1); both stay in flight under consume
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB, C16>(B, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
+        consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(A, base, re, colp, valp, x, ring, y, kb, nnz_lim, last_rel, lane, dacc);
         A.o0 = N.o0; A.o1 = N.o1;
         base += STRIDE;
         if (base + STRIDE >= re) {
-            consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
+            consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, last_rel, lane, dacc);
             break;
         }
         load_offsets(N, off, base + 2 * STRIDE, re, lane);
         issue_unit<T, LANES, CH, SB, C16>(A, colp, valp, kb, nnz_lim, last_rel, lane);
-        consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, lane, dacc);
+        consume_unit<T, LANES, CH, SB, GM, C16, RING, DOT>(B, base, re, colp, valp, x, ring, y, kb, nnz_lim, last_rel, lane, dacc);
         B.o0 = N.o0; B.o1 = N.o1;
         base += STRIDE;
     }
@@ -263,7 +302,7 @@ __device__ __forceinline__ void phase_rows(const uint32_t *__restrict__ off, con
 // gathers need whole columns and keep reading `col`
 // DOT: y holds lhs (read only) and dot_partials[blockIdx.x] = this block's share of lhs . (A x); nothing else is stored
 template <typename T, int LANES, int CH, bool C16, int RING, bool DOT = false>
-__global__ void __launch_bounds__((Ring2Cfg<T, RING>::kThreads), 4)  // 4 waves per SIMD: 16 waves per CU either way
+__global__ void __launch_bounds__((Ring2Cfg<T, RING>::kThreads), (Ring2Cfg<T, RING>::kWavesPerSimd))
 k_spmv_ring2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col, const uint16_t *__restrict__ col16,
              const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint32_t nnz_lim, uint64_t last_chunk,
              const uint32_t *__restrict__ phase_ptr, const RingPhase *__restrict__ phases, uint32_t bands,
