@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__
                                                      const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ clen,
                                                      const uint32_t *__restrict__ obase, const T3Entry<T> *__restrict__ ps,
                                                      const uint16_t *__restrict__ code_a, uint32_t *__restrict__ prow, uint32_t *__restrict__ preal,
-                                                     uint32_t *__restrict__ gcount, T3Chunk *__restrict__ desc, uint32_t *__restrict__ any_cut) {
+                                                     uint32_t *__restrict__ gcount, uint32_t group, T3Chunk *__restrict__ desc, uint32_t *__restrict__ any_cut) {
     constexpr uint32_t CH = t3_chunk<T>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void k_t3_prow(const uint32_t *__restrict__
         if (head) {
             const uint32_t row = ps[q0 + j].row;
             prow[ob + rank] = row;
-            atomicAdd(gcount + row / kT3RowGroup, 1u);  // products per group of rows: what the row blocks are cut by
+            atomicAdd(gcount + row / group, 1u);  // products per group of rows: what the row blocks are cut by
         }
         done += (uint32_t)__popcll(m);
     }
@@ -764,7 +764,9 @@ static int build_t(::smh_crs *m) {
     for (uint32_t b = 0; b < n_cb; ++b) max_slice_chunks = std::max(max_slice_chunks, cptr[b + 1] - cptr[b]);
     const uint64_t slots = (uint64_t)n_chunks * CH;
     uint32_t *cstart = nullptr, *clen = nullptr, *obase = nullptr, *preal = nullptr, *gcount = nullptr, *prow = nullptr;
-    const size_t n_groups = (m->n_rows + kT3RowGroup - 1) / kT3RowGroup;
+    uint32_t group = kT3RowGroup;
+    if (const char *e = getenv("SMH_TILED_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 1024) group = (uint32_t)v; }  // tuning knob (1: a count per row, round 3's cut)
+    const size_t n_groups = (m->n_rows + group - 1) / group;
     SMH_TRY(tmp.alloc(&cstart, (size_t)n_chunks));
     SMH_TRY(tmp.alloc(&clen, (size_t)n_chunks));
     SMH_TRY(tmp.alloc(&obase, (size_t)n_chunks + 1));
@@ -797,7 +799,7 @@ static int build_t(::smh_crs *m) {
     SMH_TRY(tmp.alloc(&prow, (size_t)n_prod));
     if (n_chunks) {
         hipLaunchKernelGGL(k_t3_prow<T>, dim3(wgrid), dim3(kBlock), 0, s, m->d_t3_cptr, n_cb, n_chunks, d_start, cstart, clen, obase, ps, m->d_t2_code, prow, preal,
-                           gcount, (T3Chunk *)m->d_t3_chunk, any_cut);
+                           gcount, group, (T3Chunk *)m->d_t3_chunk, any_cut);
         SMH_HIP(hipGetLastError());
     stage("prow");
     }
@@ -810,18 +812,50 @@ static int build_t(::smh_crs *m) {
     std::vector<uint32_t> rb_start;
     uint32_t n_rb = 0, R = 1;
     {
-        const uint32_t cap_g = std::max(1u, t3_cap_rows(m->dtype) / kT3RowGroup);
+        const uint32_t cap_g = std::max(1u, t3_cap_rows(m->dtype) / group);
         const uint64_t per_block = (uint64_t)(t3_tile_target(m->dtype) * (double)n_cb);
         std::vector<uint32_t> h_cnt(n_groups);
         if (n_groups) SMH_HIP(hipMemcpyAsync(h_cnt.data(), gcount, h_cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         SMH_HIP(hipStreamSynchronize(s));
-        size_t r = 0;
-        while (r < n_groups) {
-            rb_start.push_back((uint32_t)(r * kT3RowGroup));
-            uint64_t have = 0;
-            size_t e = r;
-            while (e < n_groups && e - r < cap_g && (e == r || have + h_cnt[e] <= per_block)) have += h_cnt[e++];
-            r = e;
+        auto cut = [&](uint64_t target, std::vector<uint32_t> &out) {
+            out.clear();
+            size_t r = 0;
+            while (r < n_groups) {
+                out.push_back((uint32_t)(r * group));
+                uint64_t have = 0;
+                size_t e = r;
+                while (e < n_groups && e - r < cap_g && (e == r || have + h_cnt[e] <= target)) have += h_cnt[e++];
+                r = e;
+            }
+        };
+        cut(per_block, rb_start);
+        // Pass 2 runs one wavefront per row block, W of them per workgroup, as many workgroups at once as the LDS of the CUs holds;
+        // a wavefront's walk over its tiles is bound by latency, so a last round with a handful of row blocks lasts as long as a
+        // full one: BASELINE C3 with 6145 row blocks (two rounds of 3072 and ONE block) ran 1.57 ms where 6122-6144 blocks run
+        // 1.44 (profiles/r04_k2t_row_block_rounds.log).  When the last round would be less than a quarter full and slightly larger
+        // tiles (up to +30 % products) make it unnecessary, the blocks are cut for one round less.
+        {
+            hipDeviceProp_t prop;
+            const uint64_t cus = hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0 ? (uint64_t)prop.multiProcessorCount : 256;
+            const uint64_t stride = (((uint64_t)t3_cap_rows(m->dtype) + 1) * sizeof(T) + 15) & ~(uint64_t)15;
+            const uint64_t slots = cus * std::max<uint64_t>(1, std::min<uint64_t>(16, ((uint64_t)160 << 10) / stride));  // row blocks per round
+            const uint64_t n0 = rb_start.size();
+            const uint64_t q = (n0 + slots - 1) / slots;
+            static const bool rounds_off = getenv("SMH_TILED_ROUNDS") && atoi(getenv("SMH_TILED_ROUNDS")) == 0;  // tuning knob
+            if (!rounds_off && q >= 2 && n0 - (q - 1) * slots < slots / 4) {
+                uint64_t lo = per_block, hi = per_block + per_block * 3 / 10;  // smallest target in (lo, hi] whose cut fits q - 1 rounds
+                const uint64_t goal = (q - 1) * slots - slots / 128;  // (a little air: rounds filled to the last slot ran 2 % slower than 99 % full ones)
+                std::vector<uint32_t> trial;
+                cut(hi, trial);
+                if (trial.size() <= goal) {
+                    while (hi - lo > 1) {
+                        const uint64_t mid = lo + (hi - lo) / 2;
+                        cut(mid, trial);
+                        if (trial.size() <= goal) hi = mid; else lo = mid;
+                    }
+                    cut(hi, rb_start);
+                }
+            }
         }
         if (rb_start.empty()) rb_start.push_back(0);
         rb_start.push_back((uint32_t)m->n_rows);
