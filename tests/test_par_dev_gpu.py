@@ -307,3 +307,66 @@ def test_full_size_c5_eight_blocks_on_one_device(gpu):
         off, col, val = oracle.gen_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, n, k, np.float32, rb, re)
         assert np.array_equal(y_st[rb:re].view(np.uint32), oracle.spmv(off, col, val, x_host).view(np.uint32))
     assert np.abs(y_st.astype(np.float64) - y_host).max() < 5e-5
+
+
+@needs_two
+@pytest.mark.parametrize("backend", ["rccl", "peer"])
+def test_distinct_devices_ragged_split_overlap_and_threads(gpu, backend):
+    nd = min(sm_device_count(), 8)
+    _ragged_split_overlap_and_threads(nd, list(range(nd)), backend)
+
+
+def test_ragged_split_overlap_and_threads_on_one_device(gpu):
+    """The body of the distinct-device test above with its blocks on ONE device (peer backend), so that what a first two-GPU box
+    runs has itself been run."""
+    _ragged_split_overlap_and_threads(3, [0, 0, 0], "peer")
+
+
+def _ragged_split_overlap_and_threads(nd, device_ids, backend):
+    """Everything else section 5 of DESIGN.md describes, so that the first box with two GPUs exercises it in one run: a split table
+    of unequal blocks (nnz-balanced: the all-gather becomes a group of broadcasts), the window exchange beside the interior rows'
+    product (cross-device events on the side streams) against the same step with the overlap off, the issuing thread per block
+    (a device per thread) against one issuing thread, and the solver on top -- all bit for bit the same, the K1s products bit for
+    bit the oracle's."""
+    dtype = np.float64
+    rng = np.random.default_rng(23)
+    n = 90_000
+    lens = np.minimum(1500, ((rng.pareto(1.3, n) + 1) * (1 + 10 * (np.arange(n) / n) ** 3)).astype(np.int64))  # long rows crowd the end
+    off = np.zeros(n + 1, np.uint32)
+    np.cumsum(lens, out=off[1:])
+    col = np.clip(np.repeat(np.arange(n), lens) + rng.integers(-900, 901, int(off[-1])), 0, n - 1).astype(np.uint32)
+    val = rng.uniform(-1, 1, len(col)).astype(dtype)
+    m = sm.SparseMatParLocal.with_sub_matrices(nd, n, n, off, col, val, device_ids=device_ids, split="nnz")
+    cut = m.split()
+    assert max(np.diff(cut)) > 1.2 * min(np.diff(cut))  # ragged by construction
+    m.set_backend(backend)
+    xh = rng.uniform(-1, 1, n).astype(dtype)
+    want = oracle.spmv(off, col, val, xh)
+    want2 = oracle.spmv(off, col, val, want)
+    res = {}
+    for threads in (0, 1):
+        m.set_threads(threads)
+        for overlap in (True, False):
+            m.set_overlap(overlap)
+            for exchange in ("window", "allgather"):
+                x, y, z = m.vec(host=xh), m.vec(), m.vec()
+                m.mvp_dev(x, y, variant="stream", exchange=exchange)
+                m.mvp_dev(y, z, variant="stream", exchange=exchange)
+                m.synchronize()
+                assert y.download().tobytes() == want.tobytes() and z.download().tobytes() == want2.tobytes(), (threads, overlap, exchange)
+    g = 24
+    off, col, val = oracle.laplace3d(g, g, g, dtype)
+    nn = g ** 3
+    mc = sm.SparseMatParLocal.with_sub_matrices(nd, nn, nn, off, col, val, device_ids=device_ids)
+    mc.set_backend(backend)
+    bh = oracle.spmv(off, col, val, np.ones(nn, dtype))
+    for threads in (0, 1):
+        mc.set_threads(threads)
+        for overlap in (True, False):
+            mc.set_overlap(overlap)
+            b, xs = mc.vec(host=bh), mc.vec()
+            res[(threads, overlap)] = (mc.cg_solve_vec(b, xs, tol=1e-10, iter_max=400, check_every=5), xs.download().tobytes())
+    assert len(set(res.values())) == 1, "iterates differ between the schedules"
+    ox, oit, _ = oracle.cg(nn, nn, off, col, val, bh, np.zeros(nn, dtype), tol=1e-10, iter_max=400)
+    (iters, rr), xb = res[(0, True)]
+    assert abs(iters - oit) <= 1 and np.abs(np.frombuffer(xb, dtype) - ox).max() < 1e-9
