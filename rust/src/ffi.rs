@@ -1,4 +1,4 @@
-//! Raw declarations of include/sparsemat_hip.h (ABI version 2) -- the subset the shim uses.
+//! Raw declarations of include/sparsemat_hip.h (ABI version 3) -- the subset the shim uses.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 

@@ -25,6 +25,18 @@ fn check(status: c_int) {
     }
 }
 
+/// The header this shim was written against (include/sparsemat_hip.h: `#define SMH_ABI_VERSION 3`).  Checked once per process
+/// before the first handle is made: a library of another ABI version must not be called through these declarations.
+pub const SMH_ABI_VERSION: c_int = 3;
+
+fn check_abi() {
+    static ONCE: std::sync::Once = std::sync::Once::new();
+    ONCE.call_once(|| {
+        let got = unsafe { ffi::smh_abi_version() };
+        assert_eq!(got, SMH_ABI_VERSION, "libsparsemat_hip.so has ABI version {}, this shim expects {}", got, SMH_ABI_VERSION);
+    });
+}
+
 /// Device-resident copy of a `SparseMatCRS<T, u32>`; the Rust side keeps owning the Vecs.
 pub struct DeviceCrs {
     handle: *mut ffi::smh_crs,
@@ -37,6 +49,7 @@ impl DeviceCrs {
     pub fn new<T: HipValue>(n_rows: usize, n_cols: usize, offset_rows: &[u32], columns: &[u32], values: &[T]) -> Self {
         assert_eq!(offset_rows.len(), n_rows + 1);
         assert_eq!(columns.len(), values.len());
+        check_abi();
         let mut handle = std::ptr::null_mut();
         check(unsafe {
             ffi::smh_crs_create(T::DTYPE, n_rows, n_cols, values.len(), offset_rows.as_ptr(), columns.as_ptr(),
