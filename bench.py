@@ -1054,6 +1054,8 @@ def main():
         result["exchange_check"] = xcheck
     if allgather_leg is not None:
         result["allgather_leg"] = allgather_leg
+    # (decided identically on every rank: rank 0 runs the probe, the others wait for it on the host)
+    probe_wanted = bool(n_gpus > 1 and launched and backend == "rccl" and rdzv_path and os.environ.get("SMH_BENCH_RCCL_PROBE", "0" if share else "1") == "1")
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             if par is None:
@@ -1072,12 +1074,26 @@ def main():
                 result["configs"] = extra_configs(args, lib, check, sm, synth, np, stream, sync)
             except Exception as e:
                 result["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if n_gpus > 1 and backend == "rccl" and os.environ.get("SMH_BENCH_RCCL_PROBE", "0" if share else "1") == "1":
+        if probe_wanted:
             result.setdefault("rccl", {})["probe"] = run_rccl_probe(n_gpus, rows, args.pattern)
+            try:  # (the other ranks wait for this file on the HOST: nobody sits inside a collective while the probe's processes use the GPUs)
+                with open(rdzv_path + ".probe_done", "w") as f:
+                    f.write("done")
+            except OSError:
+                pass
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
+    elif probe_wanted and rdzv_path:
+        deadline = time.time() + 260
+        while time.time() < deadline and not os.path.exists(rdzv_path + ".probe_done"):
+            time.sleep(0.05)
     if comm is not None:
         comm.barrier()
+        if rank == 0 and rdzv_path and probe_wanted:
+            try:
+                os.remove(rdzv_path + ".probe_done")
+            except OSError:
+                pass
         if rank == 0 and rdzv_path:
             try:
                 os.remove(rdzv_path)

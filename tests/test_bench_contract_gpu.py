@@ -81,15 +81,20 @@ def test_n_gpus_rehearsal_checks_its_exchange(gpu):
 
 
 def test_bare_gpus_n_spawns_one_process_per_gpu(gpu):
-    """`bench.py --gpus 3` bare: the default is now three fresh child processes, one per GPU, started before the parent touches the
+    """`bench.py --gpus 2` bare: the default is now fresh child processes, one per GPU, started before the parent touches the
     GPU (ranks meet through smh_comm_*, as under torch.distributed.run) -- here sharing the one device through the test suite's
-    stand-in for RCCL.  The line says how it was launched and what the communicator reports."""
+    stand-in for RCCL.  The line says how it was launched and what the communicator reports; with the probe switched on, rank 0
+    runs the job once more in small as fresh processes (the other ranks wait on the HOST meanwhile) and attaches what it said.
+    (Two ranks: with this pytest process the probe brings the box to five processes on the GPU; the limit is six.)"""
     from util import build_mock_rccl
     mock = build_mock_rccl()
-    d = run_bench(["--gpus", "3", "--rows", "300000", "--steps", "3", "--warmup", "1"], {"LD_PRELOAD": mock, "SMH_BENCH_SHARE_DEVICES": "1"})
-    assert d["n_gpus"] == 3 and d["config"]["exchange_backend"] == "rccl" and "spawned ranks" in d["config"]["launch"]
-    assert d["ranks_seen"] == 3 and d["rccl"]["version"] == 0  # (0: the stand-in's version)
+    d = run_bench(["--gpus", "2", "--rows", "300000", "--steps", "3", "--warmup", "1"],
+                  {"LD_PRELOAD": mock, "SMH_BENCH_SHARE_DEVICES": "1", "SMH_BENCH_RCCL_PROBE": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["exchange_backend"] == "rccl" and "spawned ranks" in d["config"]["launch"]
+    assert d["ranks_seen"] == 2 and d["rccl"]["version"] == 0  # (0: the stand-in's version)
     assert d["exchange_check"]["ok"] is True
+    pr = d["rccl"]["probe"]
+    assert pr.get("n_gpus") == 2 and pr.get("exchange") == "allgather" and pr.get("ranks_seen") == 2, pr
 
 
 def test_one_rank_under_the_launcher(gpu):
