@@ -530,20 +530,26 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     limit = float(os.environ.get("SMH_BENCH_SPAWN_TIMEOUT_S", "1500"))
     deadline = time.time() + limit
-    out0, worst = b"", 0
-    try:
-        out0 = procs[0].communicate(timeout=max(1.0, deadline - time.time()))[0] or b""
-        for pr in procs[1:]:
-            pr.wait(timeout=max(1.0, deadline - time.time()))
-    except subprocess.TimeoutExpired:
-        sys.stderr.write("bench.py: spawned ranks did not finish within %g s -- killing them\n" % limit)
-        worst = WATCHDOG_EXIT
+    worst, first_death = 0, None
+    # all ranks are watched together: a rank that dies leaves its peers inside a collective, so they get a short grace and are
+    # then killed by PID (rank 0's one line fits the pipe's buffer; it is read once everybody has gone)
+    while any(pr.poll() is None for pr in procs):
+        now = time.time()
+        if first_death is None and any(pr.poll() not in (None, 0) for pr in procs):
+            first_death = now
+        if now > deadline or (first_death is not None and now > first_death + 15):
+            sys.stderr.write("bench.py: %s -- killing the remaining ranks\n" % (
+                "spawned ranks did not finish within %g s" % limit if now > deadline else "a rank exited with an error"))
+            worst = WATCHDOG_EXIT
+            break
+        time.sleep(0.1)
     for pr in procs:
         if pr.poll() is None:
             pr.kill()
             pr.wait()
         if pr.returncode:
-            worst = max(worst, abs(pr.returncode))
+            worst = max(worst, abs(pr.returncode) if pr.returncode > 0 else WATCHDOG_EXIT)
+    out0 = procs[0].stdout.read() or b""
     sys.stdout.buffer.write(out0)
     sys.stdout.flush()
     if log:
