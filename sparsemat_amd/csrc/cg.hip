@@ -114,12 +114,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_alpha(CgScalars<T> *sc, const T *
     }
 }
 
+// r -= round(Ap * alpha) on [0, n), partials[blockIdx.x] = this workgroup's share of r.r   (linearsolver.rs:49-51)
 template <typename T, bool VEC>
-__global__ void __launch_bounds__(kBlock)
-k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ r, const T *__restrict__ ap, uint64_t n, T *__restrict__ partials) {
-    __shared__ T s_w[kBlock / kWave];
-    if (!sc->active) return;  // block-uniform
-    const T alpha = sc->alpha;
+__device__ __forceinline__ void cg_update_body(T alpha, T *__restrict__ r, const T *__restrict__ ap, uint64_t n, T *__restrict__ partials, T *s_w) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     T acc = T(0);
@@ -155,6 +152,14 @@ k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ r, const T *__r
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock)
+k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ r, const T *__restrict__ ap, uint64_t n, T *__restrict__ partials) {
+    __shared__ T s_w[kBlock / kWave];
+    if (!sc->active) return;  // block-uniform
+    cg_update_body<T, VEC>(sc->alpha, r, ap, n, partials, s_w);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_cg_beta(CgScalars<T> *sc, const T *__restrict__ partials, uint32_t count) {
     __shared__ T s_w[kBlock / kWave];
@@ -174,12 +179,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_beta(CgScalars<T> *sc, const T *_
     }
 }
 
+// x += round(p * alpha) (:47) and, when `rebuild`, p = round(p * beta) + r (:58-59), on [0, n)
 template <typename T, bool VEC>
-__global__ void __launch_bounds__(kBlock)
-k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restrict__ r, T *__restrict__ x, uint64_t n) {
-    if (!sc->entered) return;
-    const bool rebuild = sc->active != 0;  // (false: this body broke out at the stop test -- x is still due, p stays)
-    const T alpha = sc->alpha, beta = sc->beta;
+__device__ __forceinline__ void cg_p_body(bool rebuild, T alpha, T beta, T *__restrict__ p, const T *__restrict__ r, T *__restrict__ x, uint64_t n) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     if constexpr (VEC) {
@@ -220,6 +222,83 @@ k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restri
             if (rebuild) p[i] = cg_add(cg_mul(p[i], beta), r[i]);
         }
     }
+}
+
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock)
+k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restrict__ r, T *__restrict__ x, uint64_t n) {
+    if (!sc->entered) return;
+    // (rebuild false: this body broke out at the stop test -- x is still due, p stays)
+    cg_p_body<T, VEC>(sc->active != 0, sc->alpha, sc->beta, p, r, x, n);
+}
+
+// ---- the row-partitioned solver's forms (par.hip): the scalar kernels FUSED into the sweeps ------------------------------------
+// k_cg_alpha + k_cg_update in one launch, k_cg_beta + k_cg_p in another: every workgroup folds the blocks' `nb` values itself -- in
+// exactly the order the one-workgroup kernels fold them, so every workgroup of every block gets the same bits -- and takes the same
+// decision; workgroup 0 writes the scalar block.  The scalars are DOUBLE-BUFFERED: a launch reads only `in` and writes only `out`
+// (the host swaps them from launch to launch), so no workgroup can see a half-updated block.  Two launches fewer per block and
+// iteration (of ten).
+template <typename T>
+__device__ __forceinline__ T cg_fold_everywhere(const T *__restrict__ vals, uint32_t count, T *s_w, T *s_one) {
+    T acc = T(0);
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += vals[i];
+    const T r = cg_block_sum<T>(acc, s_w);  // (thread 0 holds it)
+    if (threadIdx.x == 0) *s_one = r;
+    __syncthreads();
+    return *s_one;
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock)
+k_cg_par_update(const CgScalars<T> *__restrict__ in, CgScalars<T> *__restrict__ out, const T *__restrict__ pap_vals, uint32_t nb,
+                T *__restrict__ r, const T *__restrict__ ap, uint64_t n, T *__restrict__ partials) {
+    __shared__ T s_w[kBlock / kWave];
+    __shared__ T s_one;
+    const T pap = cg_fold_everywhere<T>(pap_vals, nb, s_w, &s_one);
+    const bool active = !in->converged && in->iters < in->iter_max;
+    const T alpha = active ? in->rr / pap : in->alpha;  // :45 (no breakdown guard, like the reference)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CgScalars<T> o = *in;
+        o.active = active ? 1u : 0u;
+        o.entered = active ? 1u : 0u;
+        if (active) {
+            o.iters += 1;  // a loop body is entered (for _k in 0..iter_max, :41)
+            o.pap = pap;
+            o.alpha = alpha;
+        }
+        *out = o;
+    }
+    if (!active) return;  // (uniform over the grid: `in` is the same for every workgroup)
+    cg_update_body<T, VEC>(alpha, r, ap, n, partials, s_w);
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock)
+k_cg_par_p(const CgScalars<T> *__restrict__ in, CgScalars<T> *__restrict__ out, const T *__restrict__ rr_vals, uint32_t nb,
+           T *__restrict__ p, const T *__restrict__ r, T *__restrict__ x, uint64_t n) {
+    __shared__ T s_w[kBlock / kWave];
+    __shared__ T s_one;
+    const bool was_active = in->active != 0, entered = in->entered != 0;
+    T rr = T(0), beta = in->beta;
+    bool conv = false;
+    if (was_active) {
+        rr = cg_fold_everywhere<T>(rr_vals, nb, s_w, &s_one);
+        conv = sqrt((double)rr) < in->tol;  // :52-54, BEFORE the beta update
+        if (!conv) beta = rr / in->rr;      // :56
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CgScalars<T> o = *in;
+        if (was_active) {
+            o.rr_prev = in->rr;
+            o.rr = rr;
+            if (conv) { o.converged = 1; o.active = 0; }
+            else o.beta = beta;
+        }
+        *out = o;
+    }
+    if (!entered) return;
+    cg_p_body<T, VEC>(was_active && !conv, in->alpha, beta, p, r, x, n);
 }
 
 // ---- host-side driver pieces (called from capi.hip) ----------------------------------------------
@@ -339,8 +418,6 @@ int cg_fold(int dtype, const void *partials, uint32_t count, void *out, hipStrea
         return SMH_OK;                                                                                             \
     }
 SMH_CG_PAR_SCALAR(cg_par_set_rr, k_cg_set_rr)  // rr = fold(vals)                         linearsolver.rs:40
-SMH_CG_PAR_SCALAR(cg_par_alpha, k_cg_alpha)    // p.Ap = fold(vals); alpha; "active"       :45
-SMH_CG_PAR_SCALAR(cg_par_beta, k_cg_beta)      // r.r = fold(vals); stop test; beta        :51-56
 #undef SMH_CG_PAR_SCALAR
 
 int cg_par_init(int dtype, void *sc, double tol, size_t iter_max, hipStream_t s) {
@@ -350,41 +427,45 @@ int cg_par_init(int dtype, void *sc, double tol, size_t iter_max, hipStream_t s)
     return SMH_OK;
 }
 
-// r -= round(Ap*alpha) on this block's rows; partials[0..*count_out) of r.r   (:49-51)
+// p.Ap = fold(pap_vals[0..nb)); alpha; "active" (:45) -- then r -= round(Ap*alpha) on this block's rows and partials[0..*count_out)
+// of r.r (:49-51).  Scalars: read from sc_in, written to sc_out (see k_cg_par_update).
 template <typename T>
-static int cg_par_update_t(void *sc, T *r, const T *ap, size_t n, T *partials, uint32_t *count_out, hipStream_t s) {
+static int cg_par_update_t(const void *sc_in, void *sc_out, const T *pap_vals, uint32_t nb, T *r, const T *ap, size_t n, T *partials,
+                           uint32_t *count_out, hipStream_t s) {
     unsigned rb = reduce_blocks(n);
     if (rb > 512u) rb = 512u;
     if (cg_aligned16(r) && cg_aligned16(ap))
-        hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, r, ap, (uint64_t)n, partials);
+        hipLaunchKernelGGL((k_cg_par_update<T, true>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc_in, (CgScalars<T> *)sc_out, pap_vals, nb, r, ap, (uint64_t)n, partials);
     else
-        hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, r, ap, (uint64_t)n, partials);
+        hipLaunchKernelGGL((k_cg_par_update<T, false>), dim3(rb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc_in, (CgScalars<T> *)sc_out, pap_vals, nb, r, ap, (uint64_t)n, partials);
     SMH_HIP(hipGetLastError());
     *count_out = rb;
     return SMH_OK;
 }
 
-int cg_par_update(int dtype, void *sc, void *r, const void *ap, size_t n, void *partials, uint32_t *count_out, hipStream_t s) {
-    if (dtype == SMH_F64) return cg_par_update_t<double>(sc, (double *)r, (const double *)ap, n, (double *)partials, count_out, s);
-    return cg_par_update_t<float>(sc, (float *)r, (const float *)ap, n, (float *)partials, count_out, s);
+int cg_par_update(int dtype, const void *sc_in, void *sc_out, const void *pap_vals, uint32_t nb, void *r, const void *ap, size_t n, void *partials,
+                  uint32_t *count_out, hipStream_t s) {
+    if (dtype == SMH_F64) return cg_par_update_t<double>(sc_in, sc_out, (const double *)pap_vals, nb, (double *)r, (const double *)ap, n, (double *)partials, count_out, s);
+    return cg_par_update_t<float>(sc_in, sc_out, (const float *)pap_vals, nb, (float *)r, (const float *)ap, n, (float *)partials, count_out, s);
 }
 
-// x += round(p*alpha) (:47), then p = round(p*beta) + r (:58-59), on this block's rows
+// r.r = fold(rr_vals[0..nb)); stop test; beta (:51-56) -- then x += round(p*alpha) (:47) and p = round(p*beta) + r (:58-59) on this
+// block's rows.  Scalars: read from sc_in, written to sc_out.
 template <typename T>
-static int cg_par_p_t(void *sc, T *p, const T *r, T *x, size_t n, hipStream_t s) {
+static int cg_par_p_t(const void *sc_in, void *sc_out, const T *rr_vals, uint32_t nb, T *p, const T *r, T *x, size_t n, hipStream_t s) {
     uint64_t pb = (n / CgVec<T>::N + kBlock) / kBlock;
     if (pb > 512) pb = 512;
     if (cg_aligned16(p) && cg_aligned16(r) && cg_aligned16(x))
-        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, x, (uint64_t)n);
+        hipLaunchKernelGGL((k_cg_par_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc_in, (CgScalars<T> *)sc_out, rr_vals, nb, p, r, x, (uint64_t)n);
     else
-        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc, p, r, x, (uint64_t)n);
+        hipLaunchKernelGGL((k_cg_par_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc_in, (CgScalars<T> *)sc_out, rr_vals, nb, p, r, x, (uint64_t)n);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
 
-int cg_par_p(int dtype, void *sc, void *p, const void *r, void *x, size_t n, hipStream_t s) {
-    if (dtype == SMH_F64) return cg_par_p_t<double>(sc, (double *)p, (const double *)r, (double *)x, n, s);
-    return cg_par_p_t<float>(sc, (float *)p, (const float *)r, (float *)x, n, s);
+int cg_par_p(int dtype, const void *sc_in, void *sc_out, const void *rr_vals, uint32_t nb, void *p, const void *r, void *x, size_t n, hipStream_t s) {
+    if (dtype == SMH_F64) return cg_par_p_t<double>(sc_in, sc_out, (const double *)rr_vals, nb, (double *)p, (const double *)r, (double *)x, n, s);
+    return cg_par_p_t<float>(sc_in, sc_out, (const float *)rr_vals, nb, (float *)p, (const float *)r, (float *)x, n, s);
 }
 
 }  // namespace smh

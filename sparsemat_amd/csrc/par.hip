@@ -50,10 +50,9 @@ void cg_read_scalars(int dtype, const void *host_copy, int *converged, uint64_t 
 int cg_fold(int dtype, const void *partials, uint32_t count, void *out, hipStream_t s);
 int cg_par_init(int dtype, void *sc, double tol, size_t iter_max, hipStream_t s);
 int cg_par_set_rr(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
-int cg_par_alpha(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
-int cg_par_beta(int dtype, void *sc, const void *vals, uint32_t nb, hipStream_t s);
-int cg_par_update(int dtype, void *sc, void *r, const void *ap, size_t n, void *partials, uint32_t *count_out, hipStream_t s);
-int cg_par_p(int dtype, void *sc, void *p, const void *r, void *x, size_t n, hipStream_t s);
+int cg_par_update(int dtype, const void *sc_in, void *sc_out, const void *pap_vals, uint32_t nb, void *r, const void *ap, size_t n, void *partials,
+                  uint32_t *count_out, hipStream_t s);
+int cg_par_p(int dtype, const void *sc_in, void *sc_out, const void *rr_vals, uint32_t nb, void *p, const void *r, void *x, size_t n, hipStream_t s);
 }  // namespace smh
 
 #define SMH_NCCL(call)                                                                                    \
@@ -93,6 +92,7 @@ struct ParBlock {
     void *d_x = nullptr, *d_y = nullptr;
     // CG state (first solve)
     void *d_r = nullptr, *d_ap = nullptr, *d_partials = nullptr, *d_sc = nullptr;
+    void *d_sc2 = nullptr;  // the scalars are double-buffered: the alpha / update launch reads d_sc and writes d_sc2, the beta / p launch back (cg.hip)
     void *d_dotp = nullptr;  // the SpMV's p.Ap partials (one per 256-row tile), folded by launch_fold2 through d_partials
     size_t dotp_cap = 0;
     void *d_redv = nullptr;       // RCCL backend: 2 x n_blocks values (fold slots)
@@ -689,6 +689,7 @@ int ensure_cg_state(smh_par *p) {
         SMH_HIP(hipMalloc(&blk.d_redv, 2 * p->n_blocks * vs));
         SMH_HIP(hipMemset(blk.d_redv, 0, 2 * p->n_blocks * vs));
         SMH_HIP(hipMalloc(&blk.d_sc, cg_scalars_bytes(p->dtype)));
+        SMH_HIP(hipMalloc(&blk.d_sc2, cg_scalars_bytes(p->dtype)));
     }
     if (!p->h_red) {
         SMH_HIP(hipHostMalloc(&p->h_red, 2 * p->n_blocks * sizeof(double), hipHostMallocPortable | hipHostMallocMapped));
@@ -1138,7 +1139,7 @@ int smh_par_destroy(smh_par *p) {
         if (blk.ev_all[1]) (void)hipEventDestroy(blk.ev_all[1]);
         if (blk.owns_m) (void)smh_crs_destroy(blk.m);
         (void)hipFree(blk.d_x); (void)hipFree(blk.d_y); (void)hipFree(blk.d_r); (void)hipFree(blk.d_ap);
-        (void)hipFree(blk.d_partials); (void)hipFree(blk.d_dotp); (void)hipFree(blk.d_sc); (void)hipFree(blk.d_redv);
+        (void)hipFree(blk.d_partials); (void)hipFree(blk.d_dotp); (void)hipFree(blk.d_sc); (void)hipFree(blk.d_sc2); (void)hipFree(blk.d_redv);
     }
     if (p->h_red) (void)hipHostFree(p->h_red);
     if (p->h_sc) (void)hipHostFree(p->h_sc);
@@ -1541,15 +1542,14 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
             ParBlock &blk = p->b[k];
             SMH_TRY(use(blk));
             uint32_t cnt = 0;
-            SMH_TRY(cg_par_alpha(dt, blk.d_sc, red_all(p, blk, 0), nb, blk.s));
-            SMH_TRY(cg_par_update(dt, blk.d_sc, blk.d_r, blk.d_ap, blk.r1 - blk.r0, blk.d_partials, &cnt, blk.s));           // :49-51
+            SMH_TRY(cg_par_update(dt, blk.d_sc, blk.d_sc2, red_all(p, blk, 0), nb, blk.d_r, blk.d_ap, blk.r1 - blk.r0, blk.d_partials, &cnt, blk.s));  // :45, :49-51
             return cg_fold(dt, blk.d_partials, cnt, red_mine(p, blk, 1), blk.s);
         };
         auto update_p = [&](size_t k) -> int {  // beta (and the stop test before it), then p
             ParBlock &blk = p->b[k];
             SMH_TRY(use(blk));
-            SMH_TRY(cg_par_beta(dt, blk.d_sc, red_all(p, blk, 1), nb, blk.s));                                          // :52-56
-            return cg_par_p(dt, blk.d_sc, (char *)pv->d[k] + blk.r0 * vs, blk.d_r, (char *)x->d[k] + blk.r0 * vs, blk.r1 - blk.r0, blk.s);  // :47, :58-59
+            return cg_par_p(dt, blk.d_sc2, blk.d_sc, red_all(p, blk, 1), nb, (char *)pv->d[k] + blk.r0 * vs, blk.d_r, (char *)x->d[k] + blk.r0 * vs,
+                            blk.r1 - blk.r0, blk.s);  // :52-56, :47, :58-59
         };
         auto iteration = [&]() -> int {
             // the entries of p a block references and another owns -- beside the product of the interior rows, which need none
