@@ -484,7 +484,7 @@ def extra_configs(args, lib, check, sm, synth, np, stream, sync):
     bc = len(cv) * 8 + (nc + 1) * 4 + 2 * nc * 4 + 9 * nc * 4
     out["C4_cg"] = {
         "workload": "ConjugateGradient::solve, 7-point Laplacian %d^3 f32, b = A.1, x0 = 0, device-resident, %d iterations per solve (BASELINE configs[3])" % (g, iters),
-        "dtype": "f32", "kernel": "hipGraph per iteration: %s SpMV with the p.Ap fold in its epilogue + k_cg_update_xr (x, r, r.r) + k_cg_update_p" % variant4,
+        "dtype": "f32", "kernel": "hipGraph per iteration: %s SpMV with the p.Ap partials in its epilogue + k_sum_stage1 + k_cg_par_update (alpha; r, r.r) + k_cg_par_p (beta, stop test; x, p)" % variant4,
         "ms_per_iteration": it_ms, "ms_per_iteration_min": per_it[0], "ms_per_iteration_max": per_it[-1], "solves": len(per_it), "iterations_per_solve": cg.iterations,
         "timing": "host wall clock around smh_cg_solve_vec (device-synchronised on both sides) / iterations, median of 3 solves; per-kernel times: profiles/r04_cg_kernel_stats.csv",
         "algorithmic_bytes": b_cg, "algorithmic_bytes_reference_op_sequence": b4 + 12 * n4 * 4,

@@ -58,7 +58,7 @@ int current_device() {
 // defined in the kernel files
 size_t cg_scalars_bytes(int dtype);
 int cg_begin(int dtype, void *sc, const void *r, size_t n, void *partials, double tol, size_t iter_max, hipStream_t s);
-int cg_iter_tail(int dtype, void *sc, void *x, void *r, void *p, const void *ap, size_t n, void *partials,
+int cg_iter_tail(int dtype, void *sc, void *sc2, void *x, void *r, void *p, const void *ap, size_t n, void *partials,
                  const void *dot_partials, uint32_t dot_count, hipStream_t s);
 void cg_read_scalars(int dtype, const void *host_copy, int *converged, uint64_t *iters, double *rr);
 int synth_x(int dtype, uint64_t seed, size_t begin, size_t n, void *x, hipStream_t s);
@@ -1901,7 +1901,7 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
     const size_t n = m->n_rows;
     const size_t vs = dtype_size(m->dtype);
     hipStream_t s = m->stream;
-    void *r = nullptr, *p = nullptr, *ap = nullptr, *partials = nullptr, *dot_partials = nullptr, *sc = nullptr, *h_sc = nullptr;
+    void *r = nullptr, *p = nullptr, *ap = nullptr, *partials = nullptr, *dot_partials = nullptr, *sc = nullptr, *sc2 = nullptr, *h_sc = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int rc = SMH_OK;
@@ -1912,11 +1912,12 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
         SMH_HIP(hipMalloc(&r, vb));
         SMH_HIP(hipMalloc(&p, vb));
         SMH_HIP(hipMalloc(&ap, vb));
-        SMH_HIP(hipMalloc(&partials, (kReducePartials + 8) * vs));
+        SMH_HIP(hipMalloc(&partials, (2 * kReducePartials + 16) * vs));  // (r.r partials | the dot's result | a first fold of many p.Ap partials)
         // p.Ap: left in the SpMV epilogue when the kernel can (K1s), else a separate two-stage dot
         const size_t n_dot = spmv_fused_dot_partials(m, n, variant);
         if (n_dot) SMH_HIP(hipMalloc(&dot_partials, n_dot * vs));
         SMH_HIP(hipMalloc(&sc, cg_scalars_bytes(m->dtype)));
+        SMH_HIP(hipMalloc(&sc2, cg_scalars_bytes(m->dtype)));  // (the scalars are double-buffered within an iteration: cg.hip)
         SMH_HIP(hipHostMalloc(&h_sc, cg_scalars_bytes(m->dtype)));
         // r = b - A x  (:38) ; p = r.clone() (:39) ; rr = r.r (:40)
         SMH_TRY(spmv_enqueue(m, x->d, x->n, r, variant, s));
@@ -1925,7 +1926,7 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
         SMH_TRY(cg_begin(m->dtype, sc, r, n, partials, tol, iter_max, s));
         size_t launched = 0;
         int converged = 0;
-        // A batch of `check_every` iterations (7 kernels each) is captured ONCE into a hipGraph and replayed:
+        // A batch of `check_every` iterations (the product + 2 to 3 launches each) is captured ONCE into a hipGraph and replayed:
         // for small systems the loop is launch-bound.  Iterations past convergence / iter_max are no-ops on the
         // device, so whole batches can always be replayed.  (All workspaces were created by the SpMV above.)
         if (iter_max > check_every && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -1933,7 +1934,7 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
             for (size_t i = 0; i < check_every && crc == SMH_OK; ++i) {
                 crc = spmv_enqueue(m, p, n, ap, variant, s, dot_partials);
                 if (crc == SMH_OK)
-                    crc = cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, dot_partials, (uint32_t)n_dot, s);
+                    crc = cg_iter_tail(m->dtype, sc, sc2, x->d, r, p, ap, n, partials, dot_partials, (uint32_t)n_dot, s);
             }
             hipError_t ce = hipStreamEndCapture(s, &graph);
             if (crc != SMH_OK || ce != hipSuccess || !graph ||
@@ -1952,7 +1953,7 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
             } else {
                 for (size_t i = 0; i < batch; ++i) {
                     SMH_TRY(spmv_enqueue(m, p, n, ap, variant, s, dot_partials));                        // :43
-                    SMH_TRY(cg_iter_tail(m->dtype, sc, x->d, r, p, ap, n, partials, dot_partials, (uint32_t)n_dot, s));  // :45-59
+                    SMH_TRY(cg_iter_tail(m->dtype, sc, sc2, x->d, r, p, ap, n, partials, dot_partials, (uint32_t)n_dot, s));  // :45-59
                 }
             }
             launched += batch;
@@ -1977,7 +1978,7 @@ int smh_cg_solve_vec(smh_crs *m, const smh_vec *b, smh_vec *x, double tol, size_
     (void)hipStreamSynchronize(s);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
-    (void)hipFree(r); (void)hipFree(p); (void)hipFree(ap); (void)hipFree(partials); (void)hipFree(dot_partials); (void)hipFree(sc);
+    (void)hipFree(r); (void)hipFree(p); (void)hipFree(ap); (void)hipFree(partials); (void)hipFree(dot_partials); (void)hipFree(sc); (void)hipFree(sc2);
     if (h_sc) (void)hipHostFree(h_sc);
     (void)hipGetLastError();
     strncpy(g_err, keep, sizeof g_err);

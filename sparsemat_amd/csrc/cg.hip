@@ -3,12 +3,14 @@
 // Restates ConjugateGradient::solve (reference linearsolver.rs:27-61) as a stream of kernels whose
 // scalars (r.r, p.Ap, alpha, beta, the stop flag, the iteration count) never leave HBM:
 //
-//   per iteration   SpMV  Ap = A p                      (K1 / K2, launched by the caller)   :43
-//                   k_dot_stage1(p, Ap) -> partials                                          :45
-//                   k_cg_alpha   : fold partials, alpha = rr / pAp, decide "active"          :45
-//                   k_cg_update  : r -= round(Ap*alpha); partials r.r                        :49-51
-//                   k_cg_beta    : fold, rr_prev/rr, stop if sqrt(f64(rr)) < tol, else beta  :50-56
-//                   k_cg_p       : x += round(p*alpha) (:47), then p = round(p*beta) + r     :58-59
+//   per iteration   SpMV  Ap = A p  (+ per-tile partials of p.Ap where the kernel can) (launched by the caller)  :43
+//                   [k_sum_stage1 when more than 1024 partials came back / a two-stage dot when none did]       :45
+//                   k_cg_par_update : fold the partials, alpha = rr / pAp, decide "active" -- every workgroup for
+//                                     itself, workgroup 0 writes the scalars --; r -= round(Ap*alpha); partials r.r :45, :49-51
+//                   k_cg_par_p      : fold, rr_prev/rr, stop if sqrt(f64(rr)) < tol, else beta (likewise);
+//                                     x += round(p*alpha) (:47), then p = round(p*beta) + r                      :50-59
+//   (until round 4 alpha and beta were one-workgroup kernels of their own, k_cg_alpha / k_cg_beta: two more launches per
+//   iteration; the fused kernels fold in the same order, so every result kept its bits)
 //
 // `*x += p * alpha` (:47) is carried out by the sweep that rebuilds p: it reads the old p anyway, so x costs one read and
 // one write there instead of p AND x in the update sweep -- 8 n instead of 9 n values of vector traffic per iteration,
@@ -30,7 +32,7 @@ struct CgScalars {
     T rr, rr_prev, pap, alpha, beta;
     uint32_t converged;
     uint32_t active;
-    uint32_t entered;  // the current loop body was entered: its x update is due (set by k_cg_alpha)
+    uint32_t entered;  // the current loop body was entered: its x update is due (set with alpha)
     uint32_t pad_;
     uint64_t iters;
     uint64_t iter_max;
@@ -96,24 +98,6 @@ __global__ void __launch_bounds__(kBlock) k_cg_set_rr(CgScalars<T> *sc, const T 
     if (threadIdx.x == 0) sc->rr = r;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(kBlock) k_cg_alpha(CgScalars<T> *sc, const T *__restrict__ partials, uint32_t count) {
-    __shared__ T s_w[kBlock / kWave];
-    T acc = T(0);
-    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
-    const T pap = cg_block_sum<T>(acc, s_w);
-    if (threadIdx.x == 0) {
-        const bool active = !sc->converged && sc->iters < sc->iter_max;
-        sc->active = active ? 1u : 0u;
-        sc->entered = active ? 1u : 0u;
-        if (active) {
-            sc->iters += 1;  // a loop body is entered (for _k in 0..iter_max, :41)
-            sc->pap = pap;
-            sc->alpha = sc->rr / pap;  // :45 (no breakdown guard, like the reference)
-        }
-    }
-}
-
 // r -= round(Ap * alpha) on [0, n), partials[blockIdx.x] = this workgroup's share of r.r   (linearsolver.rs:49-51)
 template <typename T, bool VEC>
 __device__ __forceinline__ void cg_update_body(T alpha, T *__restrict__ r, const T *__restrict__ ap, uint64_t n, T *__restrict__ partials, T *s_w) {
@@ -150,33 +134,6 @@ __device__ __forceinline__ void cg_update_body(T alpha, T *__restrict__ r, const
     }
     const T s = cg_block_sum<T>(acc, s_w);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
-}
-
-template <typename T, bool VEC>
-__global__ void __launch_bounds__(kBlock)
-k_cg_update(const CgScalars<T> *__restrict__ sc, T *__restrict__ r, const T *__restrict__ ap, uint64_t n, T *__restrict__ partials) {
-    __shared__ T s_w[kBlock / kWave];
-    if (!sc->active) return;  // block-uniform
-    cg_update_body<T, VEC>(sc->alpha, r, ap, n, partials, s_w);
-}
-
-template <typename T>
-__global__ void __launch_bounds__(kBlock) k_cg_beta(CgScalars<T> *sc, const T *__restrict__ partials, uint32_t count) {
-    __shared__ T s_w[kBlock / kWave];
-    if (!sc->active) return;
-    T acc = T(0);
-    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
-    const T rr = cg_block_sum<T>(acc, s_w);
-    if (threadIdx.x == 0) {
-        sc->rr_prev = sc->rr;
-        sc->rr = rr;
-        if (sqrt((double)rr) < sc->tol) {  // :52-54, BEFORE the beta update
-            sc->converged = 1;
-            sc->active = 0;
-        } else {
-            sc->beta = rr / sc->rr_prev;  // :56
-        }
-    }
 }
 
 // x += round(p * alpha) (:47) and, when `rebuild`, p = round(p * beta) + r (:58-59), on [0, n)
@@ -225,18 +182,11 @@ __device__ __forceinline__ void cg_p_body(bool rebuild, T alpha, T beta, T *__re
 }
 
 
-template <typename T, bool VEC>
-__global__ void __launch_bounds__(kBlock)
-k_cg_p(const CgScalars<T> *__restrict__ sc, T *__restrict__ p, const T *__restrict__ r, T *__restrict__ x, uint64_t n) {
-    if (!sc->entered) return;
-    // (rebuild false: this body broke out at the stop test -- x is still due, p stays)
-    cg_p_body<T, VEC>(sc->active != 0, sc->alpha, sc->beta, p, r, x, n);
-}
-
-// ---- the row-partitioned solver's forms (par.hip): the scalar kernels FUSED into the sweeps ------------------------------------
-// k_cg_alpha + k_cg_update in one launch, k_cg_beta + k_cg_p in another: every workgroup folds the blocks' `nb` values itself -- in
-// exactly the order the one-workgroup kernels fold them, so every workgroup of every block gets the same bits -- and takes the same
-// decision; workgroup 0 writes the scalar block.  The scalars are DOUBLE-BUFFERED: a launch reads only `in` and writes only `out`
+// ---- the two launches of an iteration's tail (single matrix: cg_iter_tail; row-partitioned: par.hip) ----------------------------
+// alpha + the x / r update in one launch, beta with the stop test + the p sweep in the other: every workgroup folds the `nb` partial
+// sums itself (the product's per-tile p.Ap partials or their first fold; the update's r.r partials; across row blocks: the blocks'
+// values) -- in exactly the order the one-workgroup kernels of rounds 1-3 folded them, so every workgroup (of every block) gets the
+// same bits -- and takes the same decision; workgroup 0 writes the scalar block.  The scalars are DOUBLE-BUFFERED: a launch reads only `in` and writes only `out`
 // (the host swaps them from launch to launch), so no workgroup can see a half-updated block.  Two launches fewer per block and
 // iteration (of ten).
 template <typename T>
@@ -326,53 +276,62 @@ int cg_begin(int dtype, void *sc, const void *r, size_t n, void *partials, doubl
 
 // everything of one iteration AFTER the SpMV Ap = A p
 template <typename T>
-static int cg_iter_tail_t(void *scv, T *x, T *r, T *p, const T *ap, size_t n, T *partials, const T *dot_partials,
+static int cg_iter_tail_t(void *scv, void *sc2v, T *x, T *r, T *p, const T *ap, size_t n, T *partials, const T *dot_partials,
                           uint32_t dot_count, hipStream_t s) {
-    CgScalars<T> *sc = (CgScalars<T> *)scv;
+    const CgScalars<T> *sc = (const CgScalars<T> *)scv;
+    CgScalars<T> *sc2 = (CgScalars<T> *)sc2v;
     // 2 blocks per CU for the two vector sweeps of the tail: 2.51-2.57 ms per C4 iteration against 2.66-2.69 with 1024 / 2048
     // blocks in the same call (profiles/r01_cg_grid_sweep.log)
     static const unsigned grid_cap = getenv("SMH_CG_BLOCKS") ? (unsigned)atoi(getenv("SMH_CG_BLOCKS")) : 512u;  // tuning knob
     unsigned rb = reduce_blocks(n);
     if (rb > grid_cap) rb = grid_cap;
     const bool vec = cg_aligned16(x) && cg_aligned16(r) && cg_aligned16(p) && cg_aligned16(ap);
+    // Round 4: the two one-workgroup scalar kernels (alpha; beta with the stop test) ride the sweeps that follow them -- every workgroup
+    // folds the partial sums itself, in the order the one-workgroup kernels did (same bits), the scalars double-buffered (sc -> sc2 -> sc)
+    // -- so an iteration is the product + 2 launches (+ one fold when the product left more than 1024 partials) instead of + 4: what a
+    // launch-bound solve (BASELINE C1: 28 us per iteration) is made of.
     // p . Ap: either the SpMV epilogue already left per-tile partials (fused), or a separate two-stage dot
+    const T *pap_vals;
+    uint32_t pap_count;
     if (dot_partials && dot_count > (uint32_t)kReducePartials) {
-        // many tiles: fold them with a full grid first (a single block folding 5e5 values costs ~0.6 ms)
+        // many tiles: fold them with a full grid first (a single block folding 5e5 values costs ~0.6 ms); into the buffer's second half:
+        // the update's workgroups read these while others already write their r.r partials into the first
         const unsigned fb = reduce_blocks(dot_count);
-        hipLaunchKernelGGL(k_sum_stage1<T>, dim3(fb), dim3(kBlock), 0, s, dot_partials, (uint64_t)dot_count, partials);
+        T *stage1 = partials + kReducePartials + 8;
+        hipLaunchKernelGGL(k_sum_stage1<T>, dim3(fb), dim3(kBlock), 0, s, dot_partials, (uint64_t)dot_count, stage1);
         SMH_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, partials, fb);
+        pap_vals = stage1;
+        pap_count = fb;
     } else if (dot_partials) {
-        hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, dot_partials, dot_count);
+        pap_vals = dot_partials;
+        pap_count = dot_count;
     } else {
         SMH_TRY(launch_dot(sizeof(T) == 8 ? SMH_F64 : SMH_F32, p, ap, n, partials, partials + kReducePartials, s));
-        hipLaunchKernelGGL(k_cg_alpha<T>, dim3(1), dim3(kBlock), 0, s, sc, partials + kReducePartials, 1u);
+        pap_vals = partials + kReducePartials;
+        pap_count = 1u;
     }
-    SMH_HIP(hipGetLastError());
     if (vec)
-        hipLaunchKernelGGL((k_cg_update<T, true>), dim3(rb), dim3(kBlock), 0, s, sc, r, ap, (uint64_t)n, partials);
+        hipLaunchKernelGGL((k_cg_par_update<T, true>), dim3(rb), dim3(kBlock), 0, s, sc, sc2, pap_vals, pap_count, r, ap, (uint64_t)n, partials);
     else
-        hipLaunchKernelGGL((k_cg_update<T, false>), dim3(rb), dim3(kBlock), 0, s, sc, r, ap, (uint64_t)n, partials);
-    SMH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_cg_beta<T>, dim3(1), dim3(kBlock), 0, s, sc, partials, rb);
+        hipLaunchKernelGGL((k_cg_par_update<T, false>), dim3(rb), dim3(kBlock), 0, s, sc, sc2, pap_vals, pap_count, r, ap, (uint64_t)n, partials);
     SMH_HIP(hipGetLastError());
     uint64_t pb = (n / CgVec<T>::N + kBlock) / kBlock;
     static const uint64_t p_cap = getenv("SMH_CG_P_BLOCKS") ? (uint64_t)atoll(getenv("SMH_CG_P_BLOCKS")) : 512;  // tuning knob
     if (pb > p_cap) pb = p_cap;
     if (vec)
-        hipLaunchKernelGGL((k_cg_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, x, (uint64_t)n);
+        hipLaunchKernelGGL((k_cg_par_p<T, true>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc2, (CgScalars<T> *)scv, (const T *)partials, rb, p, r, x, (uint64_t)n);
     else
-        hipLaunchKernelGGL((k_cg_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, sc, p, r, x, (uint64_t)n);
+        hipLaunchKernelGGL((k_cg_par_p<T, false>), dim3((unsigned)pb), dim3(kBlock), 0, s, (const CgScalars<T> *)sc2, (CgScalars<T> *)scv, (const T *)partials, rb, p, r, x, (uint64_t)n);
     SMH_HIP(hipGetLastError());
     return SMH_OK;
 }
 
-int cg_iter_tail(int dtype, void *sc, void *x, void *r, void *p, const void *ap, size_t n, void *partials,
+int cg_iter_tail(int dtype, void *sc, void *sc2, void *x, void *r, void *p, const void *ap, size_t n, void *partials,
                  const void *dot_partials, uint32_t dot_count, hipStream_t s) {
     if (dtype == SMH_F64)
-        return cg_iter_tail_t<double>(sc, (double *)x, (double *)r, (double *)p, (const double *)ap, n, (double *)partials,
+        return cg_iter_tail_t<double>(sc, sc2, (double *)x, (double *)r, (double *)p, (const double *)ap, n, (double *)partials,
                                       (const double *)dot_partials, dot_count, s);
-    return cg_iter_tail_t<float>(sc, (float *)x, (float *)r, (float *)p, (const float *)ap, n, (float *)partials,
+    return cg_iter_tail_t<float>(sc, sc2, (float *)x, (float *)r, (float *)p, (const float *)ap, n, (float *)partials,
                                  (const float *)dot_partials, dot_count, s);
 }
 
