@@ -80,24 +80,44 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
     const uint32_t n2 = e2 > cb2 ? (e2 - al2 + 3u) >> 2 : 0u, n3 = e3 > cb3 ? (e3 - al3 + 3u) >> 2 : 0u;
     const uint32_t p1 = n0, p2 = p1 + n1, p3 = p2 + n2, xs_tot = p3 + n3;  // (<= XS * kBlock chunks, inside x: checked by the host)
     const uint32_t d0 = al0 >> 2, d1 = (al1 >> 2) - p1, d2 = (al2 >> 2) - p2, d3 = (al3 >> 2) - p3;  // (mod 2^32; j + d_q is a chunk of x)
+    // f64: a thread's 32 bytes (of x, of the values, of the products) are TWO 16-byte pieces, and a wavefront's lanes take piece
+    // l and piece 64 + l of its 128 -- each load / store instruction then covers 1 KiB of contiguous bytes.  With 32 contiguous
+    // bytes per lane (rounds 2-3) each of the two instructions touched every line and used half of it: what kept K1r's f64 kernel
+    // at 0.8 of its f32 rate did the same here.  Which thread moves which piece changes no arithmetic: the
+    // products land in the same stage slots and are added in storage order as before (bit-exact).
+    const uint32_t wbase = tid & ~(uint32_t)(kWave - 1);  // first thread of this wavefront
     T xr[XS][4];
+    uint32_t xpiece[XS][2];  // f64: the two 16-byte pieces (2 entries each) of the stage this thread fills
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
-        const uint32_t j = tid + (uint32_t)u * kBlock;
         xr[u][0] = xr[u][1] = xr[u][2] = xr[u][3] = T(0);
-        if (j < xs_tot) {
-            // chunk j of the stage = chunk j + d_q of x, q = the interval j falls into (tile-uniform offsets: three selects)
-            uint32_t d = d0;
-            d = j >= p1 ? d1 : d;
-            d = j >= p2 ? d2 : d;
-            d = j >= p3 ? d3 : d;
-            const T *g = x + 4ull * (uint64_t)(j + d);
-            if constexpr (sizeof(T) == 4) {
+        if constexpr (sizeof(T) == 4) {
+            const uint32_t j = tid + (uint32_t)u * kBlock;
+            xpiece[u][0] = xpiece[u][1] = 0;
+            if (j < xs_tot) {
+                // chunk j of the stage = chunk j + d_q of x, q = the interval j falls into (tile-uniform offsets: three selects)
+                uint32_t d = d0;
+                d = j >= p1 ? d1 : d;
+                d = j >= p2 ? d2 : d;
+                d = j >= p3 ? d3 : d;
+                const T *g = x + 4ull * (uint64_t)(j + d);
                 const xd_f4 a = *reinterpret_cast<const xd_f4 *>(g);
                 xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = a.z; xr[u][3] = a.w;
-            } else {
-                const xd_d2 a = *reinterpret_cast<const xd_d2 *>(g), b = *reinterpret_cast<const xd_d2 *>(g + 2);
-                xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = b.x; xr[u][3] = b.y;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t pi = 2u * ((uint32_t)u * kBlock + wbase) + (uint32_t)h * kWave + lane;  // piece of the stage
+                const uint32_t j = pi >> 1;                                                            // its chunk
+                xpiece[u][h] = pi;
+                if (j < xs_tot) {
+                    uint32_t d = d0;
+                    d = j >= p1 ? d1 : d;
+                    d = j >= p2 ? d2 : d;
+                    d = j >= p3 ? d3 : d;
+                    const xd_d2 a = *reinterpret_cast<const xd_d2 *>(x + 4ull * (uint64_t)(j + d) + 2u * (pi & 1u));
+                    xr[u][2 * h] = a.x; xr[u][2 * h + 1] = a.y;
+                }
             }
         }
     }
@@ -108,16 +128,22 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(val + pa), 0, (int)(hi * (uint32_t)sizeof(T)), kXdRsrc);
     xd_u2 cw[2];
     T v[2][4];
+    uint32_t epos[2][2];  // f64: the entry positions (relative to pa) of the thread's two 2-entry pieces
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
-        cw[it] = __builtin_bit_cast(xd_u2, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(j * 2u), 0, 2 /* nt */));
         if constexpr (sizeof(T) == 4) {
+            const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
+            epos[it][0] = epos[it][1] = 0;
+            cw[it] = __builtin_bit_cast(xd_u2, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(j * 2u), 0, 2 /* nt */));
             const xd_f4 a = __builtin_bit_cast(xd_f4, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 4u), 0, 2));
             v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
         } else {
-            const xd_d2 a = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 8u), 0, 2));
-            const xd_d2 b = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 8u + 16u), 0, 2));
+            const uint32_t e0p = 4u * ((uint32_t)it * kBlock + wbase) + 2u * lane, e1p = e0p + 2u * kWave;
+            epos[it][0] = e0p; epos[it][1] = e1p;
+            cw[it].x = __builtin_amdgcn_raw_buffer_load_b32(rc, (int)(e0p * 2u), 0, 2 /* nt */);
+            cw[it].y = __builtin_amdgcn_raw_buffer_load_b32(rc, (int)(e1p * 2u), 0, 2);
+            const xd_d2 a = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(e0p * 8u), 0, 2));
+            const xd_d2 b = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(e1p * 8u), 0, 2));
             v[it][0] = a.x; v[it][1] = a.y; v[it][2] = b.x; v[it][3] = b.y;
         }
     }
@@ -127,16 +153,19 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
     // ---- x into its stage ----
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
-        const uint32_t j = tid + (uint32_t)u * kBlock;
-        if (j < xs_tot) {
-            if constexpr (sizeof(T) == 4) {
+        if constexpr (sizeof(T) == 4) {
+            const uint32_t j = tid + (uint32_t)u * kBlock;
+            if (j < xs_tot) {
                 xd_f4 a; a.x = xr[u][0]; a.y = xr[u][1]; a.z = xr[u][2]; a.w = xr[u][3];
                 *reinterpret_cast<xd_f4 *>(&s_xs[4u * j]) = a;
-            } else {
-                xd_d2 a, b; a.x = xr[u][0]; a.y = xr[u][1]; b.x = xr[u][2]; b.y = xr[u][3];
-                *reinterpret_cast<xd_d2 *>(&s_xs[4u * j]) = a;
-                *reinterpret_cast<xd_d2 *>(&s_xs[4u * j + 2u]) = b;
             }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if ((xpiece[u][h] >> 1) < xs_tot) {
+                    xd_d2 a; a.x = xr[u][2 * h]; a.y = xr[u][2 * h + 1];
+                    *reinterpret_cast<xd_d2 *>(&s_xs[2u * xpiece[u][h]]) = a;
+                }
         }
     }
     __syncthreads();
@@ -144,7 +173,6 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
     const char *xs_bytes = reinterpret_cast<const char *>(s_xs);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
         T p[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -153,12 +181,13 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
             p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + ofs), v[it][e]);
         }
         if constexpr (sizeof(T) == 4) {
+            const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
             xd_f4 a; a.x = p[0]; a.y = p[1]; a.z = p[2]; a.w = p[3];
             *reinterpret_cast<xd_f4 *>(&s_prod[j]) = a;
         } else {
             xd_d2 a, b; a.x = p[0]; a.y = p[1]; b.x = p[2]; b.y = p[3];
-            *reinterpret_cast<xd_d2 *>(&s_prod[j]) = a;
-            *reinterpret_cast<xd_d2 *>(&s_prod[j + 2u]) = b;
+            *reinterpret_cast<xd_d2 *>(&s_prod[epos[it][0]]) = a;
+            *reinterpret_cast<xd_d2 *>(&s_prod[epos[it][1]]) = b;
         }
     }
     __syncthreads();
