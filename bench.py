@@ -410,9 +410,11 @@ def extra_configs(args, lib, check, sm, synth, np, stream, sync):
     share = len(big[3]) / nnz4
     cost4 = inspector_cost(m4, "auto", xp4, n4, yb4.ptr, stream, lib, check, sync, k4["mean"])
     direct = m4.stream_direct() if variant4 == "stream" else False
+    n_dict = len(m4.stream_value_dict()) if direct else 0
     out["C4_spmv"] = {
         "workload": "f32 CSR SpMV, 7-point Laplacian %d^3 (%d rows, %d entries), natural ordering, 1xMI355X (BASELINE configs[3], the product)" % (g, n4, nnz4),
-        "dtype": "f32", "kernel": "%s (AUTO)%s" % (variant4, " = k_spmv_stream_xd (x staged in LDS, 16-bit stage offsets, byte row lengths)" if direct else ""),
+        "dtype": "f32", "kernel": "%s (AUTO)%s" % (variant4, (" = k_spmv_stream_xd (x staged in LDS, 16-bit stage offsets, byte row lengths" + (
+            "; K1s XD-V: the matrix's %d distinct values in a dictionary, their indices in the codes' spare bits, the value array not read)" % n_dict if n_dict else ")")) if direct else ""),
         "kernel_ms": k4["mean"], "kernel_ms_median": k4["median"], "kernel_ms_min": k4["min"], "kernel_ms_max": k4["max"], "launches": k4["launches"],
         "timing": "HIP events on the launch stream around every product",
         "algorithmic_bytes": b4,

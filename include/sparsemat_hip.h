@@ -38,7 +38,8 @@ extern "C" {
  * pointer) and the product count has its own entry point, smh_crs_tiled_products; REMOVED since version 2:
  * smh_crs_set_stream_windows and smh_crs_stream_windows (K1s's column windows are chosen by the inspector alone; the K1s-w kernel
  * they steered left the library); ADDED: smh_crs_tiled_products, smh_crs_prepare_stats,
- * smh_comm_ranks_seen, smh_rccl_version, smh_par_set_threads.  A caller checks smh_abi_version() ==
+ * smh_comm_ranks_seen, smh_rccl_version, smh_par_set_threads,
+ * smh_crs_stream_value_dict, smh_crs_set_stream_value_dict.  A caller checks smh_abi_version() ==
  * SMH_ABI_VERSION once at load time (rust/src/lib.rs does). */
 #define SMH_ABI_VERSION 3
 
@@ -205,6 +206,15 @@ int smh_crs_set_vector_lanes(smh_crs *m, int lanes);
  * and page -- that holds x's last entry; those values are never used).  Same bits as K1s in every form. */
 int smh_crs_set_stream_xs(smh_crs *m, int mode);
 int smh_crs_stream_layout(smh_crs *m, int *coded_out, int *byte_lengths_out, int *small_tiles_out, int *xs_chunks_out);
+/* K1s XD-V, the value dictionary of the CSR-stream kernel (spmv_stream_xd.hip): when the matrix holds at most 32 distinct values (bit
+ * patterns; 16 with the 4096-entry stage of x) -- every constant-coefficient stencil, unweighted graph Laplacians, adjacency matrices --
+ * and the kernel runs with stage offsets (K1s XD), the spare bits of the 16-bit codes name each entry's value in a dictionary and the
+ * value array is not read by the product: 2 bytes per entry instead of 6 (f32) / 10 (f64).  Same products, same order of additions:
+ * still bit for bit SparseMatrix::mvp (sparsematrix.rs:146-158).  Built by smh_crs_prepare / the first product; smh_crs_update_values
+ * makes the library look again, smh_crs_scale scales the dictionary.  *n_values_out: entries of the dictionary in use, 0 = the form is
+ * not active; values_out (optional): room for 32 values.  smh_crs_set_stream_value_dict: -1 automatic, 0 never (SMH_STREAM_VDICT=0). */
+int smh_crs_stream_value_dict(smh_crs *m, int *n_values_out, void *values_out);
+int smh_crs_set_stream_value_dict(smh_crs *m, int mode);
 /* K1s XD: the XS kernel with its per-entry address arithmetic moved into the build -- the 16-bit code array holds the byte offset
  * of x[col] inside the tile's LDS stage instead of (interval, offset), the products are staged unskewed, 16 bytes per store.  Same
  * bits again.  The unskewed stage collides on rows of even length, hence mode -1 = automatic (when x is staged and most rows have

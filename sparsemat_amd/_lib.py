@@ -172,6 +172,8 @@ SIGNATURES = {
     "smh_crs_set_stream_direct": (_int, [_vp, _int]),
     "smh_crs_stream_direct": (_int, [_vp, C.POINTER(_int)]),
     "smh_crs_stream_layout": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    "smh_crs_stream_value_dict": (_int, [_vp, C.POINTER(C.c_int), _vp]),
+    "smh_crs_set_stream_value_dict": (_int, [_vp, _int]),
     "smh_last_transpose_route": (_int, []),
     "smh_pool_trim": (_int, []),
     "smh_pool_stats": (_int, [C.POINTER(_sz), C.POINTER(_sz)]),

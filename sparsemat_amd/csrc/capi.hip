@@ -589,6 +589,8 @@ static void drop_stream_codes(smh_crs *m) {
     m->d_stream_len8 = nullptr;
     m->d_stream_tbase = nullptr;
     m->stream_coded = false;
+    m->stream_direct = m->stream_vdict = false;
+    m->stream_vdict_xs = 0;
 }
 
 // does the VECTOR family run as K1r (LDS x-ring) for this matrix?
@@ -644,6 +646,7 @@ struct StreamCfg {
     bool small = false; // no tile beyond kStreamCapSmall entries: the two-chunk body
     int xs = 0;         // ... and every tile's column intervals fit an LDS stage of x: 16-byte chunks per thread (2 or 4), 0 = no
     bool direct = false;  // `code` holds byte offsets into that stage, not column codes: only K1s XD (spmv_stream_xd.hip) reads it
+    const void *dict = nullptr;  // ... with value-dictionary indices in their spare bits (K1s XD-V): the kernel does not read the values
 };
 // recode = false (every launch path): the configuration is READ from the handle -- the code array keeps the meaning it has.
 // recode = true (the first build, smh_crs_prepare, the setters): the code array is rewritten in place when the choice between
@@ -687,18 +690,41 @@ static int stream_cfg(smh_crs *m, StreamCfg *c, bool recode = false) {
         static const bool xd_off = getenv("SMH_STREAM_XD") && atoi(getenv("SMH_STREAM_XD")) == 0;  // tuning knob
         const bool want_direct = c->code && c->xs != 0 && !xd_off && m->use_stream_direct != 0 &&
                                  (m->use_stream_direct == 1 || 2 * m->stream_odd_rows >= (uint64_t)m->n_rows);
-        if (recode && c->code && want_direct != m->stream_direct) {
+        // K1s XD-V: the matrix's distinct values in a dictionary, their indices in the codes' spare bits (spmv_stream_xd.hip) -- when
+        // the values allow it (at most 32 bit patterns; 16 with the 4096-entry stage).  Looked at once per matrix, and again after
+        // smh_crs_update_values.
+        static const bool vd_off = getenv("SMH_STREAM_VDICT") && atoi(getenv("SMH_STREAM_VDICT")) == 0;  // tuning knob
+        bool want_vdict = want_direct && !vd_off && m->use_stream_vdict != 0 && m->stream_dict_state != 0;
+        bool dict_rebuilt = false;  // (the indices in the codes belong to the dictionary they were made with)
+        if (recode && want_vdict && m->stream_dict_state < 0) {
+            if (!m->d_stream_dict) SMH_HIP(hipMalloc(&m->d_stream_dict, 32 * dtype_size(m->dtype)));
+            SMH_HIP(hipDeviceSynchronize());  // (a product in flight may still read the dictionary)
+            uint32_t n_vals = 0;
+            SMH_TRY(stream_value_dict(m->dtype, m->d_val, m->nnz, m->d_stream_dict, &n_vals, m->stream));
+            m->stream_dict_n = n_vals;
+            m->stream_dict_state = n_vals ? 1 : 0;
+            dict_rebuilt = true;
+        }
+        want_vdict = want_vdict && m->stream_dict_state == 1 && m->stream_dict_n <= stream_value_dict_capacity(c->xs);
+        const bool form_ok = want_direct == m->stream_direct && want_vdict == m->stream_vdict && (!want_vdict || m->stream_vdict_xs == c->xs) &&
+                             !(dict_rebuilt && (want_vdict || m->stream_vdict));
+        if (recode && c->code && !form_ok) {
             SMH_HIP(hipDeviceSynchronize());  // (a product enqueued on any stream may still read the array)
             if (want_direct)
                 SMH_TRY(launch_stream_stage_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, (uint32_t)dtype_size(m->dtype), m->d_stream_code, m->stream));
             else
                 SMH_TRY(launch_stream_codes(m->d_off, m->d_col, m->d_stream_cwin, m->n_rows, m->d_stream_code, m->stream));
+            if (want_vdict)
+                SMH_TRY(launch_stream_value_codes(m->dtype, m->d_val, m->nnz, m->d_stream_dict, m->stream_dict_n, c->xs, m->d_stream_code, m->stream));
             SMH_HIP(hipStreamSynchronize(m->stream));
             m->stream_direct = want_direct;
+            m->stream_vdict = want_vdict;
+            m->stream_vdict_xs = want_vdict ? c->xs : 0;
         }
         // (stage offsets without a stage -- xs == 0 after a setter that was not followed by a prepare cannot happen: the setters
         // recode; an x too short / misaligned for the stage is handled per call in stream_launch)
         c->direct = c->code && m->stream_direct;
+        c->dict = c->direct && m->stream_vdict ? m->d_stream_dict : nullptr;
     }
     return SMH_OK;
 }
@@ -716,7 +742,7 @@ static int stream_launch(smh_crs *m, const StreamCfg &c, const void *x, size_t x
     if (c.direct) {
         if (xs_ok && c.xs)
             return launch_spmv_stream_xd(m->dtype, m->d_val, x, y, m->n_rows, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s,
-                                         c.xs, t0, t1);
+                                         c.xs, t0, t1, c.dict);
         // stage offsets mean nothing without the stage: this call streams the u32 columns (same arithmetic, same order)
         return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt, c.single_pass,
                                   dot_partials, nullptr, nullptr, nullptr, nullptr, dot_lhs, s, false, 0, t0, t1);
@@ -1301,7 +1327,7 @@ int smh_crs_destroy(smh_crs *m) {
     (void)hipFree(m->d_tile_row); (void)hipFree(m->d_tile_nz); (void)hipFree(m->d_carry_row); (void)hipFree(m->d_carry_val);
     (void)hipFree(m->d_phase_ptr); (void)hipFree(m->d_phases); (void)hipFree(m->d_col16); (void)hipFree(m->d_ring_win);
     (void)hipFree(m->d_stream_cwin); (void)hipFree(m->d_stream_code);
-    (void)hipFree(m->d_stream_len8); (void)hipFree(m->d_stream_tbase);
+    (void)hipFree(m->d_stream_len8); (void)hipFree(m->d_stream_tbase); (void)hipFree(m->d_stream_dict);
     (void)hipFree(m->d_cb_off); (void)hipFree(m->d_cb_col); (void)hipFree(m->d_cb_val);
     (void)hipFree(m->d_cf_seg); (void)hipFree(m->d_cf_cnt); (void)hipFree(m->d_cf_col); (void)hipFree(m->d_cf_val);
     (void)hipFree(m->d_cf_tile_row);
@@ -1318,6 +1344,13 @@ int smh_crs_update_values(smh_crs *m, const void *values_host) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL argument");
     if (m->nnz && values_host) SMH_HIP(hipMemcpy(m->d_val, values_host, m->nnz * dtype_size(m->dtype), hipMemcpyHostToDevice));
     drop_colblock(m);
+    // the value dictionary of K1s XD-V described the OLD values: look again now (one pass over the values: nothing beside the copy above)
+    // and take the indices out of the codes, or put the new ones in
+    m->stream_dict_state = -1;
+    if (m->stream_coded && m->stream_direct) {
+        StreamCfg c;
+        SMH_TRY(stream_cfg(m, &c, true));
+    }
     return SMH_OK;
 }
 
@@ -1352,6 +1385,8 @@ int smh_crs_col_range(const smh_crs *m, uint32_t *min_out, uint32_t *max_out) {
 int smh_crs_scale(smh_crs *m, double a) {
     if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
     SMH_TRY(launch_scale_values(m->dtype, m->d_val, m->nnz, a, m->stream));
+    // (K1s XD-V: every entry is its dictionary value times a, rounded as the entry itself is: the indices in the codes stay right)
+    if (m->d_stream_dict && m->stream_dict_state == 1) SMH_TRY(launch_scale_values(m->dtype, m->d_stream_dict, 32, a, m->stream));
     if (m->cb_built) SMH_TRY(launch_scale_values(m->dtype, m->d_cb_val, m->nnz, a, m->stream));
     if (m->cf_built && m->cf_ok) SMH_TRY(launch_scale_values(m->dtype, m->d_cf_val, m->nnz, a, m->stream));
     if (m->t2_built && m->t2_ok) SMH_TRY(launch_scale_values(m->dtype, m->d_t2_val, (size_t)m->t2_tot, a, m->stream));
@@ -1484,6 +1519,29 @@ int smh_crs_stream_direct(smh_crs *m, int *direct_out) {
     StreamCfg c;
     SMH_TRY(stream_cfg(m, &c));
     *direct_out = c.direct && c.xs != 0;
+    return SMH_OK;
+}
+
+int smh_crs_stream_value_dict(smh_crs *m, int *n_values_out, void *values_out) {
+    if (!m || !n_values_out) return fail(SMH_ERR_INVALID, "NULL argument");
+    StreamCfg c;
+    SMH_TRY(stream_cfg(m, &c));
+    *n_values_out = c.dict ? (int)m->stream_dict_n : 0;
+    if (c.dict && values_out) {
+        SMH_HIP(hipMemcpyAsync(values_out, m->d_stream_dict, (size_t)m->stream_dict_n * dtype_size(m->dtype), hipMemcpyDeviceToHost, m->stream));
+        SMH_HIP(hipStreamSynchronize(m->stream));
+    }
+    return SMH_OK;
+}
+
+int smh_crs_set_stream_value_dict(smh_crs *m, int mode) {
+    if (!m) return fail(SMH_ERR_INVALID, "NULL handle");
+    if (mode < -1 || mode > 0) return fail(SMH_ERR_INVALID, "mode must be -1 (automatic: whenever the values allow) or 0 (never)");
+    m->use_stream_vdict = mode;
+    if (m->stream_coded) {
+        StreamCfg c;
+        SMH_TRY(stream_cfg(m, &c, true));
+    }
     return SMH_OK;
 }
 

@@ -78,7 +78,12 @@ int launch_stream_codes(const uint32_t *off, const uint32_t *col, const uint32_t
 // K1s XD (spmv_stream_xd.hip): the code array as byte offsets into the tile's LDS stage of x, an unskewed product stage
 int launch_spmv_stream_xd(int dtype, const void *val, const void *x, void *y, size_t n_rows, void *dot_partials, const uint16_t *scode,
                           const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs, hipStream_t s, int xs,
-                          uint64_t tile_begin = 0, uint64_t tile_end = ~uint64_t(0));
+                          uint64_t tile_begin = 0, uint64_t tile_end = ~uint64_t(0), const void *dict = nullptr /* K1s XD-V: value dictionary */);
+// K1s XD-V (spmv_stream_xd.hip): the dictionary of val's distinct bit patterns (32 entries of the value type on the device; *count_out
+// = 0 when there are more), the codes' spare bits filled with the entries' dictionary indices, and how many indices those bits can name
+int stream_value_dict(int dtype, const void *val, size_t nnz, void *dict_out, uint32_t *count_out, hipStream_t s);
+int launch_stream_value_codes(int dtype, const void *val, size_t nnz, const void *dict, uint32_t n, int xs, uint16_t *code, hipStream_t s);
+uint32_t stream_value_dict_capacity(int xs);
 int launch_stream_stage_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint32_t elem_bytes,
                               uint16_t *code, hipStream_t s);
 int launch_stream_odd_rows(const uint8_t *len8, size_t n_padded, unsigned long long *d_out, hipStream_t s);
@@ -270,6 +275,13 @@ struct smh_crs {
     int use_stream_xs = -1;  // K1s XS: -1 automatic (x beyond the L2s; the 4096-entry stage on f32 only), 0 never, 1 whenever the tiles allow
     uint32_t stream_xs_chunks = 0xFFFFFFFFu, stream_xs_end = 0;  // K1s XS: most x chunks a tile needs; largest x index + 1 they touch
     bool stream_direct = false;   // d_stream_code holds stage byte offsets (K1s XD) instead of column codes
+    // K1s XD-V: ... and, in their spare bits, indices into a dictionary of the matrix's distinct values (the value array is then not read)
+    bool stream_vdict = false;    // the codes carry the indices now (built for a stage of stream_vdict_xs * 1024 entries)
+    int stream_vdict_xs = 0;
+    int stream_dict_state = -1;   // -1 not looked at (or the values changed), 0 too many distinct values, 1 d_stream_dict / stream_dict_n are valid
+    uint32_t stream_dict_n = 0;
+    void *d_stream_dict = nullptr;  // 32 values
+    int use_stream_vdict = -1;    // -1 automatic (whenever the values allow), 0 never
     int use_stream_direct = -1;   // K1s XD: -1 automatic (most rows of odd length), 0 never, 1 whenever x is staged
     uint64_t stream_odd_rows = 0; // rows of odd length (taken with the byte lengths)
     uint16_t *d_col16 = nullptr;  // K1r: 16-bit column array for the ring phases (lazy; null: not used)

@@ -52,13 +52,34 @@ __device__ __forceinline__ uint32_t xd_wave_scan(uint32_t v) {
 constexpr int kXdSlots = 2 * 4 * kBlock;  // product slots of a tile: two 4-entry chunks per thread (kStreamCapSmall + 3 <= 2048)
 static_assert(kStreamCapSmall + 3 <= kXdSlots, "a tile's entries from an aligned start fit two chunks per thread");
 
-// XS: 16-byte chunks of x per thread the tile's stage holds (2 or 4)
-template <typename T, bool DOT, int XS>
+// K1s XD-V: the VALUE DICTIONARY form.  A stage offset is a multiple of sizeof(T) below the stage's size, so a 16-bit code has bits
+// to spare -- the low log2(sizeof T) ones and those above the stage: 5 bits with the 2048-entry stage (f32 and f64), 4 with the
+// 4096-entry one.  When the matrix holds no more than 32 / 16 DISTINCT values (bit patterns) -- every constant-coefficient stencil,
+// every unweighted graph Laplacian or adjacency matrix; BASELINE C4 has two, 6 and -1 -- those bits name the entry's value in a
+// dictionary the kernel keeps in LDS, and the value array is not read at all: 2 bytes per entry leave HBM instead of 6 (f32) / 10
+// (f64).  The product is x times the very same bit pattern as before, the adds are in storage order: still bit for bit the
+// reference's result.  (capi.hip decides; k_value_dict_* below build the dictionary, exactly, or say that it does not exist.)
+template <typename T, int XS> struct XdBits {
+    static constexpr uint32_t kLow = sizeof(T) == 8 ? 3u : 2u;                 // free low bits
+    static constexpr uint32_t kIdx = XS == 4 ? 12u : 11u;                      // bits of an entry index inside the stage
+    static constexpr uint32_t kOfsMask = ((1u << (kLow + kIdx)) - 1u) & ~((1u << kLow) - 1u);
+    static constexpr uint32_t kValues = 1u << (16u - kIdx);                    // 32 / 16 dictionary entries
+    __device__ static __forceinline__ uint32_t ofs(uint32_t c) { return c & kOfsMask; }
+    __device__ static __forceinline__ uint32_t vidx(uint32_t c) { return (c & ((1u << kLow) - 1u)) | ((c >> (kLow + kIdx)) << kLow); }
+};
+
+// XS: 16-byte chunks of x per thread the tile's stage holds (2 or 4); VD: the codes carry value-dictionary indices (val is not read)
+template <typename T, bool DOT, int XS, bool VD = false>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t n_tiles,
                  T *__restrict__ dot_partials, const uint16_t *__restrict__ scode, const uint32_t *__restrict__ cwin,
-                 const uint8_t *__restrict__ len8, const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs, uint64_t tile0) {
+                 const uint8_t *__restrict__ len8, const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs, uint64_t tile0,
+                 const T *__restrict__ dict = nullptr) {
     constexpr int kXsCap = XS * kBlock * 4;  // entries of x the stage holds (2048 / 4096)
+    __shared__ T s_dict[VD ? 32 : 1];
+    if constexpr (VD) {
+        if (threadIdx.x < 32u) s_dict[threadIdx.x] = dict[threadIdx.x];  // (the dictionary array has 32 entries whatever its fill; read before the barrier below)
+    }
     __shared__ __attribute__((aligned(16))) T s_xs[kXsCap];
     __shared__ __attribute__((aligned(16))) T s_prod[kXdSlots + 8];  // (+8: a row's eight unconditional reads may pass the tile's end)
     __shared__ uint32_t s_wtot[kBlock / kWave];
@@ -131,20 +152,25 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
     uint32_t epos[2][2];  // f64: the entry positions (relative to pa) of the thread's two 2-entry pieces
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
+        v[it][0] = v[it][1] = v[it][2] = v[it][3] = T(0);
         if constexpr (sizeof(T) == 4) {
             const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
             epos[it][0] = epos[it][1] = 0;
             cw[it] = __builtin_bit_cast(xd_u2, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(j * 2u), 0, 2 /* nt */));
-            const xd_f4 a = __builtin_bit_cast(xd_f4, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 4u), 0, 2));
-            v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+            if constexpr (!VD) {
+                const xd_f4 a = __builtin_bit_cast(xd_f4, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(j * 4u), 0, 2));
+                v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+            }
         } else {
             const uint32_t e0p = 4u * ((uint32_t)it * kBlock + wbase) + 2u * lane, e1p = e0p + 2u * kWave;
             epos[it][0] = e0p; epos[it][1] = e1p;
             cw[it].x = __builtin_amdgcn_raw_buffer_load_b32(rc, (int)(e0p * 2u), 0, 2 /* nt */);
             cw[it].y = __builtin_amdgcn_raw_buffer_load_b32(rc, (int)(e1p * 2u), 0, 2);
-            const xd_d2 a = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(e0p * 8u), 0, 2));
-            const xd_d2 b = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(e1p * 8u), 0, 2));
-            v[it][0] = a.x; v[it][1] = a.y; v[it][2] = b.x; v[it][3] = b.y;
+            if constexpr (!VD) {
+                const xd_d2 a = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(e0p * 8u), 0, 2));
+                const xd_d2 b = __builtin_bit_cast(xd_d2, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(e1p * 8u), 0, 2));
+                v[it][0] = a.x; v[it][1] = a.y; v[it][2] = b.x; v[it][3] = b.y;
+            }
         }
     }
     // ---- row boundaries: prefix sum of the byte lengths (its cross-wave part rides on the barrier below) ----
@@ -177,8 +203,13 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t cword = (e >> 1) ? cw[it].y : cw[it].x;
-            const uint32_t ofs = (e & 1) ? (cword >> 16) : (cword & 0xFFFFu);
-            p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + ofs), v[it][e]);
+            const uint32_t code = (e & 1) ? (cword >> 16) : (cword & 0xFFFFu);
+            if constexpr (VD) {
+                // (a slot past the tile reads code 0: stage entry 0 times dictionary entry 0 -- never added to any row)
+                p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + XdBits<T, XS>::ofs(code)), s_dict[XdBits<T, XS>::vidx(code)]);
+            } else {
+                p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + code), v[it][e]);
+            }
         }
         if constexpr (sizeof(T) == 4) {
             const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
@@ -248,6 +279,103 @@ k_stream_stage_codes(const uint32_t *__restrict__ off, const uint32_t *__restric
     }
 }
 
+// ---- the value dictionary (see K1s XD-V above) --------------------------------------------------------------------------------------
+// Distinct BIT PATTERNS of val[0..nnz), at most kXdDictCap of them, exactly -- or the verdict that there are more.  Phase 1: every
+// workgroup collects the patterns of its share in an LDS table (compare-and-swap into the first empty slot) and leaves the table in
+// global memory; a workgroup whose table overflows raises a flag that makes everybody stop (a matrix with arbitrary values is found
+// out within the first few hundred entries of every workgroup).  Phase 2: one workgroup merges the tables the same way, sorts the
+// result by bit pattern (the dictionary must not depend on who came first) and publishes it.
+constexpr uint32_t kXdDictCap = 32;
+// (a slot is empty while it holds this pattern -- a NaN payload no computation produces; a matrix that does hold it is reported as
+// "more than the dictionary holds", which costs it nothing but this optimisation)
+template <typename T> struct XdPat;
+template <> struct XdPat<float> { typedef uint32_t U; static constexpr U kEmpty = 0x7FC5A5A5u; };
+template <> struct XdPat<double> { typedef unsigned long long U; static constexpr U kEmpty = 0x7FF8A5A55A5AA5A5ull; };
+
+template <typename U>
+__device__ __forceinline__ bool xd_dict_insert(U *tab, U pat, U empty) {  // false: the table is full and does not hold pat
+    for (uint32_t i = 0; i < kXdDictCap; ++i) {
+        const U seen = tab[i];
+        if (seen == pat) return true;
+        if (seen == empty) {
+            const U old = atomicCAS(tab + i, empty, pat);
+            if (old == empty || old == pat) return true;
+        }
+    }
+    return false;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_value_dict_collect(const T *__restrict__ val, uint64_t nnz, typename XdPat<T>::U *__restrict__ wg_tables, uint32_t *__restrict__ overflow) {
+    typedef typename XdPat<T>::U U;
+    __shared__ U tab[kXdDictCap];
+    if (threadIdx.x < kXdDictCap) tab[threadIdx.x] = XdPat<T>::kEmpty;
+    __syncthreads();
+    const U *bits = reinterpret_cast<const U *>(val);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kBlock) {
+        if (*(volatile uint32_t *)overflow) break;  // somebody found a 33rd value: nothing left to learn
+        const U pat = bits[i];
+        if (pat == XdPat<T>::kEmpty || !xd_dict_insert<U>(tab, pat, XdPat<T>::kEmpty)) { atomicOr(overflow, 1u); break; }
+    }
+    __syncthreads();
+    if (threadIdx.x < kXdDictCap) wg_tables[(uint64_t)blockIdx.x * kXdDictCap + threadIdx.x] = tab[threadIdx.x];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_value_dict_merge(const typename XdPat<T>::U *__restrict__ wg_tables, uint32_t n_tables, T *__restrict__ dict, uint32_t *__restrict__ count,
+                   uint32_t *__restrict__ overflow) {
+    typedef typename XdPat<T>::U U;
+    __shared__ U tab[kXdDictCap];
+    __shared__ uint32_t s_over;
+    if (threadIdx.x < kXdDictCap) tab[threadIdx.x] = XdPat<T>::kEmpty;
+    if (threadIdx.x == 0) s_over = *overflow;
+    __syncthreads();
+    if (!s_over) {
+        for (uint32_t i = threadIdx.x; i < n_tables * kXdDictCap; i += kBlock) {
+            const U pat = wg_tables[i];
+            if (pat != XdPat<T>::kEmpty && !xd_dict_insert<U>(tab, pat, XdPat<T>::kEmpty)) s_over = 1u;  // (benign race: any writer writes 1)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        U sorted[kXdDictCap];
+        for (uint32_t i = 0; i < kXdDictCap; ++i)
+            if (tab[i] != XdPat<T>::kEmpty) sorted[n++] = tab[i];
+        for (uint32_t i = 1; i < n; ++i) {  // insertion sort by bit pattern: <= 32 entries, once per matrix
+            const U v = sorted[i];
+            uint32_t j = i;
+            while (j > 0 && sorted[j - 1] > v) { sorted[j] = sorted[j - 1]; --j; }
+            sorted[j] = v;
+        }
+        U *out = reinterpret_cast<U *>(dict);
+        for (uint32_t i = 0; i < kXdDictCap; ++i) out[i] = i < n ? sorted[i] : (U)0;
+        *count = s_over ? 0u : n;
+        *overflow = s_over;
+    }
+}
+
+// code[k] |= the dictionary index of val[k], spread over the code's spare bits (low `low` bits, then the bits from `high_shift` up)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_value_dict_encode(const T *__restrict__ val, uint64_t nnz, const T *__restrict__ dict, uint32_t n, uint32_t low, uint32_t high_shift,
+                    uint16_t *__restrict__ code) {
+    typedef typename XdPat<T>::U U;
+    __shared__ U tab[kXdDictCap];
+    if (threadIdx.x < kXdDictCap) tab[threadIdx.x] = reinterpret_cast<const U *>(dict)[threadIdx.x];
+    __syncthreads();
+    const U *bits = reinterpret_cast<const U *>(val);
+    for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += (uint64_t)gridDim.x * kBlock) {
+        const U pat = bits[k];
+        uint32_t idx = 0;
+        for (uint32_t i = 0; i < n; ++i) idx = tab[i] == pat ? i : idx;  // (every pattern is in the dictionary: it was built from these values)
+        const uint32_t lowmask = (1u << low) - 1u;
+        code[k] = (uint16_t)(code[k] | (idx & lowmask) | ((idx >> low) << high_shift));
+    }
+}
+
 // rows of odd length (decides whether the unskewed stage applies)
 __global__ void __launch_bounds__(kBlock)
 k_stream_odd_rows(const uint8_t *__restrict__ len8, uint64_t n, unsigned long long *__restrict__ out) {
@@ -260,18 +388,25 @@ k_stream_odd_rows(const uint8_t *__restrict__ len8, uint64_t n, unsigned long lo
 
 template <typename T>
 int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, const uint16_t *scode, const uint32_t *cwin,
-                const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs, hipStream_t s, int xs, uint64_t tile_begin, uint64_t tile_end) {
+                const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs, hipStream_t s, int xs, uint64_t tile_begin, uint64_t tile_end,
+                const T *dict) {
     const uint64_t all_tiles = stream_tiles(n_rows, 1);
     const uint64_t tile0 = tile_begin < all_tiles ? tile_begin : all_tiles, tile1 = tile_end < all_tiles ? tile_end : all_tiles;
     if (tile1 <= tile0) return SMH_OK;
     const uint64_t n_tiles = tile1 - tile0;
     const dim3 grid((unsigned)n_tiles), block(kBlock);
-#define SMH_XD(D, P)                                                                                                              \
-    hipLaunchKernelGGL((k_spmv_stream_xd<T, D, P>), grid, block, 0, s, val, x, y, (uint64_t)n_rows, n_tiles, dot_partials, scode, \
-                       cwin, len8, tbase, dot_lhs, tile0)
-    if (xs == 2) { if (dot_partials) SMH_XD(true, 2); else SMH_XD(false, 2); }
-    else if (xs == 4) { if (dot_partials) SMH_XD(true, 4); else SMH_XD(false, 4); }
+#define SMH_XD(D, P, V)                                                                                                              \
+    hipLaunchKernelGGL((k_spmv_stream_xd<T, D, P, V>), grid, block, 0, s, val, x, y, (uint64_t)n_rows, n_tiles, dot_partials, scode, \
+                       cwin, len8, tbase, dot_lhs, tile0, dict)
+#define SMH_XD2(P)                                                                       \
+    do {                                                                                 \
+        if (dict) { if (dot_partials) SMH_XD(true, P, true); else SMH_XD(false, P, true); } \
+        else { if (dot_partials) SMH_XD(true, P, false); else SMH_XD(false, P, false); }    \
+    } while (0)
+    if (xs == 2) SMH_XD2(2);
+    else if (xs == 4) SMH_XD2(4);
     else return fail(SMH_ERR_INVALID, "K1s XD: the stage of x holds 2 or 4 chunks per thread");
+#undef SMH_XD2
 #undef SMH_XD
     SMH_HIP(hipGetLastError());
     return SMH_OK;
@@ -279,18 +414,74 @@ int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, 
 
 }  // namespace
 
+// dict != NULL: the codes carry value-dictionary indices (K1s XD-V); val is then not read
 int launch_spmv_stream_xd(int dtype, const void *val, const void *x, void *y, size_t n_rows, void *dot_partials, const uint16_t *scode,
                           const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs, hipStream_t s, int xs,
-                          uint64_t tile_begin, uint64_t tile_end) {
+                          uint64_t tile_begin, uint64_t tile_end, const void *dict) {
     if (n_rows == 0) return SMH_OK;
     if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
     if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
     if (dtype == SMH_F64)
         return launch_xd_t<double>((const double *)val, (const double *)x, (double *)y, n_rows, (double *)dot_partials, scode, cwin, len8,
-                                   tbase, (const double *)dot_lhs, s, xs, tile_begin, tile_end);
+                                   tbase, (const double *)dot_lhs, s, xs, tile_begin, tile_end, (const double *)dict);
     return launch_xd_t<float>((const float *)val, (const float *)x, (float *)y, n_rows, (float *)dot_partials, scode, cwin, len8, tbase,
-                              (const float *)dot_lhs, s, xs, tile_begin, tile_end);
+                              (const float *)dot_lhs, s, xs, tile_begin, tile_end, (const float *)dict);
 }
+
+// The dictionary of val's distinct bit patterns: dict_out (device, 32 entries of the value type, sorted by pattern, unused ones zero)
+// and *count_out = how many (0: more than 32, or the reserved pattern occurs).  Synchronises the stream.
+template <typename T>
+static int value_dict_t(const T *val, size_t nnz, T *dict_out, uint32_t *count_out, hipStream_t s) {
+    typedef typename XdPat<T>::U U;
+    *count_out = 0;
+    if (nnz == 0) return SMH_OK;
+    uint64_t blocks = (nnz + (uint64_t)kBlock * 64 - 1) / ((uint64_t)kBlock * 64);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    U *tables = nullptr;
+    uint32_t *flags = nullptr;  // [0] overflow, [1] count
+    SMH_HIP(hipMalloc((void **)&tables, blocks * kXdDictCap * sizeof(U)));
+    hipError_t e = hipMalloc((void **)&flags, 2 * sizeof(uint32_t));
+    uint32_t h[2] = {1u, 0u};
+    auto go = [&]() -> int {
+        SMH_HIP(e);
+        SMH_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_value_dict_collect<T>, dim3((unsigned)blocks), dim3(kBlock), 0, s, val, (uint64_t)nnz, tables, flags);
+        SMH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_value_dict_merge<T>, dim3(1), dim3(kBlock), 0, s, (const U *)tables, (uint32_t)blocks, dict_out, flags + 1, flags);
+        SMH_HIP(hipGetLastError());
+        SMH_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
+        SMH_HIP(hipStreamSynchronize(s));
+        return SMH_OK;
+    };
+    const int rc = go();
+    (void)hipFree(tables);
+    (void)hipFree(flags);
+    SMH_TRY(rc);
+    *count_out = h[0] ? 0u : h[1];
+    return SMH_OK;
+}
+
+int stream_value_dict(int dtype, const void *val, size_t nnz, void *dict_out, uint32_t *count_out, hipStream_t s) {
+    return dtype == SMH_F64 ? value_dict_t<double>((const double *)val, nnz, (double *)dict_out, count_out, s)
+                            : value_dict_t<float>((const float *)val, nnz, (float *)dict_out, count_out, s);
+}
+
+// code[k] |= index of val[k] in the dictionary (n entries), in the spare bits of a stage-offset code for a stage of xs * 1024 entries
+int launch_stream_value_codes(int dtype, const void *val, size_t nnz, const void *dict, uint32_t n, int xs, uint16_t *code, hipStream_t s) {
+    if (nnz == 0) return SMH_OK;
+    const uint32_t low = dtype == SMH_F64 ? 3u : 2u, high_shift = low + (xs == 4 ? 12u : 11u);
+    uint64_t blocks = (nnz + kBlock - 1) / kBlock;
+    if (blocks > 16384) blocks = 16384;
+    if (dtype == SMH_F64)
+        hipLaunchKernelGGL(k_value_dict_encode<double>, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const double *)val, (uint64_t)nnz, (const double *)dict, n, low, high_shift, code);
+    else
+        hipLaunchKernelGGL(k_value_dict_encode<float>, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float *)val, (uint64_t)nnz, (const float *)dict, n, low, high_shift, code);
+    SMH_HIP(hipGetLastError());
+    return SMH_OK;
+}
+
+// how many dictionary entries the spare bits of a code can name, for a stage of xs * 1024 entries
+uint32_t stream_value_dict_capacity(int xs) { return xs == 4 ? 16u : 32u; }
 
 int launch_stream_stage_codes(const uint32_t *off, const uint32_t *col, const uint32_t *win, size_t n_rows, uint32_t elem_bytes,
                               uint16_t *code, hipStream_t s) {

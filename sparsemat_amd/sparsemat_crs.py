@@ -309,6 +309,19 @@ class SparseMatCRS:
         check(lib().smh_crs_stream_direct(self._h, C.byref(a)))
         return bool(a.value)
 
+    def stream_value_dict(self):
+        """K1s XD-V (``smh_crs_stream_value_dict``): the dictionary of the matrix's distinct values the CSR-stream kernel multiplies
+        with instead of reading the value array -- a numpy array of its entries, empty when the form is not active (more than 32 / 16
+        distinct values, or no stage-offset codes)."""
+        n = C.c_int()
+        buf = np.zeros(32, dtype=self.dtype)
+        check(lib().smh_crs_stream_value_dict(self._h, C.byref(n), buf.ctypes.data))
+        return buf[:n.value].copy()
+
+    def set_stream_value_dict(self, mode):
+        """-1 automatic (whenever the values allow), 0 never (``smh_crs_set_stream_value_dict``)."""
+        check(lib().smh_crs_set_stream_value_dict(self._h, int(mode)))
+
     def stream_layout(self):
         """What a STREAM launch of this matrix uses: dict(coded, byte_lengths, small_tiles, xs_chunks)."""
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -305,3 +305,82 @@ def test_stream_xd_stage_offsets_bit_exact(gpu, dtype):
         assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), name
         m.set_stream_direct(-1)
         assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(y_ref)), name
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_stream_value_dictionary_bit_exact(gpu, dtype):
+    """K1s XD-V: with at most 32 distinct values (16 with the 4096-entry stage) the spare bits of the stage-offset codes name each entry's
+    value in a dictionary and the kernel does not read the value array.  The dictionary is exact (bit patterns, -0.0 and +0.0 apart),
+    sorted by pattern, and vanishes the moment the values do not allow it; update_values looks again, scale scales it; the product, the
+    dot epilogue and the solver stay bit for bit what they were."""
+    rng = np.random.default_rng(77)
+    u = np.uint32 if dtype == np.float32 else np.uint64
+
+    def expect(vals):  # distinct bit patterns, sorted as unsigned integers
+        return np.sort(np.unique(np.asarray(vals, dtype).view(u))).view(dtype)
+
+    def check(m, off, col, val, n, name, want_n):
+        x, lhs = rng.uniform(-1, 1, n).astype(dtype), rng.uniform(-1, 1, n).astype(dtype)
+        d = m.stream_value_dict()
+        assert len(d) == want_n, (name, len(d), want_n)
+        if want_n:  # (sorted by bit pattern when it is built; smh_crs_scale scales it in place, which may reorder the patterns)
+            assert np.array_equal(np.sort(bits(d)), bits(expect(val))), name
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x))), name
+        m.set_stream_value_dict(0)   # the same kernel reading the value array: same bits, same dot
+        assert len(m.stream_value_dict()) == 0
+        ip0 = m.inner_prod(lhs, x, variant="stream")
+        assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(oracle.spmv(off, col, val, x))), name
+        m.set_stream_value_dict(-1)
+        assert len(m.stream_value_dict()) == want_n and m.inner_prod(lhs, x, variant="stream") == ip0, name
+
+    # the stencils: two values; the 2048-entry stage and (wide planes) the 4096-entry one
+    for g in ((40, 40, 40), (1000, 30, 3)):
+        off, col, val = oracle.laplace3d(*g, dtype)
+        n = g[0] * g[1] * g[2]
+        m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+        m.set_stream_xs(1)
+        m.set_stream_direct(1)   # (automatic only where most rows are of odd length: not so on the three-plane grid)
+        assert m.stream_direct() and (m.stream_layout()["xs_chunks"] == 4) == (g[0] == 1000)
+        check(m, off, col, val, n, "laplace %s" % (g,), 2)
+        # scale: the dictionary is scaled with the values
+        m.scale(-0.375)
+        check(m, off, col, (val * dtype(-0.375)).astype(dtype), n, "scaled", 2)
+        # new values, arbitrary: the form goes away; back to a few: it returns
+        v2 = rng.uniform(-1, 1, len(val)).astype(dtype)
+        m.update_values(v2)
+        check(m, off, col, v2, n, "arbitrary values", 0)
+        few = np.array([0.0, -0.0, 1.5, -2.25, 3.0], dtype)
+        v3 = few[rng.integers(0, 5, len(val))]
+        m.update_values(v3)
+        check(m, off, col, v3, n, "five values, both zeros", 5)
+        # the solver on top (fused p.Ap epilogue) against the oracle
+        m.update_values(val)   # other values, the same NUMBER of them as before the last update is not the same dictionary
+        check(m, off, col, val, n, "the first values again", 2)
+        m.update_values(v3)
+        m.update_values((v3 * dtype(2)).astype(dtype))
+        check(m, off, col, (v3 * dtype(2)).astype(dtype), n, "five values doubled", 5)
+        if g[0] == 40:
+            m.update_values(val)
+            b = oracle.spmv(off, col, val, np.ones(n, dtype))
+            tol = 2e-2 if dtype == np.float32 else 1e-9  # (f32: well above what the type attains on this matrix, cf. bench.py's C4 gate)
+            xs = np.zeros(n, dtype)
+            cg = sm.ConjugateGradient(tol, 500)
+            cg.solve(m, b, xs)
+            x_ref, it_ref, _ = oracle.cg(n, n, off, col, val, b, np.zeros(n, dtype), tol=tol, iter_max=500)
+            assert len(m.stream_value_dict()) == 2 and abs(cg.iterations - it_ref) <= 1 and np.abs(xs - x_ref).max() <= 10 * tol, (cg.iterations, it_ref)
+    # capacity: 32 distinct values with the 2048-entry stage (33: no), 16 with the 4096-entry one (17: no)
+    for g, cap in (((40, 40, 40), 32), ((1000, 30, 3), 16)):
+        off, col, _ = oracle.laplace3d(*g, dtype)
+        n = g[0] * g[1] * g[2]
+        for k in (cap, cap + 1):
+            pool = (np.arange(k) * 0.37 - 3.0).astype(dtype)
+            val = pool[rng.integers(0, k, len(col))]
+            val[:k] = pool   # every value occurs
+            m = sm.SparseMatCRS.from_raw_parts(n, n, off, col, val)
+            m.set_stream_xs(1)
+            m.set_stream_direct(1)
+            check(m, off, col, val, n, "%d values" % k, k if k <= cap else 0)
+    # without stage offsets (x not staged) there are no spare bits: nothing changes
+    off, col, val = oracle.laplace3d(12, 12, 12, dtype)
+    m = sm.SparseMatCRS.from_raw_parts(1728, 1728, off, col, val)
+    assert not m.stream_direct() and len(m.stream_value_dict()) == 0
