@@ -647,6 +647,7 @@ struct StreamCfg {
     int xs = 0;         // ... and every tile's column intervals fit an LDS stage of x: 16-byte chunks per thread (2 or 4), 0 = no
     bool direct = false;  // `code` holds byte offsets into that stage, not column codes: only K1s XD (spmv_stream_xd.hip) reads it
     const void *dict = nullptr;  // ... with value-dictionary indices in their spare bits (K1s XD-V): the kernel does not read the values
+    bool dict_high = false;      // ... in the high spare bits alone (few values)
 };
 // recode = false (every launch path): the configuration is READ from the handle -- the code array keeps the meaning it has.
 // recode = true (the first build, smh_crs_prepare, the setters): the code array is rewritten in place when the choice between
@@ -725,6 +726,7 @@ static int stream_cfg(smh_crs *m, StreamCfg *c, bool recode = false) {
         // recode; an x too short / misaligned for the stage is handled per call in stream_launch)
         c->direct = c->code && m->stream_direct;
         c->dict = c->direct && m->stream_vdict ? m->d_stream_dict : nullptr;
+        c->dict_high = c->dict && stream_value_dict_high(m->dtype, m->stream_dict_n, m->stream_vdict_xs);
     }
     return SMH_OK;
 }
@@ -742,7 +744,7 @@ static int stream_launch(smh_crs *m, const StreamCfg &c, const void *x, size_t x
     if (c.direct) {
         if (xs_ok && c.xs)
             return launch_spmv_stream_xd(m->dtype, m->d_val, x, y, m->n_rows, dot_partials, c.code, c.cwin, c.len8, c.tbase, dot_lhs, s,
-                                         c.xs, t0, t1, c.dict);
+                                         c.xs, t0, t1, c.dict, c.dict_high);
         // stage offsets mean nothing without the stage: this call streams the u32 columns (same arithmetic, same order)
         return launch_spmv_stream(m->dtype, m->d_off, m->d_col, m->d_val, x, y, m->n_rows, m->nnz, m->owns, c.rpt, c.single_pass,
                                   dot_partials, nullptr, nullptr, nullptr, nullptr, dot_lhs, s, false, 0, t0, t1);

@@ -78,7 +78,9 @@ int launch_stream_codes(const uint32_t *off, const uint32_t *col, const uint32_t
 // K1s XD (spmv_stream_xd.hip): the code array as byte offsets into the tile's LDS stage of x, an unskewed product stage
 int launch_spmv_stream_xd(int dtype, const void *val, const void *x, void *y, size_t n_rows, void *dot_partials, const uint16_t *scode,
                           const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs, hipStream_t s, int xs,
-                          uint64_t tile_begin = 0, uint64_t tile_end = ~uint64_t(0), const void *dict = nullptr /* K1s XD-V: value dictionary */);
+                          uint64_t tile_begin = 0, uint64_t tile_end = ~uint64_t(0), const void *dict = nullptr /* K1s XD-V: value dictionary */,
+                          bool dict_high = false /* ... its indices sit in the codes' high spare bits alone */);
+bool stream_value_dict_high(int dtype, uint32_t n, int xs);
 // K1s XD-V (spmv_stream_xd.hip): the dictionary of val's distinct bit patterns (32 entries of the value type on the device; *count_out
 // = 0 when there are more), the codes' spare bits filled with the entries' dictionary indices, and how many indices those bits can name
 int stream_value_dict(int dtype, const void *val, size_t nnz, void *dict_out, uint32_t *count_out, hipStream_t s);

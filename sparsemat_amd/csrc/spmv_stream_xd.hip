@@ -64,12 +64,16 @@ template <typename T, int XS> struct XdBits {
     static constexpr uint32_t kIdx = XS == 4 ? 12u : 11u;                      // bits of an entry index inside the stage
     static constexpr uint32_t kOfsMask = ((1u << (kLow + kIdx)) - 1u) & ~((1u << kLow) - 1u);
     static constexpr uint32_t kValues = 1u << (16u - kIdx);                    // 32 / 16 dictionary entries
+    static constexpr uint32_t kHigh = 16u - (kLow + kIdx);                     // spare bits above the offset: 3 (f32, 2048-entry stage) or 2
     __device__ static __forceinline__ uint32_t ofs(uint32_t c) { return c & kOfsMask; }
     __device__ static __forceinline__ uint32_t vidx(uint32_t c) { return (c & ((1u << kLow) - 1u)) | ((c >> (kLow + kIdx)) << kLow); }
+    // dictionaries of at most 2^kHigh values (every stencil) keep the index in the HIGH bits alone: one shift instead of three operations
+    __device__ static __forceinline__ uint32_t vidx_high(uint32_t c) { return c >> (kLow + kIdx); }
 };
 
-// XS: 16-byte chunks of x per thread the tile's stage holds (2 or 4); VD: the codes carry value-dictionary indices (val is not read)
-template <typename T, bool DOT, int XS, bool VD = false>
+// XS: 16-byte chunks of x per thread the tile's stage holds (2 or 4); VD: the codes carry value-dictionary indices (val is not read) --
+// 1: in the low and the high spare bits (up to 32 / 16 values), 2: in the high ones alone (up to 8 / 4 values)
+template <typename T, bool DOT, int XS, int VD = 0>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t n_tiles,
                  T *__restrict__ dot_partials, const uint16_t *__restrict__ scode, const uint32_t *__restrict__ cwin,
@@ -206,7 +210,8 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
             const uint32_t code = (e & 1) ? (cword >> 16) : (cword & 0xFFFFu);
             if constexpr (VD) {
                 // (a slot past the tile reads code 0: stage entry 0 times dictionary entry 0 -- never added to any row)
-                p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + XdBits<T, XS>::ofs(code)), s_dict[XdBits<T, XS>::vidx(code)]);
+                const uint32_t vi = VD == 2 ? XdBits<T, XS>::vidx_high(code) : XdBits<T, XS>::vidx(code);
+                p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + XdBits<T, XS>::ofs(code)), s_dict[vi]);
             } else {
                 p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + code), v[it][e]);
             }
@@ -389,7 +394,7 @@ k_stream_odd_rows(const uint8_t *__restrict__ len8, uint64_t n, unsigned long lo
 template <typename T>
 int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, const uint16_t *scode, const uint32_t *cwin,
                 const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs, hipStream_t s, int xs, uint64_t tile_begin, uint64_t tile_end,
-                const T *dict) {
+                const T *dict, bool dict_high) {
     const uint64_t all_tiles = stream_tiles(n_rows, 1);
     const uint64_t tile0 = tile_begin < all_tiles ? tile_begin : all_tiles, tile1 = tile_end < all_tiles ? tile_end : all_tiles;
     if (tile1 <= tile0) return SMH_OK;
@@ -398,10 +403,11 @@ int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, 
 #define SMH_XD(D, P, V)                                                                                                              \
     hipLaunchKernelGGL((k_spmv_stream_xd<T, D, P, V>), grid, block, 0, s, val, x, y, (uint64_t)n_rows, n_tiles, dot_partials, scode, \
                        cwin, len8, tbase, dot_lhs, tile0, dict)
-#define SMH_XD2(P)                                                                       \
-    do {                                                                                 \
-        if (dict) { if (dot_partials) SMH_XD(true, P, true); else SMH_XD(false, P, true); } \
-        else { if (dot_partials) SMH_XD(true, P, false); else SMH_XD(false, P, false); }    \
+#define SMH_XD2(P)                                                                                  \
+    do {                                                                                            \
+        if (dict && dict_high) { if (dot_partials) SMH_XD(true, P, 2); else SMH_XD(false, P, 2); } \
+        else if (dict) { if (dot_partials) SMH_XD(true, P, 1); else SMH_XD(false, P, 1); }         \
+        else { if (dot_partials) SMH_XD(true, P, 0); else SMH_XD(false, P, 0); }                   \
     } while (0)
     if (xs == 2) SMH_XD2(2);
     else if (xs == 4) SMH_XD2(4);
@@ -417,15 +423,15 @@ int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, 
 // dict != NULL: the codes carry value-dictionary indices (K1s XD-V); val is then not read
 int launch_spmv_stream_xd(int dtype, const void *val, const void *x, void *y, size_t n_rows, void *dot_partials, const uint16_t *scode,
                           const uint32_t *cwin, const uint8_t *len8, const uint32_t *tbase, const void *dot_lhs, hipStream_t s, int xs,
-                          uint64_t tile_begin, uint64_t tile_end, const void *dict) {
+                          uint64_t tile_begin, uint64_t tile_end, const void *dict, bool dict_high) {
     if (n_rows == 0) return SMH_OK;
     if (dot_partials && !dot_lhs) dot_lhs = x;  // CG's p.Ap
     if (!dot_partials && !y) return fail(SMH_ERR_INVALID, "K1s: no output");
     if (dtype == SMH_F64)
         return launch_xd_t<double>((const double *)val, (const double *)x, (double *)y, n_rows, (double *)dot_partials, scode, cwin, len8,
-                                   tbase, (const double *)dot_lhs, s, xs, tile_begin, tile_end, (const double *)dict);
+                                   tbase, (const double *)dot_lhs, s, xs, tile_begin, tile_end, (const double *)dict, dict_high);
     return launch_xd_t<float>((const float *)val, (const float *)x, (float *)y, n_rows, (float *)dot_partials, scode, cwin, len8, tbase,
-                              (const float *)dot_lhs, s, xs, tile_begin, tile_end, (const float *)dict);
+                              (const float *)dot_lhs, s, xs, tile_begin, tile_end, (const float *)dict, dict_high);
 }
 
 // The dictionary of val's distinct bit patterns: dict_out (device, 32 entries of the value type, sorted by pattern, unused ones zero)
@@ -467,9 +473,16 @@ int stream_value_dict(int dtype, const void *val, size_t nnz, void *dict_out, ui
 }
 
 // code[k] |= index of val[k] in the dictionary (n entries), in the spare bits of a stage-offset code for a stage of xs * 1024 entries
+// do n dictionary entries fit the spare bits ABOVE the offset alone (the cheaper form for the kernel)?
+bool stream_value_dict_high(int dtype, uint32_t n, int xs) {
+    const uint32_t low = dtype == SMH_F64 ? 3u : 2u, high_shift = low + (xs == 4 ? 12u : 11u);
+    return n <= (1u << (16u - high_shift));
+}
+
 int launch_stream_value_codes(int dtype, const void *val, size_t nnz, const void *dict, uint32_t n, int xs, uint16_t *code, hipStream_t s) {
     if (nnz == 0) return SMH_OK;
-    const uint32_t low = dtype == SMH_F64 ? 3u : 2u, high_shift = low + (xs == 4 ? 12u : 11u);
+    const uint32_t high_shift = (dtype == SMH_F64 ? 3u : 2u) + (xs == 4 ? 12u : 11u);
+    const uint32_t low = stream_value_dict_high(dtype, n, xs) ? 0u : (dtype == SMH_F64 ? 3u : 2u);  // (low == 0: the whole index goes above the offset)
     uint64_t blocks = (nnz + kBlock - 1) / kBlock;
     if (blocks > 16384) blocks = 16384;
     if (dtype == SMH_F64)
