@@ -259,6 +259,195 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
     }
 }
 
+// ---- K1s XD-V on PERSISTENT workgroups ------------------------------------------------------------------------------------------
+// With the value array gone the kernel above is bound by LATENCY: a workgroup lives 2.85 us -- the two dependent memory round trips of
+// its tile (tile table -> codes and x chunks) -- at full occupancy (profiles/r04_k1s_value_dictionary.log).  Here a workgroup walks a
+// contiguous run of tiles and the NEXT tile's table entries, codes, x chunks and row lengths are on their way while the current tile is
+// multiplied and summed: the same loads, the same LDS stages, the same products and the same order of additions per row (bit-exact),
+// two barriers per tile as before; what a thread holds of a tile is the register set XdTileRegs, two of them alternate.
+template <typename T, int XS>
+struct XdTileRegs {
+    uint32_t k0, pa, my_len, xs_tot;
+    uint64_t r0, tile;
+    T dl;
+    T xr[XS][4];
+    uint32_t xpiece[XS][2];
+    xd_u2 cw[2];
+    uint32_t epos[2][2];
+};
+
+template <typename T, bool DOT, int XS, int VD>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_stream_xdp(const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, uint64_t n_tiles, T *__restrict__ dot_partials,
+                  const uint16_t *__restrict__ scode, const uint32_t *__restrict__ cwin, const uint8_t *__restrict__ len8,
+                  const uint32_t *__restrict__ tbase, const T *__restrict__ dot_lhs, uint64_t tile0, const T *__restrict__ dict) {
+    static_assert(VD == 1 || VD == 2, "the persistent form exists for the value-dictionary kernels");
+    constexpr int kXsCap = XS * kBlock * 4;
+    __shared__ T s_dict[32];
+    __shared__ __attribute__((aligned(16))) T s_xs[kXsCap];
+    __shared__ __attribute__((aligned(16))) T s_prod[kXdSlots + 8];
+    __shared__ uint32_t s_wtot[2][kBlock / kWave];  // (by tile parity: a fast wavefront stages the next tile while a slow one still sums)
+    __shared__ T s_red[kBlock / kWave];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));
+    const uint32_t wbase = tid & ~(uint32_t)(kWave - 1);
+    if (tid < 32u) s_dict[tid] = dict[tid];
+    // XCD g (= blockIdx % 8) owns a contiguous eighth of the launch's tiles, its workgroups contiguous runs of those
+    const uint64_t q8 = n_tiles >> 3, rm = n_tiles & 7, xcd = blockIdx.x & 7, wgx = gridDim.x >> 3, j_wg = blockIdx.x >> 3;
+    const uint64_t xcd_first = xcd < rm ? xcd * (q8 + 1) : rm * (q8 + 1) + (xcd - rm) * q8, xcd_count = q8 + (xcd < rm ? 1u : 0u);
+    const uint64_t per = (xcd_count + wgx - 1) / wgx;
+    const uint64_t t_begin = xcd_first + j_wg * per;
+    const uint64_t t_end = t_begin + per < xcd_first + xcd_count ? t_begin + per : xcd_first + xcd_count;
+    if (t_begin >= t_end) return;  // (whole workgroup, before any barrier)
+
+    auto load = [&](XdTileRegs<T, XS> &R, uint64_t t) {  // t: index inside the launch; everything of tile tile0 + t a thread needs, requested
+        R.tile = tile0 + t;
+        R.r0 = R.tile * (uint64_t)kStreamRows;
+        const uint32_t k0 = tbase[R.tile], k1 = tbase[R.tile + 1];
+        R.k0 = k0;
+        R.my_len = len8[R.r0 + tid];
+        R.dl = T(0);
+        if constexpr (DOT) R.dl = R.r0 + tid < n_rows ? dot_lhs[R.r0 + tid] : T(0);
+        const uint32_t *w = cwin + 8 * R.tile;
+        const uint32_t cb0 = w[0], e0 = w[1], cb1 = w[2], e1 = w[3], cb2 = w[4], e2 = w[5], cb3 = w[6], e3 = w[7];
+        const uint32_t al0 = cb0 & ~3u, al1 = cb1 & ~3u, al2 = cb2 & ~3u, al3 = cb3 & ~3u;
+        const uint32_t n0 = e0 > cb0 ? (e0 - al0 + 3u) >> 2 : 0u, n1 = e1 > cb1 ? (e1 - al1 + 3u) >> 2 : 0u;
+        const uint32_t n2 = e2 > cb2 ? (e2 - al2 + 3u) >> 2 : 0u, n3 = e3 > cb3 ? (e3 - al3 + 3u) >> 2 : 0u;
+        const uint32_t p1 = n0, p2 = p1 + n1, p3 = p2 + n2;
+        R.xs_tot = p3 + n3;
+        const uint32_t d0 = al0 >> 2, d1 = (al1 >> 2) - p1, d2 = (al2 >> 2) - p2, d3 = (al3 >> 2) - p3;
+#pragma unroll
+        for (int u = 0; u < XS; ++u) {
+            R.xr[u][0] = R.xr[u][1] = R.xr[u][2] = R.xr[u][3] = T(0);
+            if constexpr (sizeof(T) == 4) {
+                const uint32_t j = tid + (uint32_t)u * kBlock;
+                R.xpiece[u][0] = R.xpiece[u][1] = 0;
+                if (j < R.xs_tot) {
+                    uint32_t d = d0;
+                    d = j >= p1 ? d1 : d;
+                    d = j >= p2 ? d2 : d;
+                    d = j >= p3 ? d3 : d;
+                    const xd_f4 a = *reinterpret_cast<const xd_f4 *>(x + 4ull * (uint64_t)(j + d));
+                    R.xr[u][0] = a.x; R.xr[u][1] = a.y; R.xr[u][2] = a.z; R.xr[u][3] = a.w;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t pi = 2u * ((uint32_t)u * kBlock + wbase) + (uint32_t)h * kWave + lane;
+                    const uint32_t j = pi >> 1;
+                    R.xpiece[u][h] = pi;
+                    if (j < R.xs_tot) {
+                        uint32_t d = d0;
+                        d = j >= p1 ? d1 : d;
+                        d = j >= p2 ? d2 : d;
+                        d = j >= p3 ? d3 : d;
+                        const xd_d2 a = *reinterpret_cast<const xd_d2 *>(x + 4ull * (uint64_t)(j + d) + 2u * (pi & 1u));
+                        R.xr[u][2 * h] = a.x; R.xr[u][2 * h + 1] = a.y;
+                    }
+                }
+            }
+        }
+        const uint32_t pa = k0 & ~3u, hi = k1 - pa;
+        R.pa = pa;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(scode + pa), 0, (int)(((hi + 3u) & ~3u) * 2u), kXdRsrc);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if constexpr (sizeof(T) == 4) {
+                const uint32_t j = 4u * tid + (uint32_t)it * (4u * kBlock);
+                R.epos[it][0] = j; R.epos[it][1] = j;
+                R.cw[it] = __builtin_bit_cast(xd_u2, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(j * 2u), 0, 2 /* nt */));
+            } else {
+                const uint32_t e0p = 4u * ((uint32_t)it * kBlock + wbase) + 2u * lane, e1p = e0p + 2u * kWave;
+                R.epos[it][0] = e0p; R.epos[it][1] = e1p;
+                R.cw[it].x = __builtin_amdgcn_raw_buffer_load_b32(rc, (int)(e0p * 2u), 0, 2);
+                R.cw[it].y = __builtin_amdgcn_raw_buffer_load_b32(rc, (int)(e1p * 2u), 0, 2);
+            }
+        }
+    };
+    // one tile with its registers R, prefetching tile t_next into N between the two barriers
+    auto tile_body = [&](XdTileRegs<T, XS> &R, XdTileRegs<T, XS> &N, uint64_t t_next, uint32_t par) {
+        const uint32_t incl = xd_wave_scan(R.my_len);
+        if (lane == kWave - 1) s_wtot[par][wave] = incl;
+#pragma unroll
+        for (int u = 0; u < XS; ++u) {
+            if constexpr (sizeof(T) == 4) {
+                const uint32_t j = tid + (uint32_t)u * kBlock;
+                if (j < R.xs_tot) {
+                    xd_f4 a; a.x = R.xr[u][0]; a.y = R.xr[u][1]; a.z = R.xr[u][2]; a.w = R.xr[u][3];
+                    *reinterpret_cast<xd_f4 *>(&s_xs[4u * j]) = a;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if ((R.xpiece[u][h] >> 1) < R.xs_tot) {
+                        xd_d2 a; a.x = R.xr[u][2 * h]; a.y = R.xr[u][2 * h + 1];
+                        *reinterpret_cast<xd_d2 *>(&s_xs[2u * R.xpiece[u][h]]) = a;
+                    }
+            }
+        }
+        __syncthreads();
+        load(N, t_next);  // (always: no branch around the loads; the last tile is simply requested once more)
+        const char *xs_bytes = reinterpret_cast<const char *>(s_xs);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            T p[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t cword = (e >> 1) ? R.cw[it].y : R.cw[it].x;
+                const uint32_t code = (e & 1) ? (cword >> 16) : (cword & 0xFFFFu);
+                const uint32_t vi = VD == 2 ? XdBits<T, XS>::vidx_high(code) : XdBits<T, XS>::vidx(code);
+                p[e] = xd_mul(*reinterpret_cast<const T *>(xs_bytes + XdBits<T, XS>::ofs(code)), s_dict[vi]);
+            }
+            if constexpr (sizeof(T) == 4) {
+                xd_f4 a; a.x = p[0]; a.y = p[1]; a.z = p[2]; a.w = p[3];
+                *reinterpret_cast<xd_f4 *>(&s_prod[R.epos[it][0]]) = a;
+            } else {
+                xd_d2 a, b; a.x = p[0]; a.y = p[1]; b.x = p[2]; b.y = p[3];
+                *reinterpret_cast<xd_d2 *>(&s_prod[R.epos[it][0]]) = a;
+                *reinterpret_cast<xd_d2 *>(&s_prod[R.epos[it][1]]) = b;
+            }
+        }
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (int ww = 0; ww < kBlock / kWave - 1; ++ww) before += (uint32_t)ww < wave ? s_wtot[par][ww] : 0u;
+        const T *pp = s_prod + ((R.k0 - R.pa) + before + (incl - R.my_len));
+        T q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = pp[i];
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if ((uint32_t)i < R.my_len) acc = xd_add(acc, q[i]);
+        for (uint32_t i = 8; i < R.my_len; ++i) acc = xd_add(acc, pp[i]);
+        const uint64_t r = R.r0 + tid;
+        if (r < n_rows && (!DOT || y)) __builtin_nontemporal_store(acc, &y[r]);
+        if constexpr (DOT) {  // fixed order: lanes (butterfly), waves (index order) -- bitwise reproducible, as K1s
+            T d = T(0);
+            if (r < n_rows) d += R.dl * acc;
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
+            if (lane == 0) s_red[wave] = d;
+            __syncthreads();
+            if (tid == 0) {
+                T t = T(0);
+#pragma unroll
+                for (int ww = 0; ww < kBlock / kWave; ++ww) t += s_red[ww];
+                dot_partials[R.tile] = t;
+            }
+        }
+    };
+    XdTileRegs<T, XS> A, B;
+    const uint64_t t_last = t_end - 1;
+    load(A, t_begin);
+    for (uint64_t t = t_begin;;) {
+        tile_body(A, B, t + 1 < t_end ? t + 1 : t_last, 0u);
+        if (++t >= t_end) break;
+        tile_body(B, A, t + 1 < t_end ? t + 1 : t_last, 1u);
+        if (++t >= t_end) break;
+    }
+}
+
 // stage offsets: code = BYTES from the start of the tile's LDS stage of x to x[column] -- the stage holds the tile's intervals
 // back to back, each from its 4-aligned start in whole 16-byte chunks (exactly what the kernel's fill does)
 __global__ void __launch_bounds__(kBlock)
@@ -400,6 +589,44 @@ int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, 
     if (tile1 <= tile0) return SMH_OK;
     const uint64_t n_tiles = tile1 - tile0;
     const dim3 grid((unsigned)n_tiles), block(kBlock);
+    // K1s XD-V in f64 runs on persistent workgroups (k_spmv_stream_xdp), as many as the chip holds at once.  Measured on C4 (512^3,
+    // profiles/r04_k1s_xdv_persistent.log): f64 product 1.45 -> 1.15 ms, CG iteration 3.18 -> 2.99 ms; f32 product 0.73 ms either way
+    // (bound by instruction issue, not latency: 8 workgroups per CU already hide the round trips) and its dot-fused form slower
+    // (1.76 against 1.52 ms per CG iteration), so f32 keeps one workgroup per tile.  SMH_STREAM_PERSIST = 0 / 1 forces it off / on for both.
+    static const int persist_env = getenv("SMH_STREAM_PERSIST") ? atoi(getenv("SMH_STREAM_PERSIST")) : -1;  // tuning knob
+    const bool persist = persist_env < 0 ? sizeof(T) == 8 : persist_env != 0;
+    if (dict && persist && (xs == 2 || xs == 4)) {
+        static int cus_cache[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int &cus = cus_cache[dev & 63];
+        if (cus == 0) {
+            hipDeviceProp_t prop;
+            cus = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        static const int per_cu_env = getenv("SMH_STREAM_PERSIST_WGS") ? atoi(getenv("SMH_STREAM_PERSIST_WGS")) : 0;  // tuning knob
+#define SMH_XDP(D, P, V)                                                                                                           \
+    do {                                                                                                                           \
+        static int resident = 0; /* workgroups of this instantiation one CU holds */                                               \
+        if (resident == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_spmv_stream_xdp<T, D, P, V>, kBlock, 0) != hipSuccess || resident < 1)) \
+            resident = 4;                                                                                                          \
+        uint64_t wgx = (uint64_t)(cus / 8 > 0 ? cus / 8 : 1) * (uint64_t)(per_cu_env > 0 ? per_cu_env : resident); /* per XCD */   \
+        if (wgx > (n_tiles + 7) / 8) wgx = (n_tiles + 7) / 8;                                                                      \
+        if (wgx < 1) wgx = 1;                                                                                                      \
+        hipLaunchKernelGGL((k_spmv_stream_xdp<T, D, P, V>), dim3((unsigned)(8 * wgx)), block, 0, s, x, y, (uint64_t)n_rows, n_tiles, \
+                           dot_partials, scode, cwin, len8, tbase, dot_lhs, tile0, dict);                                          \
+    } while (0)
+#define SMH_XDP2(P)                                                                              \
+    do {                                                                                         \
+        if (dict_high) { if (dot_partials) SMH_XDP(true, P, 2); else SMH_XDP(false, P, 2); }    \
+        else { if (dot_partials) SMH_XDP(true, P, 1); else SMH_XDP(false, P, 1); }              \
+    } while (0)
+        if (xs == 2) SMH_XDP2(2); else SMH_XDP2(4);
+#undef SMH_XDP2
+#undef SMH_XDP
+        SMH_HIP(hipGetLastError());
+        return SMH_OK;
+    }
 #define SMH_XD(D, P, V)                                                                                                              \
     hipLaunchKernelGGL((k_spmv_stream_xd<T, D, P, V>), grid, block, 0, s, val, x, y, (uint64_t)n_rows, n_tiles, dot_partials, scode, \
                        cwin, len8, tbase, dot_lhs, tile0, dict)

@@ -384,3 +384,19 @@ def test_stream_value_dictionary_bit_exact(gpu, dtype):
     off, col, val = oracle.laplace3d(12, 12, 12, dtype)
     m = sm.SparseMatCRS.from_raw_parts(1728, 1728, off, col, val)
     assert not m.stream_direct() and len(m.stream_value_dict()) == 0
+
+
+@pytest.mark.parametrize("persist", ["0", "1"])
+def test_stream_value_dictionary_both_launch_forms(gpu, persist):
+    """K1s XD-V has two launch forms -- one workgroup per tile, and persistent workgroups that fetch the next tile while they multiply
+    (k_spmv_stream_xdp; the default for f64 only) -- chosen once per process by SMH_STREAM_PERSIST.  Both must give the oracle's bits
+    in both types: the dictionary test above and BASELINE C1's product (3907 tiles: several per persistent workgroup, a ragged last
+    one) run again in a fresh process under each setting."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(here, "test_stream_gpu.py"),
+                        os.path.join(here, "test_c1_gpu.py"), "-k", "test_stream_value_dictionary_bit_exact or test_c1_product"],
+                       env=dict(os.environ, SMH_STREAM_PERSIST=persist), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
