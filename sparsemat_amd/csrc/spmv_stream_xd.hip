@@ -81,9 +81,11 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
                  const T *__restrict__ dict = nullptr) {
     constexpr int kXsCap = XS * kBlock * 4;  // entries of x the stage holds (2048 / 4096)
     __shared__ T s_dict[VD ? 32 : 1];
-    if constexpr (VD) {
-        if (threadIdx.x < 32u) s_dict[threadIdx.x] = dict[threadIdx.x];  // (the dictionary array has 32 entries whatever its fill; read before the barrier below)
-    }
+    // (the dictionary array has 32 entries whatever its fill.  Requested by EVERY thread, without a branch, and put into the LDS only with
+    // the stage of x below: inside `if (tid < 32)` the compiler waits for the load on the spot -- a whole memory round trip for the first
+    // wavefront before it has requested anything else, and the workgroup's barrier waits for that wavefront.)
+    T dict_v = T(0);
+    if constexpr (VD) dict_v = dict[threadIdx.x & 31u];
     __shared__ __attribute__((aligned(16))) T s_xs[kXsCap];
     __shared__ __attribute__((aligned(16))) T s_prod[kXdSlots + 8];  // (+8: a row's eight unconditional reads may pass the tile's end)
     __shared__ uint32_t s_wtot[kBlock / kWave];
@@ -197,6 +199,9 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
                     *reinterpret_cast<xd_d2 *>(&s_xs[2u * xpiece[u][h]]) = a;
                 }
         }
+    }
+    if constexpr (VD) {
+        if (tid < 32u) s_dict[tid] = dict_v;
     }
     __syncthreads();
     // ---- products: x from the stage by byte offset, four products per 16-byte store at the chunk's own position ----
