@@ -35,6 +35,27 @@ inline size_t dtype_size(int dt) { return dt == SMH_F64 ? 8 : 4; }
 
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kBlock = 256;         // 4 waves: one per SIMD
+// The sum of a value over the wavefront by DPP (row_shr 1, 2, 4, 8, row_bcast 15, 31: an inclusive scan; lane 63 ends with the total)
+// -- six vector instructions in a fixed order, where the __shfl_down butterfly is a chain of six ds_bpermute round trips through
+// the LDS at the very end of a workgroup's life.  Lanes without a source add +0.
+template <int CTRL, int ROWS> __device__ __forceinline__ float wave_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false));
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ double wave_dpp_add(double v) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWS, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)b >> 32), CTRL, ROWS, 0xF, false);
+    return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <typename T> __device__ __forceinline__ T wave_sum_to_lane63(T v) {
+    v = wave_dpp_add<0x111, 0xF>(v);
+    v = wave_dpp_add<0x112, 0xF>(v);
+    v = wave_dpp_add<0x114, 0xF>(v);
+    v = wave_dpp_add<0x118, 0xF>(v);
+    v = wave_dpp_add<0x142, 0xA>(v);
+    v = wave_dpp_add<0x143, 0xC>(v);
+    return v;
+}
 constexpr int kMergeItemsPerThread = 8;
 constexpr int kMergeTile = kBlock * kMergeItemsPerThread;  // merge items (rows + nnz) per tile
 constexpr int kReducePartials = 1024;  // blocks of a stage-1 reduction

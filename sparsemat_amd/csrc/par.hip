@@ -187,7 +187,7 @@ struct smh_par {
     smh_par_vec *cg_p = nullptr;    // the search direction of the solver (full-length per block)
     smh_par_vec *io_b = nullptr, *io_x = nullptr;  // staging of the host-vector solve
     ParPool *pool = nullptr;        // issuing threads (lazy; blocks 1 .. n_local - 1)
-    int use_threads = -1;           // -1 automatic (on with more than one local block; SMH_PAR_THREADS=0 switches it off), 0 never, 1 always
+    int use_threads = -1;           // -1 automatic (= off unless SMH_PAR_THREADS=1: threads_wanted() says why), 0 never, 1 always
 };
 
 struct smh_par_vec {

@@ -468,9 +468,8 @@ k_spmv_stream(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
             const uint64_t r = r0 + (uint64_t)rr * kBlock + tid;
             if (r < r1) d += dl[rr] * sum[rr];
         }
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
-        if ((tid & (kWave - 1)) == 0) s_red[tid / kWave] = d;
+        d = wave_sum_to_lane63(d);  // (lanes by the DPP scan network, then the wavefronts in index order; K1s XD adds in the same order)
+        if ((tid & (kWave - 1)) == kWave - 1) s_red[tid / kWave] = d;
         __syncthreads();
         if (tid == 0) {
             T t = T(0);

@@ -247,13 +247,12 @@ k_spmv_stream_xd(const T *__restrict__ val, const T *__restrict__ x, T *__restri
     for (uint32_t i = 8; i < my_len; ++i) acc = xd_add(acc, pp[i]);
     const uint64_t r = r0 + tid;
     if (r < n_rows && (!DOT || y)) __builtin_nontemporal_store(acc, &y[r]);  // (DOT with y == NULL: only lhs . (A x) is wanted)
-    if constexpr (DOT) {  // fixed order: lanes (butterfly), waves (index order) -- bitwise reproducible, as K1s
+    if constexpr (DOT) {  // fixed order: lanes (DPP scan network), waves (index order) -- bitwise reproducible, as K1s
         __shared__ T s_red[kBlock / kWave];
         T d = T(0);
         if (r < n_rows) d += dl * acc;  // (as K1s: 0 + the product)
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
-        if (lane == 0) s_red[wave] = d;
+        d = wave_sum_to_lane63(d);
+        if (lane == kWave - 1) s_red[wave] = d;
         __syncthreads();
         if (tid == 0) {
             T t = T(0);
@@ -427,12 +426,11 @@ k_spmv_stream_xdp(const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, u
         for (uint32_t i = 8; i < R.my_len; ++i) acc = xd_add(acc, pp[i]);
         const uint64_t r = R.r0 + tid;
         if (r < n_rows && (!DOT || y)) __builtin_nontemporal_store(acc, &y[r]);
-        if constexpr (DOT) {  // fixed order: lanes (butterfly), waves (index order) -- bitwise reproducible, as K1s
+        if constexpr (DOT) {  // fixed order: lanes (DPP scan network), waves (index order) -- bitwise reproducible, as K1s
             T d = T(0);
             if (r < n_rows) d += R.dl * acc;
-#pragma unroll
-            for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o, kWave);
-            if (lane == 0) s_red[wave] = d;
+            d = wave_sum_to_lane63(d);
+            if (lane == kWave - 1) s_red[wave] = d;
             __syncthreads();
             if (tid == 0) {
                 T t = T(0);
