@@ -291,7 +291,7 @@ k_spmv_stream_xdp(const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, u
     __shared__ __attribute__((aligned(16))) T s_xs[kXsCap];
     __shared__ __attribute__((aligned(16))) T s_prod[kXdSlots + 8];
     __shared__ uint32_t s_wtot[2][kBlock / kWave];  // (by tile parity: a fast wavefront stages the next tile while a slow one still sums)
-    __shared__ T s_red[kBlock / kWave];
+    __shared__ T s_red[2][kBlock / kWave];          // (by tile parity too: folded one barrier later, see fold_dot)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));
     const uint32_t wbase = tid & ~(uint32_t)(kWave - 1);
@@ -368,8 +368,19 @@ k_spmv_stream_xdp(const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, u
             }
         }
     };
+    // the wavefronts' shares of a tile's dot, folded in index order (as the per-tile kernel does) -- by thread 0 AFTER the next barrier the
+    // workgroup passes anyway (the first one of the following tile; a closing one after the last): a barrier of its own per tile, with
+    // one thread folding behind it while 255 wait at the next, cost the f32 solver 0.25 ms per iteration
+    auto fold_dot = [&](uint32_t par, uint64_t tile) {
+        if (tid == 0) {
+            T t = T(0);
+#pragma unroll
+            for (int ww = 0; ww < kBlock / kWave; ++ww) t += s_red[par][ww];
+            dot_partials[tile] = t;
+        }
+    };
     // one tile with its registers R, prefetching tile t_next into N between the two barriers
-    auto tile_body = [&](XdTileRegs<T, XS> &R, XdTileRegs<T, XS> &N, uint64_t t_next, uint32_t par) {
+    auto tile_body = [&](XdTileRegs<T, XS> &R, XdTileRegs<T, XS> &N, uint64_t t_next, uint32_t par, bool first) {
         const uint32_t incl = xd_wave_scan(R.my_len);
         if (lane == kWave - 1) s_wtot[par][wave] = incl;
 #pragma unroll
@@ -390,6 +401,9 @@ k_spmv_stream_xdp(const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, u
             }
         }
         __syncthreads();
+        if constexpr (DOT) {
+            if (!first) fold_dot(par ^ 1u, R.tile - 1);  // (a workgroup's tiles are consecutive)
+        }
         load(N, t_next);  // (always: no branch around the loads; the last tile is simply requested once more)
         const char *xs_bytes = reinterpret_cast<const char *>(s_xs);
 #pragma unroll
@@ -430,24 +444,24 @@ k_spmv_stream_xdp(const T *__restrict__ x, T *__restrict__ y, uint64_t n_rows, u
             T d = T(0);
             if (r < n_rows) d += R.dl * acc;
             d = wave_sum_to_lane63(d);
-            if (lane == kWave - 1) s_red[wave] = d;
-            __syncthreads();
-            if (tid == 0) {
-                T t = T(0);
-#pragma unroll
-                for (int ww = 0; ww < kBlock / kWave; ++ww) t += s_red[ww];
-                dot_partials[R.tile] = t;
-            }
+            if (lane == kWave - 1) s_red[par][wave] = d;
         }
     };
     XdTileRegs<T, XS> A, B;
     const uint64_t t_last = t_end - 1;
     load(A, t_begin);
+    uint32_t last_par = 0;
     for (uint64_t t = t_begin;;) {
-        tile_body(A, B, t + 1 < t_end ? t + 1 : t_last, 0u);
+        tile_body(A, B, t + 1 < t_end ? t + 1 : t_last, 0u, t == t_begin);
+        last_par = 0;
         if (++t >= t_end) break;
-        tile_body(B, A, t + 1 < t_end ? t + 1 : t_last, 1u);
+        tile_body(B, A, t + 1 < t_end ? t + 1 : t_last, 1u, false);
+        last_par = 1;
         if (++t >= t_end) break;
+    }
+    if constexpr (DOT) {
+        __syncthreads();
+        fold_dot(last_par, tile0 + t_last);
     }
 }
 
@@ -583,6 +597,21 @@ k_stream_odd_rows(const uint8_t *__restrict__ len8, uint64_t n, unsigned long lo
     if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(out, (unsigned long long)c);  // integer count: exact, order independent
 }
 
+// workgroups of k_spmv_stream_xdp<T, DOT, XS, VD> a CU holds.  Both DOT forms are asked about at the first launch of either: the dot-fused
+// one is first launched inside the solver's stream capture, where the runtime refuses the query (the fallback of 4 then halved f32's
+// grid: 1.74 against 1.45 ms per CG iteration until this was found); a refused query is not remembered.
+template <typename T, int XS, int VD> int xdp_resident(bool dot) {
+    static int res[2] = {0, 0};
+    if (res[0] == 0 || res[1] == 0) {
+        int a = 0, b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_spmv_stream_xdp<T, false, XS, VD>, kBlock, 0) == hipSuccess && a > 0) res[0] = a;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_spmv_stream_xdp<T, true, XS, VD>, kBlock, 0) == hipSuccess && b > 0) res[1] = b;
+        (void)hipGetLastError();
+    }
+    const int r = res[dot ? 1 : 0];
+    return r > 0 ? r : (sizeof(T) == 8 ? 4 : 8);
+}
+
 template <typename T>
 int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, const uint16_t *scode, const uint32_t *cwin,
                 const uint8_t *len8, const uint32_t *tbase, const T *dot_lhs, hipStream_t s, int xs, uint64_t tile_begin, uint64_t tile_end,
@@ -610,9 +639,7 @@ int launch_xd_t(const T *val, const T *x, T *y, size_t n_rows, T *dot_partials, 
         static const int per_cu_env = getenv("SMH_STREAM_PERSIST_WGS") ? atoi(getenv("SMH_STREAM_PERSIST_WGS")) : 0;  // tuning knob
 #define SMH_XDP(D, P, V)                                                                                                           \
     do {                                                                                                                           \
-        static int resident = 0; /* workgroups of this instantiation one CU holds */                                               \
-        if (resident == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_spmv_stream_xdp<T, D, P, V>, kBlock, 0) != hipSuccess || resident < 1)) \
-            resident = 4;                                                                                                          \
+        const int resident = xdp_resident<T, P, V>(D); /* workgroups of this instantiation one CU holds */                         \
         uint64_t wgx = (uint64_t)(cus / 8 > 0 ? cus / 8 : 1) * (uint64_t)(per_cu_env > 0 ? per_cu_env : resident); /* per XCD */   \
         if (wgx > (n_tiles + 7) / 8) wgx = (n_tiles + 7) / 8;                                                                      \
         if (wgx < 1) wgx = 1;                                                                                                      \
