@@ -488,7 +488,7 @@ def extra_configs(args, lib, check, sm, synth, np, stream, sync):
         "workload": "ConjugateGradient::solve, 7-point Laplacian %d^3 f32, b = A.1, x0 = 0, device-resident, %d iterations per solve (BASELINE configs[3])" % (g, iters),
         "dtype": "f32", "kernel": "hipGraph per iteration: %s SpMV with the p.Ap partials in its epilogue + k_sum_stage1 + k_cg_par_update (alpha; r, r.r) + k_cg_par_p (beta, stop test; x, p)" % variant4,
         "ms_per_iteration": it_ms, "ms_per_iteration_min": per_it[0], "ms_per_iteration_max": per_it[-1], "solves": len(per_it), "iterations_per_solve": cg.iterations,
-        "timing": "host wall clock around smh_cg_solve_vec (device-synchronised on both sides) / iterations, median of 3 solves; per-kernel times: profiles/r04_cg_kernel_stats.csv",
+        "timing": "host wall clock around smh_cg_solve_vec (device-synchronised on both sides) / iterations, median of 3 solves; per-kernel times at this size: profiles/r04_cg_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/cg_bench.py)",
         "algorithmic_bytes": b_cg, "algorithmic_bytes_reference_op_sequence": b4 + 12 * n4 * 4,
         "roofline": {"bound": "hbm", "achieved": b_cg / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": b_cg / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
