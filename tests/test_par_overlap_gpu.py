@@ -180,3 +180,38 @@ def test_k1s_xd_blocks_launched_by_runs_of_rows(gpu, dtype):
     b, xs = m.vec(host=b_host), m.vec()
     again = (m.cg_solve_vec(b, xs, tol=1e-6 if dtype == np.float32 else 1e-10, iter_max=60, check_every=3), xs.download())
     assert again[0] == res[True][0] and again[1].tobytes() == res[True][1].tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_value_dictionary_blocks_of_many_tiles_by_runs_of_rows(gpu, dtype):
+    """BASELINE C1's matrix (5-point Laplacian 1000 x 1000: two distinct values -> K1s XD-V) cut into three ragged blocks of ~1300 tiles:
+    in f64 the kernel runs on persistent workgroups that walk SEVERAL tiles each, here over the runs of rows the overlapped product
+    launches separately (boundary tiles, interior tiles: tile ranges that do not start at 0).  Same bits as the oracle with the overlap
+    on and off, the solver's iterates identical either way."""
+    g, n_blocks = 1000, 3
+    off, col, val = oracle.laplace2d(g, g, dtype)
+    n = g * g
+    cuts = [0, 333_411, 667_003, n]
+    blocks = []
+    for b in range(n_blocks):
+        r0, r1 = cuts[b], cuts[b + 1]
+        k0, k1 = int(off[r0]), int(off[r1])
+        blk = sm.SparseMatCRS.from_raw_parts(r1 - r0, n, (off[r0:r1 + 1] - off[r0]).astype(np.uint32), col[k0:k1], val[k0:k1])
+        blk.set_stream_xs(1)
+        assert blk.stream_direct() and len(blk.stream_value_dict()) == 2
+        blocks.append(blk)
+    m = sm.SparseMatParLocal.adopt(blocks, n, split_rows=cuts)
+    rng = np.random.default_rng(18)
+    x_host = rng.uniform(-1, 1, n).astype(dtype)
+    want = oracle.spmv(off, col, val, x_host)
+    b_host = oracle.spmv(off, col, val, np.ones(n, dtype))
+    res = {}
+    for on in (True, False):
+        m.set_overlap(on)
+        x, y = m.vec(host=x_host), m.vec()
+        m.mvp_dev(x, y, variant="stream", exchange="window")
+        m.synchronize()
+        assert y.download().tobytes() == want.tobytes(), on
+        b, xs = m.vec(host=b_host), m.vec()
+        res[on] = (m.cg_solve_vec(b, xs, tol=1e-30, iter_max=12, check_every=4), xs.download())
+    assert res[True][0] == res[False][0] and res[True][1].tobytes() == res[False][1].tobytes()
