@@ -1352,8 +1352,10 @@ int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int varia
         }));
         return exchange(p, y, mode);
     }
-    // the rows other blocks reference first, then the exchange on the side streams while the interior rows are multiplied; every
-    // block's calls from its own issuing thread, the phases meeting where a wait names another block's event (see ParPool)
+    // the rows other blocks reference and their exchange on the side streams, the interior rows on the main ones -- BOTH from the start:
+    // the boundary rows are one or two launches of a few workgroups (13 us each on an otherwise idle chip: 27 us of a 355 us step when
+    // they ran ahead of everything, profiles/r04_par_boundary_on_side_stream.log); every block's calls from its own issuing thread, the
+    // phases meeting where a wait names another block's event (see ParPool)
     const size_t nl = p->b.size();
     std::vector<size_t> ia(nl, 0), ie(nl, 0);
     std::vector<uint8_t> pulled(nl * nl, 0);
@@ -1370,12 +1372,13 @@ int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int varia
         SMH_TRY(interior_for(blk, variant, &ia[k], &ie[k]));
         char *yk = (char *)y->d[k] + blk.r0 * vs;
         if (ie[k] > ia[k]) {
-            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.s, 0, ia[k]));
-            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.s, ie[k], blk.r1 - blk.r0));
+            SMH_TRY(fork_one(blk));  // (the side stream after everything the main one holds: x is written, y's readers are through)
+            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.sx, 0, ia[k]));
+            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.sx, ie[k], blk.r1 - blk.r0));
         } else {
             SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, yk, variant, blk.s));
+            SMH_TRY(fork_one(blk));
         }
-        SMH_TRY(fork_one(blk));
         return peer ? peer_mark(p, k, true) : SMH_OK;
     }));
     if (!peer) {
@@ -1511,7 +1514,8 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
         const bool lone = lone_block_skips(p);
         const size_t nl = p->b.size();
         std::vector<uint8_t> pulled(nl * nl, 0);
-        // the product of block k's rows [part 0: its interior | part 1: the rest, or all of them] and, after part 1, its p.Ap
+        // the product of block k's rows [part 0: its interior, on the main stream | part 1: the rest -- on the SIDE stream, behind the
+        // exchange they wait for and beside the interior rows -- or, unsplit, all of them | part 2, after the join: the block's p.Ap]
         auto products = [&](size_t k, int part, bool side) -> int {
             ParBlock &blk = p->b[k];
             SMH_TRY(use(blk));
@@ -1527,13 +1531,14 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
             void *dotp = fused ? blk.d_dotp : nullptr;
             const void *lhs = fused ? (const char *)pv->d[k] + blk.r0 * vs : nullptr;
             if (part == 0) return spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ia, ie, dotp, lhs);
-            if (split) {
-                SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, 0, ia, dotp, lhs));
-                SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ie, n_loc, dotp, lhs));
-            } else if (fused) {
-                SMH_TRY(spmv_enqueue(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, blk.d_dotp, lhs));
-            } else {
-                SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));
+            if (part == 1 && split) {
+                SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.sx, 0, ia, dotp, lhs));
+                return spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.sx, ie, n_loc, dotp, lhs);
+            }
+            if (part == 1) return SMH_OK;  // (unsplit: everything in part 2, after the exchange has been joined)
+            if (!split) {
+                if (fused) SMH_TRY(spmv_enqueue(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, blk.d_dotp, lhs));
+                else SMH_TRY(smh_crs_spmv_dev(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s));
             }
             if (fused) return launch_fold2(dt, blk.d_dotp, n_dot, blk.d_partials, red_mine(p, blk, 0), blk.s);
             return launch_dot(dt, (const char *)pv->d[k] + blk.r0 * vs, blk.d_ap, n_loc, blk.d_partials, red_mine(p, blk, 0), blk.s);
@@ -1566,9 +1571,10 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
                     return side ? products(k, 0, side) : SMH_OK;
                 }));
                 SMH_TRY(par_for(p, [&](size_t k) -> int {
+                    if (side) SMH_TRY(products(k, 1, side));  // (behind this block's pulls on its side stream)
                     if (xchg) SMH_TRY(peer_guard(p, k, side, pulled.data()));
                     if (side) SMH_TRY(join_one(p->b[k]));
-                    SMH_TRY(products(k, 1, side));
+                    SMH_TRY(products(k, 2, side));
                     return lone ? SMH_OK : red_mark(p, k, 0);
                 }));
                 if (!lone) SMH_TRY(red_hub(p, 0));
@@ -1587,10 +1593,13 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
             if (side) SMH_TRY(fork_side(p));
             SMH_TRY(exchange(p, pv, mode, side));
             if (side) {
-                SMH_TRY(par_for(p, [&](size_t k) { return products(k, 0, side); }));
+                SMH_TRY(par_for(p, [&](size_t k) -> int {
+                    SMH_TRY(products(k, 1, side));
+                    return products(k, 0, side);
+                }));
                 SMH_TRY(join_side(p));
             }
-            SMH_TRY(par_for(p, [&](size_t k) { return products(k, 1, side); }));
+            SMH_TRY(par_for(p, [&](size_t k) { return products(k, 2, side); }));
             SMH_TRY(combine(p, 0));
             SMH_TRY(par_for(p, update_xr));
             SMH_TRY(combine(p, 1));
