@@ -571,7 +571,7 @@ def run_rccl_probe(n_gpus, rows, pattern_name):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_gpus), "--rows", str(rows), "--steps", "2", "--warmup", "1",
            "--exchange", "allgather", "--pattern", pattern_name, "--rccl-probe"]
     try:
-        r = subprocess.run(cmd, cwd=ROOT, env=dict(env, SMH_BENCH_SPAWN_TIMEOUT_S="150"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=200)
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(env, SMH_BENCH_SPAWN_TIMEOUT_S="75"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=100)
         lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": "probe exit status %d, %d line(s)" % (r.returncode, len(lines))}
@@ -1092,7 +1092,7 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     elif probe_wanted and rdzv_path:
-        deadline = time.time() + 260
+        deadline = time.time() + 130  # (the probe is bounded to 100 s)
         while time.time() < deadline and not os.path.exists(rdzv_path + ".probe_done"):
             time.sleep(0.05)
     if comm is not None:
