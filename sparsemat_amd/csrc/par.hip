@@ -1373,8 +1373,8 @@ int smh_par_spmv_dev(smh_par *p, const smh_par_vec *x, smh_par_vec *y, int varia
         char *yk = (char *)y->d[k] + blk.r0 * vs;
         if (ie[k] > ia[k]) {
             SMH_TRY(fork_one(blk));  // (the side stream after everything the main one holds: x is written, y's readers are through)
-            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.sx, 0, ia[k]));
-            SMH_TRY(spmv_enqueue_rows(blk.m, x->d[k], x->n, yk, variant, blk.sx, ie[k], blk.r1 - blk.r0));
+            SMH_TRY(spmv_enqueue_rows_short(blk.m, x->d[k], x->n, yk, variant, blk.sx, 0, ia[k]));
+            SMH_TRY(spmv_enqueue_rows_short(blk.m, x->d[k], x->n, yk, variant, blk.sx, ie[k], blk.r1 - blk.r0));
         } else {
             SMH_TRY(smh_crs_spmv_dev(blk.m, x->d[k], x->n, yk, variant, blk.s));
             SMH_TRY(fork_one(blk));
@@ -1532,6 +1532,10 @@ int smh_par_cg_solve_vec(smh_par *p, const smh_par_vec *b, smh_par_vec *x, doubl
             const void *lhs = fused ? (const char *)pv->d[k] + blk.r0 * vs : nullptr;
             if (part == 0) return spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.s, ia, ie, dotp, lhs);
             if (part == 1 && split) {
+                if (!dotp) {
+                    SMH_TRY(spmv_enqueue_rows_short(blk.m, pv->d[k], n, blk.d_ap, variant, blk.sx, 0, ia));
+                    return spmv_enqueue_rows_short(blk.m, pv->d[k], n, blk.d_ap, variant, blk.sx, ie, n_loc);
+                }
                 SMH_TRY(spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.sx, 0, ia, dotp, lhs));
                 return spmv_enqueue_rows(blk.m, pv->d[k], n, blk.d_ap, variant, blk.sx, ie, n_loc, dotp, lhs);
             }
