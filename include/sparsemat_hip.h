@@ -502,9 +502,11 @@ int smh_par_backend(const smh_par *p);
  * reference's design are independent (sparsemat_par.rs:54-64: every block multiplies on its own, results at b R), so the order
  * in which a block's rows are multiplied is free of semantics.  When the exchange of a call is a WINDOW and the block's kernel
  * can be launched by runs of rows (K1s: 256-row tiles, K1r: the plan's row ranges -- same kernels, same arithmetic per row, so
- * results are bit-identical either way), smh_par_spmv_dev multiplies the rows other blocks reference first, starts the exchange
- * on a second stream per block and multiplies the block's INTERIOR rows meanwhile; smh_par_cg_solve_vec starts the exchange of p,
- * multiplies the interior rows (which reference no other block's entries) meanwhile and the rest after it.  smh_par_interior:
+ * results are bit-identical either way), smh_par_spmv_dev multiplies the rows other blocks reference on a second stream per
+ * block, the exchange behind them, and the block's INTERIOR rows on its main stream meanwhile; smh_par_cg_solve_vec starts the
+ * exchange of p on the second stream and behind it the rows that wait for it, and multiplies the interior rows (which reference no
+ * other block's entries) on the main stream meanwhile.  (f32 ring matrices: the few boundary rows go through the plain lane-group
+ * kernel, whose results are the ring kernel's bit for bit.)  smh_par_interior:
  * the rows [*row_begin, *row_end) (local) of local block i that its kernel for `variant` treats as interior (equal: none -- the
  * call is then not split for that block). */
 int smh_par_set_overlap(smh_par *p, int on);
