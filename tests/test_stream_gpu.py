@@ -397,6 +397,45 @@ def test_stream_value_dictionary_both_launch_forms(gpu, persist):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(here, "test_stream_gpu.py"),
-                        os.path.join(here, "test_c1_gpu.py"), "-k", "test_stream_value_dictionary_bit_exact or test_c1_product"],
+                        os.path.join(here, "test_c1_gpu.py"), "-k", "test_stream_value_dictionary_bit_exact or test_stream_value_dictionary_rows_beyond_eight_entries or test_c1_product"],
                        env=dict(os.environ, SMH_STREAM_PERSIST=persist), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_stream_value_dictionary_rows_beyond_eight_entries(gpu, dtype):
+    """K1s XD folds a row's first eight products from registers and the rest in a loop: a 5-point Laplacian in which every 97th row
+    carries 6 or 8 more entries (11 / 13 in all; duplicates of its own columns, values from the matrix's small set), so that the loop
+    runs in the dictionary kernels of both launch forms (f32: a workgroup per tile, f64: persistent workgroups) -- bit for bit the
+    oracle, with and without the dictionary, the dot epilogue too."""
+    nx, ny = 1000, 60
+    off, col, val = oracle.laplace2d(nx, ny, dtype)
+    n = nx * ny
+    rng = np.random.default_rng(97)
+    lens = np.diff(off).astype(np.int64)
+    extra = np.zeros(n, np.int64)
+    extra[::97] = np.where(np.arange(0, n, 97) % 2 == 0, 6, 8)
+    new_off = np.zeros(n + 1, np.uint32)
+    np.cumsum(lens + extra, out=new_off[1:])
+    new_col = np.empty(int(new_off[-1]), np.uint32)
+    new_val = np.empty(int(new_off[-1]), dtype)
+    pool = np.array([4.0, -1.0, 0.5], dtype)
+    for i in range(n):
+        a, b = int(off[i]), int(off[i + 1])
+        o = int(new_off[i])
+        new_col[o:o + b - a] = col[a:b]
+        new_val[o:o + b - a] = val[a:b]
+        e = int(extra[i])
+        if e:
+            new_col[o + b - a:o + b - a + e] = col[a:b][rng.integers(0, b - a, e)]
+            new_val[o + b - a:o + b - a + e] = pool[rng.integers(0, 3, e)]
+    m = sm.SparseMatCRS.from_raw_parts(n, n, new_off, new_col, new_val)
+    m.set_stream_xs(1)
+    m.set_stream_direct(1)
+    assert m.stream_direct() and len(m.stream_value_dict()) == 3 and m.max_row_len() == 13
+    x, lhs = rng.uniform(-1, 1, n).astype(dtype), rng.uniform(-1, 1, n).astype(dtype)
+    want = oracle.spmv(new_off, new_col, new_val, x)
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(want))
+    ip = m.inner_prod(lhs, x, variant="stream")
+    m.set_stream_value_dict(0)
+    assert np.array_equal(bits(m.mvp(x, variant="stream")), bits(want)) and m.inner_prod(lhs, x, variant="stream") == ip
