@@ -267,6 +267,13 @@ def test_k1_is_k1r_bit_for_bit_in_f32(gpu):
     centers = np.repeat(np.arange(n_rows), lens)
     col = np.clip(centers + rng.integers(-3000, 3000, len(centers)), 0, n_rows - 1).astype(np.uint32)
     cases.append(sm.SparseMatCRS.from_raw_parts(n_rows, n_rows, off, col, rng.uniform(-1, 1, len(col)).astype(np.float32)))
+    # a stencil (the banded ring: four bands) and rows of 64 entries in a +-8000 band (the wide ring)
+    off, col, val = oracle.laplace3d(48, 40, 36, np.float32)
+    cases.append(sm.SparseMatCRS.from_raw_parts(48 * 40 * 36, 48 * 40 * 36, off, col, val))
+    n_rows = 120_000
+    off = (np.arange(n_rows + 1, dtype=np.uint64) * 64).astype(np.uint32)
+    col = np.clip(np.repeat(np.arange(n_rows), 64) + rng.integers(-8000, 8000, n_rows * 64), 0, n_rows - 1).astype(np.uint32)
+    cases.append(sm.SparseMatCRS.from_raw_parts(n_rows, n_rows, off, col, rng.uniform(-1, 1, len(col)).astype(np.float32)))
     for m in cases:
         x = rng.uniform(-1, 1, m.n_cols()).astype(np.float32)
         for lanes in (0, 4, 8, 16):
