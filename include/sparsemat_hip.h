@@ -505,7 +505,7 @@ int smh_par_backend(const smh_par *p);
  * results are bit-identical either way), smh_par_spmv_dev multiplies the rows other blocks reference on a second stream per
  * block, the exchange behind them, and the block's INTERIOR rows on its main stream meanwhile; smh_par_cg_solve_vec starts the
  * exchange of p on the second stream and behind it the rows that wait for it, and multiplies the interior rows (which reference no
- * other block's entries) on the main stream meanwhile.  (f32 ring matrices: the few boundary rows go through the plain lane-group
+ * other block's entries) on the main stream meanwhile.  (Ring matrices: the few boundary rows go through the plain lane-group
  * kernel, whose results are the ring kernel's bit for bit.)  smh_par_interior:
  * the rows [*row_begin, *row_end) (local) of local block i that its kernel for `variant` treats as interior (equal: none -- the
  * call is then not split for that block). */

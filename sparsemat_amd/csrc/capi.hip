@@ -908,21 +908,22 @@ int spmv_enqueue_rows(smh_crs *m, const void *x, size_t x_len, void *y, int vari
 
 // The same for a SHORT run of rows (a partition block's boundary rows: a few thousand), any row0 / row1.  One ring workgroup walks its
 // ~6500 rows in ~100 us whatever else the chip does -- the ring kernel gets its rate from 512 of them at once -- so two boundary
-// launches were 200 us of a rank's 340 us step (profiles/r04_par_boundary_rows_k1.log).  In f32 the plain lane-group kernel K1 (same
-// lanes, same chunk grid, same order of FMAs; x through L1 / L2 instead of the LDS ring) gives the ring kernel's bits
-// (tests/test_ring_gpu.py::test_k1_is_k1r_bit_for_bit_in_f32, and every overlap-on / overlap-off comparison of the partition tests),
-// and a short run is a hundred small workgroups: microseconds.  Everything else goes the way of spmv_enqueue_rows.
+// launches were 200 us of a rank's 340 us step (profiles/r04_par_boundary_rows_k1.log).  The plain lane-group kernel K1 (same lanes,
+// same chunk grid and lane layout, same order of FMAs; x through L1 / L2 instead of the LDS ring) gives the ring kernel's bits in
+// both value types (tests/test_ring_gpu.py::test_k1_is_k1r_bit_for_bit, and every overlap-on / overlap-off comparison of the
+// partition tests), and a short run is a hundred small workgroups: microseconds.  Everything else goes the way of spmv_enqueue_rows.
 int spmv_enqueue_rows_short(smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, size_t row0, size_t row1) {
     static const bool off = getenv("SMH_PAR_BOUNDARY_K1") && atoi(getenv("SMH_PAR_BOUNDARY_K1")) == 0;  // tuning knob
     if (row1 > m->n_rows) row1 = m->n_rows;
     if (row0 >= row1) return SMH_OK;
-    if (!off && m->dtype == SMH_F32 && resolve_variant(m, variant) == SMH_SPMV_VECTOR && auto_lanes(m) >= 4 && row1 - row0 <= (size_t)1 << 20) {
+    if (!off && resolve_variant(m, variant) == SMH_SPMV_VECTOR && auto_lanes(m) >= 4 && row1 - row0 <= (size_t)1 << 20) {
         bool ring = false;
         SMH_TRY(vector_uses_ring(m, &ring));
         if (ring) {
             if (m->nnz > 0 && (size_t)m->max_col >= x_len)
                 return fail(SMH_ERR_INDEX_RANGE, "index out of bounds: the len is %zu but the index is %u", x_len, m->max_col);
-            return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off + row0, m->d_col, m->d_val, x, (float *)y + row0, row1 - row0, m->nnz, s);
+            return launch_spmv_vector(m->dtype, auto_lanes(m), m->d_off + row0, m->d_col, m->d_val, x, (char *)y + row0 * dtype_size(m->dtype), row1 - row0,
+                                      m->nnz, s);
         }
     }
     return spmv_enqueue_rows(m, x, x_len, y, variant, s, row0, row1, nullptr, nullptr);

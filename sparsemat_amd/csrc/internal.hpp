@@ -202,7 +202,7 @@ int spmv_enqueue(::smh_crs *m, const void *x, size_t x_len, void *y, int variant
 int spmv_rows_granularity(::smh_crs *m, int variant, size_t *gran_out);
 int spmv_enqueue_rows(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, size_t row0, size_t row1,
                       void *dot_partials = nullptr, const void *dot_lhs = nullptr);
-// ... of a SHORT run (a block's boundary rows), any row0 / row1: f32 ring matrices through the plain lane-group kernel (same bits)
+// ... of a SHORT run (a block's boundary rows), any row0 / row1: ring matrices through the plain lane-group kernel (same bits)
 int spmv_enqueue_rows_short(::smh_crs *m, const void *x, size_t x_len, void *y, int variant, hipStream_t s, size_t row0, size_t row1);
 // BLAS-1 (a_dev: scalar read from device memory when non-null, else `a`)
 enum class Ew { Add, Sub, Scale, Axpy, Xpby, RSubInto };

@@ -56,6 +56,23 @@ __device__ __forceinline__ void load_chunk(const uint32_t *__restrict__ col, con
     }
 }
 
+// Two consecutive entries starting at the EVEN element k (f64's 16-byte piece); past the arrays' end entry by entry.
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void load_pair(const uint32_t *__restrict__ col, const T *__restrict__ val, uint64_t k, uint64_t nnz,
+                                          uint32_t &c0, uint32_t &c1, T &v0, T &v1) {
+    static_assert(sizeof(T) == 8, "the two-entry piece is f64's");
+    if (k + 2 <= nnz) {
+        const u32x2v cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2v *>(col + k));
+        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + k));
+        c0 = cc.x; c1 = cc.y; v0 = a.x; v1 = a.y;
+    } else {
+        const bool in0 = k < nnz;
+        c0 = in0 ? col[k] : 0u; v0 = in0 ? val[k] : T(0);
+        c1 = 0u; v1 = T(0);
+    }
+}
+
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
@@ -92,14 +109,32 @@ k_spmv_vector(const uint32_t *__restrict__ off, const uint32_t *__restrict__ col
         for (int u = 0; u < UNROLL; ++u) {
             sum[u] = T(0);
             const uint64_t s = start[u], e = end[u];
-            for (uint64_t k = (s & ~uint64_t(3)) + 4u * lane; k < e; k += 4u * LANES) {
-                uint32_t c[4];
-                T v[4];
-                load_chunk<T>(col, val, k, nnz, c, v);
+            if constexpr (sizeof(T) == 8) {
+                // f64 (round 4): a lane's 32 bytes of values per pass are TWO 16-byte pieces -- entries 2 lane, 2 lane + 1 and 2 LANES +
+                // 2 lane, 2 LANES + 2 lane + 1 of the pass -- so that each load instruction of the lane group covers contiguous bytes
+                // (K1r's lesson, spmv_ring2.hip lane_pos): the same slots, the same order of FMAs per lane as K1r, hence its bits.
+                for (uint64_t kb = s & ~uint64_t(3); kb + 2u * lane < e; kb += 4u * LANES) {
+                    uint32_t c[4];
+                    T v[4];
+                    const uint64_t i0 = kb + 2u * lane, i1 = kb + 2u * LANES + 2u * lane;
+                    load_pair<T>(col, val, i0, nnz, c[0], c[1], v[0], v[1]);
+                    load_pair<T>(col, val, i1, nnz, c[2], c[3], v[2], v[3]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint64_t idx = k + j;
-                    if (idx >= s && idx < e) sum[u] = fma_t(v[j], x[c[j]], sum[u]);
+                    for (int j = 0; j < 4; ++j) {
+                        const uint64_t idx = (j < 2 ? i0 : i1 - 2u) + (uint64_t)j;
+                        if (idx >= s && idx < e) sum[u] = fma_t(v[j], x[c[j]], sum[u]);
+                    }
+                }
+            } else {
+                for (uint64_t k = (s & ~uint64_t(3)) + 4u * lane; k < e; k += 4u * LANES) {
+                    uint32_t c[4];
+                    T v[4];
+                    load_chunk<T>(col, val, k, nnz, c, v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint64_t idx = k + j;
+                        if (idx >= s && idx < e) sum[u] = fma_t(v[j], x[c[j]], sum[u]);
+                    }
                 }
             }
         }

@@ -252,30 +252,32 @@ def test_ring_small_and_edge_shapes(gpu):
             assert_spmv_close(m.mvp(x, variant="vector"), off, col, val, x, "%dx%d lanes%d" % (n_rows, n_cols, lanes))
 
 
-def test_k1_is_k1r_bit_for_bit_in_f32(gpu):
-    """The plain lane-group kernel (VECTOR with the ring off) and the LDS-ring kernel share lanes, chunk grid and the order of their
-    FMAs; in f32 their results are the same bits.  The partition relies on it: a block's few boundary rows go through K1 (a hundred
-    small workgroups) while the interior goes through K1r (spmv_enqueue_rows_short, capi.hip).  (f64: K1r's line-load layout of round 4
-    pairs other entries per lane; there the boundary rows stay with K1r.)"""
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_k1_is_k1r_bit_for_bit(gpu, dtype):
+    """The plain lane-group kernel (VECTOR with the ring off) and the LDS-ring kernel share lanes, chunk grid, lane layout (f64: two
+    16-byte pieces per lane and pass in both) and the order of their FMAs: their results are the same bits.  The partition relies on
+    it: a block's few boundary rows go through K1 (a hundred small workgroups) while the interior goes through K1r
+    (spmv_enqueue_rows_short, capi.hip)."""
     rng = np.random.default_rng(5)
-    cases = [synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_WINDOW, 400_000, 32, np.float32),
-             synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, 200_000, 7, np.float32)]
+    u = np.uint32 if dtype == np.float32 else np.uint64
+    cases = [synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_WINDOW, 400_000, 32, dtype),
+             synth.crs_fixed(synth.SEED_MATRIX, synth.PATTERN_BANDED, 200_000, 7, dtype)]
     n_rows = 60_000
     lens = rng.integers(0, 90, n_rows)
     off = np.zeros(n_rows + 1, np.uint32)
     np.cumsum(lens, out=off[1:])
     centers = np.repeat(np.arange(n_rows), lens)
     col = np.clip(centers + rng.integers(-3000, 3000, len(centers)), 0, n_rows - 1).astype(np.uint32)
-    cases.append(sm.SparseMatCRS.from_raw_parts(n_rows, n_rows, off, col, rng.uniform(-1, 1, len(col)).astype(np.float32)))
+    cases.append(sm.SparseMatCRS.from_raw_parts(n_rows, n_rows, off, col, rng.uniform(-1, 1, len(col)).astype(dtype)))
     # a stencil (the banded ring: four bands) and rows of 64 entries in a +-8000 band (the wide ring)
-    off, col, val = oracle.laplace3d(48, 40, 36, np.float32)
+    off, col, val = oracle.laplace3d(48, 40, 36, dtype)
     cases.append(sm.SparseMatCRS.from_raw_parts(48 * 40 * 36, 48 * 40 * 36, off, col, val))
     n_rows = 120_000
     off = (np.arange(n_rows + 1, dtype=np.uint64) * 64).astype(np.uint32)
     col = np.clip(np.repeat(np.arange(n_rows), 64) + rng.integers(-8000, 8000, n_rows * 64), 0, n_rows - 1).astype(np.uint32)
-    cases.append(sm.SparseMatCRS.from_raw_parts(n_rows, n_rows, off, col, rng.uniform(-1, 1, len(col)).astype(np.float32)))
+    cases.append(sm.SparseMatCRS.from_raw_parts(n_rows, n_rows, off, col, rng.uniform(-1, 1, len(col)).astype(dtype)))
     for m in cases:
-        x = rng.uniform(-1, 1, m.n_cols()).astype(np.float32)
+        x = rng.uniform(-1, 1, m.n_cols()).astype(dtype)
         for lanes in (0, 4, 8, 16):
             m.set_vector_lanes(lanes)
             m.set_ring(1)
@@ -283,4 +285,4 @@ def test_k1_is_k1r_bit_for_bit_in_f32(gpu):
             y1 = m.mvp(x, variant="vector")
             m.set_ring(0)
             y0 = m.mvp(x, variant="vector")
-            assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32)), lanes
+            assert np.array_equal(y1.view(u), y0.view(u)), lanes
